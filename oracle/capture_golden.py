@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ -- TEST INFRASTRUCTURE, container only.
+
+Runs the GENUINE reference (oracle/_ref/ref_harness, built by `make -C oracle ref`
+from /root/reference/src) on small generated periodic meshes and stores its
+inputs and outputs as compressed .npz fixtures.  The fixtures are data (arrays
+in, arrays out); no reference source travels.
+
+    python oracle/capture_golden.py            # all cases
+    python oracle/capture_golden.py hex_p2_n3_deformed
+
+Each fixture holds: the case description (`meta_json`), the mesh vertices
+(`xv`) and the arrays named in oracle/ref_harness.cpp.
+"""
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+from gen_neu_mesh import write_neu  # noqa: E402
+
+REF_HOME = os.environ.get("HIFILES_HOME", "/root/reference")
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# fluid / free-stream block of the shipped TGV case
+# (/root/reference/testcases/navier-stokes/Taylor_Green_vortex/input_TGV_SD_hex:96-117)
+TGV_FLUID = dict(
+    gamma=1.4, prandtl=0.72, S_gas=120.0, T_gas=291.15, R_gas=286.9, mu_gas=1.827e-05,
+    fix_vis=1, Mach_free_stream=0.1, rho_free_stream=0.0008421095852102401,
+    L_free_stream=1.0, T_free_stream=300.0,
+    rho_c_ic=0.0008421095852102401, Mach_c_ic=0.1, T_c_ic=300.0,
+)
+
+BASE = dict(
+    equation=0, viscous=1, riemann_solve_type=3, vis_riemann_solve_type=0,
+    ic_form=7, test_case=0, order=2, dt_type=0, dt=0.00001440389, n_steps=1, adv_type=3,
+    LES=0, restart_flag=0, mesh_file="mesh.neu",
+    dx_cyclic=6.2831853071795862, dy_cyclic=6.2831853071795862, dz_cyclic=6.2831853071795862,
+    p_res=2, write_type=0, monitor_res_freq=100000, plot_freq=100000000, restart_dump_freq=100000000,
+    res_norm_type=1, error_norm_type=1,
+    upts_type_quad=0, vcjh_scheme_quad=1, eta_quad=0.0, sparse_quad=0,
+    upts_type_hexa=0, vcjh_scheme_hexa=1, eta_hexa=0.0, sparse_hexa=0,
+    sparse_tri=0, sparse_tet=0, sparse_pri=0,
+    bc_Cyclic_type="cyclic",
+)
+BASE.update(TGV_FLUID)
+
+
+def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, **over):
+    d = dict(BASE)
+    d.update(over)
+    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d)
+
+
+CASES = [
+    # full dump of every intermediate of one residual on a deformed mesh
+    case("hex_p2_n3_deformed", amp=0.15, level=2, order=2, steps=2),
+    # uniform mesh: exact-zero normal components exercise the LDG tie-breaks (inters.cpp:568-581)
+    case("hex_p2_n3_uniform", amp=0.0, level=1, order=2, steps=2),
+    # the headline polynomial order
+    case("hex_p4_n3_deformed", amp=0.15, level=1, order=4, steps=1),
+    # variants on tiny P1 cases: time schemes, Riemann solvers, Sutherland viscosity, correction functions
+    case("hex_p1_rk_euler", amp=0.1, order=1, adv_type=0, steps=2),
+    case("hex_p1_rk24", amp=0.1, order=1, adv_type=1, steps=2),
+    case("hex_p1_rk34", amp=0.1, order=1, adv_type=2, steps=2),
+    case("hex_p1_rk414", amp=0.1, order=1, adv_type=4, steps=1),
+    case("hex_p1_rusanov", amp=0.1, order=1, riemann_solve_type=0),
+    case("hex_p1_roem", amp=0.1, order=1, riemann_solve_type=2),
+    case("hex_p1_sutherland", amp=0.1, order=1, fix_vis=0, T_c_ic=350.0),
+    case("hex_p1_ldg_tau", amp=0.1, order=1, ldg_tau=0.3, ldg_beta=0.25),
+    case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
+    case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
+    case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+]
+
+
+def read_dump(path):
+    out = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    off = 0
+    while off < len(data):
+        (nl,) = struct.unpack_from("<i", data, off); off += 4
+        name = data[off:off + nl].decode(); off += nl
+        dtype = chr(data[off]); off += 1
+        (nd,) = struct.unpack_from("<i", data, off); off += 4
+        dims = struct.unpack_from("<%dq" % nd, data, off); off += 8 * nd
+        n = int(np.prod(dims))
+        if dtype == "d":
+            a = np.frombuffer(data, dtype="<f8", count=n, offset=off); off += 8 * n
+        else:
+            a = np.frombuffer(data, dtype="<i4", count=n, offset=off); off += 4 * n
+        # hf_array is column-major (include/hf_array.h:303-325)
+        out[name] = np.array(a).reshape(dims, order="F")
+    return out
+
+
+def run_case(c):
+    with tempfile.TemporaryDirectory() as td:
+        xv = write_neu(os.path.join(td, "mesh.neu"), c["n"], c["dims"], amp=c["amp"])
+        keys = dict(c["keys"])
+        keys["n_steps"] = c["steps"]
+        if c["dims"] == 2:
+            keys.pop("dz_cyclic")
+        with open(os.path.join(td, "input"), "w") as f:
+            for k, v in keys.items():
+                f.write("%s %s\n" % (k, repr(v) if isinstance(v, float) else v))
+        env = dict(os.environ, HIFILES_HOME=REF_HOME)
+        r = subprocess.run([HARNESS, "input", "dump.bin", str(c["steps"]), str(c["level"])],
+                           cwd=td, env=env, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout[-3000:] + r.stderr[-3000:])
+            raise SystemExit("harness failed for " + c["name"])
+        arrs = read_dump(os.path.join(td, "dump.bin"))
+    arrs["xv"] = xv
+    meta = dict(name=c["name"], n=c["n"], dims=c["dims"], amp=c["amp"], steps=c["steps"],
+                level=c["level"], keys=c["keys"],
+                generator="oracle/capture_golden.py via oracle/_ref/ref_harness (genuine reference)")
+    arrs["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    os.makedirs(GOLDEN, exist_ok=True)
+    out = os.path.join(GOLDEN, c["name"] + ".npz")
+    np.savez_compressed(out, **arrs)
+    print("%-24s %8.1f kB  %d arrays" % (c["name"], os.path.getsize(out) / 1e3, len(arrs)))
+
+
+if __name__ == "__main__":
+    want = sys.argv[1:]
+    for c in CASES:
+        if not want or c["name"] in want:
+            run_case(c)

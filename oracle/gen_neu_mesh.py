@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Periodic box mesh writer in Gambit neutral (.neu) format -- TEST INFRASTRUCTURE.
+
+Writes the input the genuine reference solver (oracle/_ref) reads, following the
+format parsed by /root/reference/src/mesh_reader.cpp:105-393 (6-line header,
+counts line, NODAL COORDINATES, ELEMENTS/CELLS, BOUNDARY CONDITIONS).
+
+Conventions (re-derived from mesh_reader.cpp:241 and
+eles_hexas.cpp:1198-1214): an 8-node brick record lists file nodes f0..f7 which
+the reader stores in shape slots 0,2,4,6,1,3,5,7; shape slot s = r + 2 s + 4 t.
+We choose (r,s,t) = (x,y,z), so file order is the slots [0,2,4,6,1,3,5,7].
+Quads (mesh_reader.cpp:209): file order f0 f1 f2 f3 -> slots 0,1,3,2.
+
+Elements are numbered x-fastest: e = ix + nx*(iy + ny*iz); vertices
+v = ix + (nx+1)*(iy + (ny+1)*iz) (1-based in the file).
+Optional smooth periodic deformation of the vertices (amp != 0) makes the
+Jacobian non-constant and the face normals generic.
+"""
+import argparse
+import math
+import numpy as np
+
+
+def box_vertices(n, dims, length=2.0 * math.pi, amp=0.0):
+    """Vertex coordinates of the (possibly deformed) periodic box, shape (nv, dims)."""
+    n = list(n)
+    ax = [np.linspace(0.0, length, n[d] + 1) for d in range(dims)]
+    # exact end point so that opposite faces differ by exactly `length`
+    for a in ax:
+        a[-1] = length
+    if dims == 3:
+        Z, Y, X = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+        x, y, z = X.ravel().copy(), Y.ravel().copy(), Z.ravel().copy()
+        if amp != 0.0:
+            k = 2.0 * math.pi / length
+            dx = amp * np.sin(k * y + 0.3) * np.cos(k * z + 0.5)
+            dy = amp * np.cos(k * x + 0.7) * np.sin(k * z + 0.2)
+            dz = amp * np.sin(k * x + 0.1) * np.sin(k * y + 0.9)
+            # make the deformation bit-identical on periodic images
+            def wrap(v):
+                return np.where(np.isclose(v, length), 0.0, v)
+            xw, yw, zw = wrap(x), wrap(y), wrap(z)
+            dx = amp * np.sin(k * yw + 0.3) * np.cos(k * zw + 0.5)
+            dy = amp * np.cos(k * xw + 0.7) * np.sin(k * zw + 0.2)
+            dz = amp * np.sin(k * xw + 0.1) * np.sin(k * yw + 0.9)
+            x, y, z = x + dx, y + dy, z + dz
+        return np.stack([x, y, z], axis=1)
+    else:
+        Y, X = np.meshgrid(ax[1], ax[0], indexing="ij")
+        x, y = X.ravel().copy(), Y.ravel().copy()
+        if amp != 0.0:
+            k = 2.0 * math.pi / length
+            def wrap(v):
+                return np.where(np.isclose(v, length), 0.0, v)
+            xw, yw = wrap(x), wrap(y)
+            dx = amp * np.sin(k * yw + 0.3)
+            dy = amp * np.cos(k * xw + 0.7)
+            x, y = x + dx, y + dy
+        return np.stack([x, y], axis=1)
+
+
+def write_neu(path, n, dims=3, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
+    if isinstance(n, int):
+        n = [n] * dims
+    xv = box_vertices(n, dims, length, amp)
+    nv = xv.shape[0]
+    nx, ny = n[0], n[1]
+    nz = n[2] if dims == 3 else 1
+    ne = nx * ny * nz
+
+    def vid(i, j, k=0):
+        return 1 + i + (nx + 1) * (j + (ny + 1) * k)
+
+    with open(path, "w") as f:
+        f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\nperiodic_box\n")
+        f.write("PROGRAM:                Gambit     VERSION:  2.3.16\n\n")
+        f.write("     NUMNP     NELEM     NGRPS    NBSETS     NDFCD     NDFVL\n")
+        f.write("%10d%10d%10d%10d%10d%10d\n" % (nv, ne, 1, 1, dims, dims))
+        f.write("ENDOFSECTION\n   NODAL COORDINATES 2.3.16\n")
+        for i in range(nv):
+            f.write("%10d" % (i + 1) + "".join(" %.17e" % c for c in xv[i]) + "\n")
+        f.write("ENDOFSECTION\n      ELEMENTS/CELLS 2.3.16\n")
+        bfaces = []
+        e = 0
+        for k in range(nz):
+            for j in range(ny):
+                for i in range(nx):
+                    e += 1
+                    if dims == 3:
+                        slot = {}
+                        for t in range(2):
+                            for s in range(2):
+                                for r in range(2):
+                                    slot[r + 2 * s + 4 * t] = vid(i + r, j + s, k + t)
+                        order = [0, 2, 4, 6, 1, 3, 5, 7]
+                        nodes = [slot[o] for o in order]
+                        f.write("%8d %2d %2d " % (e, 4, 8) + "".join("%8d" % v for v in nodes[:7]) + "\n")
+                        f.write(" " * 15 + "%8d\n" % nodes[7])
+                        # gambit face ids (mesh_reader.cpp:336-350): code face 0<-1, 3<-2, 5<-3, 1<-4, 4<-5, 2<-6
+                        if k == 0: bfaces.append((e, 4, 1))       # z-min : code face 0
+                        if j == 0: bfaces.append((e, 4, 4))       # y-min : code face 1
+                        if i == nx - 1: bfaces.append((e, 4, 6))  # x-max : code face 2
+                        if j == ny - 1: bfaces.append((e, 4, 2))  # y-max : code face 3
+                        if i == 0: bfaces.append((e, 4, 5))       # x-min : code face 4
+                        if k == nz - 1: bfaces.append((e, 4, 3))  # z-max : code face 5
+                    else:
+                        # quad slots 0:(0,0) 1:(1,0) 2:(0,1) 3:(1,1); file order -> slots 0,1,3,2
+                        slot = {r + 2 * s: vid(i + r, j + s) for s in range(2) for r in range(2)}
+                        nodes = [slot[0], slot[1], slot[3], slot[2]]
+                        f.write("%8d %2d %2d " % (e, 2, 4) + "".join("%8d" % v for v in nodes) + "\n")
+                        # quad faces (eles_quads.cpp:209-248): 0: eta=-1, 1: xi=+1, 2: eta=+1, 3: xi=-1; gambit k = face+1
+                        if j == 0: bfaces.append((e, 2, 1))
+                        if i == nx - 1: bfaces.append((e, 2, 2))
+                        if j == ny - 1: bfaces.append((e, 2, 3))
+                        if i == 0: bfaces.append((e, 2, 4))
+        f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
+        f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n" % (1, ne, 2, 1))
+        f.write("                           fluid\n       0\n")
+        ids = list(range(1, ne + 1))
+        for s in range(0, ne, 10):
+            f.write("".join("%8d" % v for v in ids[s:s + 10]) + "\n")
+        f.write("ENDOFSECTION\n BOUNDARY CONDITIONS 2.3.16\n")
+        f.write("%32s%8d%8d%8d%8d\n" % (bcname, 1, len(bfaces), 0, 6))
+        for (el, ty, fc) in bfaces:
+            f.write("%10d%5d%5d\n" % (el, ty, fc))
+        f.write("ENDOFSECTION\n")
+    return xv
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("-n", type=int, default=3)
+    ap.add_argument("--dims", type=int, default=3)
+    ap.add_argument("--amp", type=float, default=0.0)
+    a = ap.parse_args()
+    write_neu(a.out, a.n, a.dims, amp=a.amp)

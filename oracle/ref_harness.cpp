@@ -1,0 +1,328 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE, container-only.
+//
+// Drives the GENUINE reference (compiled from /root/reference/src where the
+// sources lie, see oracle/Makefile) through the same sequence as
+// /root/reference/src/HiFiLES.cpp:113-217 (setup, GeoPreprocess, InitSolution,
+// RK loop of CalcResidual + AdvanceSolution) and dumps every array the hot
+// path consumes or produces into one binary file, which
+// oracle/capture_golden.py converts into the fixtures under tests/golden/.
+//
+// Nothing here is product code and nothing here travels to the GPU box
+// except the built binary under oracle/_ref/ (which cannot run there anyway
+// because it needs /root/reference/data).  No reference source is copied:
+// the reference headers are #included from /root/reference/include.
+//
+// usage: HIFILES_HOME=/root/reference ref_harness <input_file> <out.bin> <n_steps> <level>
+//   level 0: state after every stage only
+//   level 1: + operators, params, face tables, div_tconf of the first residual
+//   level 2: + metrics and every intermediate array of the first CalcResidual
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <iostream>
+#include <fstream>
+#include <sstream>
+#include <iomanip>
+#include <algorithm>
+#include <map>
+#include <cstdint>
+
+// The hot-path arrays are protected members of eles / inters
+// (include/eles.h:470-935, include/inters.h:86-126): open them for dumping.
+#define protected public
+#define private public
+#include "global.h"
+#include "geometry.h"
+#include "solver.h"
+#include "output.h"
+#include "solution.h"
+#include "mesh.h"
+#undef protected
+#undef private
+
+using namespace std;
+
+static FILE *g_out = NULL;
+
+static void put_header(const char *name, char dtype, const vector<int64_t> &dims)
+{
+  int32_t nl = (int32_t)strlen(name);
+  fwrite(&nl, 4, 1, g_out);
+  fwrite(name, 1, nl, g_out);
+  fwrite(&dtype, 1, 1, g_out);
+  int32_t nd = (int32_t)dims.size();
+  fwrite(&nd, 4, 1, g_out);
+  fwrite(dims.data(), 8, nd, g_out);
+}
+
+static void put_d(const string &name, const double *p, vector<int64_t> dims)
+{
+  int64_t n = 1;
+  for (auto d : dims) n *= d;
+  put_header(name.c_str(), 'd', dims);
+  fwrite(p, 8, n, g_out);
+}
+
+static void put_i(const string &name, const int32_t *p, vector<int64_t> dims)
+{
+  int64_t n = 1;
+  for (auto d : dims) n *= d;
+  put_header(name.c_str(), 'i', dims);
+  fwrite(p, 4, n, g_out);
+}
+
+static void put_arr(const string &name, hf_array<double> &a)
+{
+  vector<int64_t> dims;
+  // trailing unit dimensions are dropped, but keep at least one
+  int d[4] = {a.get_dim(0), a.get_dim(1), a.get_dim(2), a.get_dim(3)};
+  int nd = 4;
+  while (nd > 1 && d[nd - 1] == 1) nd--;
+  for (int i = 0; i < nd; i++) dims.push_back(d[i]);
+  put_d(name, a.get_ptr_cpu(), dims);
+}
+
+static void put_scalar(const string &name, double v) { put_d(name, &v, {1}); }
+
+// pointer table -> index table relative to the owning array
+static void put_ptr_table(const string &name, hf_array<double *> &t, double *base, int n0, int n1)
+{
+  vector<int32_t> idx((size_t)n0 * n1);
+  for (int i = 0; i < n1; i++)
+    for (int j = 0; j < n0; j++)
+      idx[j + (size_t)n0 * i] = (int32_t)(t(j, i) - base);
+  put_i(name, idx.data(), {n0, n1});
+}
+
+int main(int argc, char *argv[])
+{
+  if (argc < 5)
+  {
+    fprintf(stderr, "usage: ref_harness <input> <out.bin> <n_steps> <level>\n");
+    return 2;
+  }
+  int n_steps = atoi(argv[3]);
+  int level = atoi(argv[4]);
+
+  struct solution FlowSol;
+  mesh *mesh_data = new mesh();
+
+  run_input.setup(argv[1], 0);
+  SetInput(&FlowSol);
+  GeoPreprocess(&FlowSol, *mesh_data);
+  delete mesh_data;
+  InitSolution(&FlowSol);
+
+  int RKSteps = 1;
+  if (run_input.adv_type == 1 || run_input.adv_type == 2) RKSteps = 4;
+  else if (run_input.adv_type == 3) RKSteps = 5;
+  else if (run_input.adv_type == 4) RKSteps = 14;
+
+  g_out = fopen(argv[2], "wb");
+  if (!g_out) { perror("open out"); return 1; }
+
+  // which element class carries the mesh (fixtures are single-type meshes)
+  eles *E = NULL;
+  int etype = -1;
+  for (int i = 0; i < FlowSol.n_ele_types; i++)
+    if (FlowSol.mesh_eles(i)->get_n_eles() != 0)
+    {
+      if (E) { fprintf(stderr, "harness: mixed meshes not supported\n"); return 1; }
+      E = FlowSol.mesh_eles(i);
+      etype = i;
+    }
+  int n_eles = E->n_eles, n_upts = E->n_upts_per_ele, n_fpts = E->n_fpts_per_ele;
+  int n_fields = E->n_fields, n_dims = E->n_dims;
+
+  {
+    int32_t sizes[8] = {n_eles, n_upts, n_fpts, n_fields, n_dims, E->order, etype, RKSteps};
+    put_i("sizes", sizes, {8});
+  }
+
+  if (level >= 1)
+  {
+    // frozen scalars the path reads from run_input
+    put_scalar("gamma", run_input.gamma);
+    put_scalar("prandtl", run_input.prandtl);
+    put_scalar("rt_inf", run_input.rt_inf);
+    put_scalar("mu_inf", run_input.mu_inf);
+    put_scalar("c_sth", run_input.c_sth);
+    put_scalar("fix_vis", run_input.fix_vis);
+    put_scalar("dt", run_input.dt);
+    put_scalar("ldg_beta", run_input.ldg_beta);
+    put_scalar("ldg_tau", run_input.ldg_tau);
+    put_scalar("viscous", run_input.viscous);
+    put_scalar("riemann_solve_type", run_input.riemann_solve_type);
+    put_scalar("vis_riemann_solve_type", run_input.vis_riemann_solve_type);
+    put_scalar("adv_type", run_input.adv_type);
+    put_scalar("dt_type", run_input.dt_type);
+    put_scalar("R_ref", run_input.R_ref);
+    put_scalar("p_c_ic", run_input.p_c_ic);
+    put_scalar("rho_c_ic", run_input.rho_c_ic);
+    put_scalar("T_c_ic", run_input.T_c_ic);
+    put_scalar("uvw_c_ic", run_input.uvw_c_ic);
+    put_scalar("uvw_ref", run_input.uvw_ref);
+    put_arr("RK_a", run_input.RK_a);
+    put_arr("RK_b", run_input.RK_b);
+
+    put_arr("opp_0", E->opp_0);
+    put_arr("opp_3", E->opp_3);
+    for (int d = 0; d < n_dims; d++)
+    {
+      string s = to_string(d);
+      put_arr("opp_1_" + s, E->opp_1(d));
+      put_arr("opp_2_" + s, E->opp_2(d));
+      if (run_input.viscous)
+      {
+        put_arr("opp_4_" + s, E->opp_4(d));
+        put_arr("opp_5_" + s, E->opp_5(d));
+      }
+    }
+    if (run_input.viscous) put_arr("opp_6", E->opp_6);
+    put_arr("loc_upts", E->loc_upts);
+    put_arr("tloc_fpts", E->tloc_fpts);
+    put_arr("tnorm_fpts", E->tnorm_fpts);
+    put_arr("shape", E->shape);
+
+    // interior face tables as offsets into the owning element arrays
+    for (int t = 0; t < FlowSol.n_int_inter_types; t++)
+    {
+      int_inters &I = FlowSol.mesh_int_inters(t);
+      if (I.n_inters == 0) continue;
+      string s = "int" + to_string(t) + "_";
+      int nf = I.n_fpts_per_inter, ni = I.n_inters;
+      // field-0 plane; consistency of the other fields / arrays is asserted below
+      vector<int32_t> L((size_t)nf * ni), R((size_t)nf * ni);
+      double *base = E->disu_fpts.get_ptr_cpu();
+      double *base_tc = E->norm_tconf_fpts.get_ptr_cpu();
+      for (int i = 0; i < ni; i++)
+        for (int j = 0; j < nf; j++)
+        {
+          L[j + (size_t)nf * i] = (int32_t)(I.disu_fpts_l(j, i, 0) - base);
+          R[j + (size_t)nf * i] = (int32_t)(I.disu_fpts_r(j, i, 0) - base);
+          for (int k = 0; k < n_fields; k++)
+          {
+            if (I.disu_fpts_l(j, i, k) - base != L[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles ||
+                I.disu_fpts_r(j, i, k) - base != R[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles ||
+                I.norm_tconf_fpts_l(j, i, k) - base_tc != L[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles ||
+                I.norm_tconf_fpts_r(j, i, k) - base_tc != R[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles)
+            {
+              fprintf(stderr, "harness: face table layout assumption violated\n");
+              return 1;
+            }
+          }
+          if (I.tdA_fpts_l(j, i) - E->tdA_fpts.get_ptr_cpu() != L[j + (size_t)nf * i] ||
+              I.tdA_fpts_r(j, i) - E->tdA_fpts.get_ptr_cpu() != R[j + (size_t)nf * i] ||
+              I.norm_fpts(j, i, 0) - E->norm_fpts.get_ptr_cpu() != L[j + (size_t)nf * i])
+          {
+            fprintf(stderr, "harness: face metric table layout assumption violated\n");
+            return 1;
+          }
+        }
+      put_i(s + "L", L.data(), {nf, ni});
+      put_i(s + "R", R.data(), {nf, ni});
+    }
+  }
+  if (level >= 2)
+  {
+    put_arr("detjac_upts", E->detjac_upts);
+    put_arr("JGinv_upts", E->JGinv_upts);
+    put_arr("detjac_fpts", E->detjac_fpts);
+    put_arr("JGinv_fpts", E->JGinv_fpts);
+    put_arr("tdA_fpts", E->tdA_fpts);
+    put_arr("norm_fpts", E->norm_fpts);
+    put_arr("pos_upts", E->pos_upts);
+    put_arr("pos_fpts", E->pos_fpts);
+  }
+
+  put_arr("u_init", E->disu_upts(0));
+
+  for (int step = 0; step < n_steps; step++)
+  {
+    calc_time_step(&FlowSol);
+    for (int rk = 0; rk < RKSteps; rk++)
+    {
+      if (step == 0 && rk == 0 && level >= 1)
+      {
+        // the sequence of CalcResidual (src/solver.cpp:50-223) for a
+        // single-rank, LES-off, RANS-off, forcing-off run, with dumps between calls
+        int i;
+        for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->extrapolate_solution();
+        if (level >= 2) put_arr("s0_disu_fpts", E->disu_fpts);
+        if (run_input.viscous)
+        {
+          for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->calculate_gradient();
+          if (level >= 2) put_arr("s0_grad_disu_upts_ref", E->grad_disu_upts);
+        }
+        if (run_input.over_int)
+          for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->evaluate_invFlux_over_int();
+        else
+          for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->evaluate_invFlux();
+        if (level >= 2) put_arr("s0_tdisf_upts_inv", E->tdisf_upts);
+        for (i = 0; i < FlowSol.n_int_inter_types; i++) FlowSol.mesh_int_inters(i).calculate_common_invFlux();
+        for (i = 0; i < FlowSol.n_bdy_inter_types; i++)
+          FlowSol.mesh_bdy_inters(i).evaluate_boundaryConditions_invFlux(&FlowSol, FlowSol.time);
+        if (level >= 2)
+        {
+          put_arr("s0_norm_tconf_fpts_inv", E->norm_tconf_fpts);
+          if (run_input.viscous) put_arr("s0_delta_disu_fpts", E->delta_disu_fpts);
+        }
+        if (run_input.viscous)
+        {
+          for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->correct_gradient();
+          if (level >= 2)
+          {
+            put_arr("s0_grad_disu_upts", E->grad_disu_upts);
+            put_arr("s0_grad_disu_fpts", E->grad_disu_fpts);
+          }
+          for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->evaluate_viscFlux();
+          if (level >= 2) put_arr("s0_tdisf_upts", E->tdisf_upts);
+        }
+        for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->extrapolate_totalFlux();
+        if (level >= 2) put_arr("s0_norm_tdisf_fpts", E->norm_tdisf_fpts);
+        for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->calculate_divergence();
+        if (level >= 2) put_arr("s0_div_tconf_upts_disc", E->div_tconf_upts(0));
+        if (run_input.viscous)
+        {
+          for (i = 0; i < FlowSol.n_int_inter_types; i++) FlowSol.mesh_int_inters(i).calculate_common_viscFlux();
+          for (i = 0; i < FlowSol.n_bdy_inter_types; i++)
+            FlowSol.mesh_bdy_inters(i).evaluate_boundaryConditions_viscFlux(FlowSol.time);
+          if (level >= 2) put_arr("s0_norm_tconf_fpts", E->norm_tconf_fpts);
+        }
+        for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->calculate_corrected_divergence();
+        put_arr("s0_div_tconf_upts", E->div_tconf_upts(0));
+        // residual norms as the reference's monitor computes them (eles.cpp:5045-5074):
+        // L1 / L2 sums over all upts of |div_tconf/detjac - src|
+        vector<double> res(2 * n_fields);
+        for (int f = 0; f < n_fields; f++)
+        {
+          res[f] = E->compute_res_upts(1, f);
+          res[n_fields + f] = E->compute_res_upts(2, f);
+        }
+        put_d("s0_res_sums", res.data(), {2, n_fields});
+      }
+      else
+        CalcResidual(FlowSol.ini_iter + step, rk, &FlowSol);
+
+      for (int j = 0; j < FlowSol.n_ele_types; j++)
+        FlowSol.mesh_eles(j)->AdvanceSolution(rk, run_input.adv_type);
+      if (run_input.shock_cap)
+        for (int j = 0; j < FlowSol.n_ele_types; j++) FlowSol.mesh_eles(j)->shock_capture();
+
+      if (level >= 1 || rk == RKSteps - 1)
+      {
+        char nm[64];
+        snprintf(nm, sizeof nm, "u_step%d_stage%d", step, rk);
+        put_arr(nm, E->disu_upts(0));
+      }
+    }
+    FlowSol.time += run_input.dt;
+    run_input.time = FlowSol.time;
+  }
+  fclose(g_out);
+  return 0;
+}
