@@ -1,0 +1,813 @@
+/* oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  See oracle.h.
+ *
+ * CPU restatement of the reference's hot path.  Every function cites the
+ * reference file:line it follows; loop nests and summation orders are kept so
+ * that results agree with the genuine reference to rounding (the fixtures in
+ * tests/golden pin that).  OpenMP only distributes independent columns /
+ * points / faces over threads; it never changes a summation order.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+
+void orc_set_threads(int n)
+{
+  g_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+  omp_set_num_threads(g_threads);
+#endif
+}
+
+#define MAXF 6 /* n_fields <= 5 here; room for an SA field */
+#define MAXD 3
+
+/* ------------------------------------------------------------------------ */
+/* src/funcs.cpp:49-123 : C := alpha*A*B + beta*C, column-major, no transposes.
+ * For each column j, for l ascending: C(:,j) += (alpha*B(l,j)) * A(:,l).    */
+void orc_dgemm(int Arows, int Bcols, int Acols, double alpha, double beta,
+               const double *a, const double *b, double *c)
+{
+  if (Arows == 0 || Bcols == 0 || ((alpha == 0. || Acols == 0) && beta == 1.)) return;
+  if (alpha == 0.)
+  {
+    for (long j = 0; j < Bcols; j++)
+      for (int i = 0; i < Arows; i++)
+        c[i + j * Arows] = (beta == 0.) ? 0. : beta * c[i + j * Arows];
+    return;
+  }
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (long j = 0; j < Bcols; j++)
+  {
+    double *cj = c + j * (long)Arows;
+    const double *bj = b + j * (long)Acols;
+    if (beta == 0.)
+      for (int i = 0; i < Arows; i++) cj[i] = 0.;
+    else if (beta != 1.)
+      for (int i = 0; i < Arows; i++) cj[i] = beta * cj[i];
+    for (int l = 0; l < Acols; l++)
+    {
+      double temp = alpha * bj[l];
+      const double *al = a + (long)l * Arows;
+      for (int i = 0; i < Arows; i++) cj[i] += temp * al[i];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/flux.cpp:33-72 (2-D), :74-125 (3-D); f(k,m) = f[k + n_fields*m]      */
+void orc_calc_invf(int n_dims, double gamma, const double *u, double *f)
+{
+  if (n_dims == 2)
+  {
+    const int nf = 4;
+    double vx = u[1] / u[0];
+    double vy = u[2] / u[0];
+    double p = (gamma - 1.0) * (u[3] - (0.5 * u[0] * ((vx * vx) + (vy * vy))));
+    f[0 + nf * 0] = u[1];
+    f[1 + nf * 0] = p + (u[1] * vx);
+    f[2 + nf * 0] = u[2] * vx;
+    f[3 + nf * 0] = vx * (u[3] + p);
+    f[0 + nf * 1] = u[2];
+    f[1 + nf * 1] = u[1] * vy;
+    f[2 + nf * 1] = p + (u[2] * vy);
+    f[3 + nf * 1] = vy * (u[3] + p);
+  }
+  else
+  {
+    const int nf = 5;
+    double vx = u[1] / u[0];
+    double vy = u[2] / u[0];
+    double vz = u[3] / u[0];
+    double p = (gamma - 1.0) * (u[4] - (0.5 * u[0] * ((vx * vx) + (vy * vy) + (vz * vz))));
+    f[0 + nf * 0] = u[1];
+    f[1 + nf * 0] = p + (u[1] * vx);
+    f[2 + nf * 0] = u[2] * vx;
+    f[3 + nf * 0] = u[3] * vx;
+    f[4 + nf * 0] = vx * (u[4] + p);
+    f[0 + nf * 1] = u[2];
+    f[1 + nf * 1] = u[1] * vy;
+    f[2 + nf * 1] = p + (u[2] * vy);
+    f[3 + nf * 1] = u[3] * vy;
+    f[4 + nf * 1] = vy * (u[4] + p);
+    f[0 + nf * 2] = u[3];
+    f[1 + nf * 2] = u[1] * vz;
+    f[2 + nf * 2] = u[2] * vz;
+    f[3 + nf * 2] = p + (u[3] * vz);
+    f[4 + nf * 2] = vz * (u[4] + p);
+  }
+}
+
+/* src/flux.cpp:129-254 (2-D), :257-422 (3-D); RANS off (mu_t = 0).
+ * grad_u(k,m) = g[k + n_fields*m]                                           */
+void orc_calc_visf(int n_dims, const orc_params *P, const double *u, const double *g, double *f)
+{
+  const double gamma = P->gamma;
+  if (n_dims == 2)
+  {
+    const int nf = 4;
+    double rho = u[0], mom_x = u[1], mom_y = u[2], ene = u[3];
+    double rho_dx = g[0], mom_x_dx = g[1], mom_y_dx = g[2], ene_dx = g[3];
+    double rho_dy = g[0 + nf], mom_x_dy = g[1 + nf], mom_y_dy = g[2 + nf], ene_dy = g[3 + nf];
+    double uu = mom_x / rho, v = mom_y / rho;
+    double inte = ene / rho - 0.5 * (uu * uu + v * v);
+    double rt_ratio = (gamma - 1.0) * inte / (P->rt_inf);
+    double mu = (P->mu_inf) * pow(rt_ratio, 1.5) * (1. + (P->c_sth)) / (rt_ratio + (P->c_sth));
+    mu = mu + P->fix_vis * (P->mu_inf - mu);
+    double mu_t = 0.0;
+    double du_dx = (mom_x_dx - rho_dx * uu) / rho;
+    double du_dy = (mom_x_dy - rho_dy * uu) / rho;
+    double dv_dx = (mom_y_dx - rho_dx * v) / rho;
+    double dv_dy = (mom_y_dy - rho_dy * v) / rho;
+    double dke_dx = 0.5 * (uu * uu + v * v) * rho_dx + rho * (uu * du_dx + v * dv_dx);
+    double dke_dy = 0.5 * (uu * uu + v * v) * rho_dy + rho * (uu * du_dy + v * dv_dy);
+    double de_dx = (ene_dx - dke_dx - rho_dx * inte) / rho;
+    double de_dy = (ene_dy - dke_dy - rho_dy * inte) / rho;
+    double diag = (du_dx + dv_dy) / 3.0;
+    double tauxx = 2.0 * (mu + mu_t) * (du_dx - diag);
+    double tauxy = (mu + mu_t) * (du_dy + dv_dx);
+    double tauyy = 2.0 * (mu + mu_t) * (dv_dy - diag);
+    /* mu_t/prandtl_t term is exactly 0 with RANS off */
+    f[0] = 0.0;
+    f[1] = -tauxx;
+    f[2] = -tauxy;
+    f[3] = -(uu * tauxx + v * tauxy + (mu / P->prandtl + 0.0) * (gamma)*de_dx);
+    f[0 + nf] = 0.0;
+    f[1 + nf] = -tauxy;
+    f[2 + nf] = -tauyy;
+    f[3 + nf] = -(uu * tauxy + v * tauyy + (mu / P->prandtl + 0.0) * (gamma)*de_dy);
+  }
+  else
+  {
+    const int nf = 5;
+    double rho = u[0], mom_x = u[1], mom_y = u[2], mom_z = u[3], ene = u[4];
+    double rho_dx = g[0], mom_x_dx = g[1], mom_y_dx = g[2], mom_z_dx = g[3], ene_dx = g[4];
+    double rho_dy = g[0 + nf], mom_x_dy = g[1 + nf], mom_y_dy = g[2 + nf], mom_z_dy = g[3 + nf], ene_dy = g[4 + nf];
+    double rho_dz = g[0 + 2 * nf], mom_x_dz = g[1 + 2 * nf], mom_y_dz = g[2 + 2 * nf], mom_z_dz = g[3 + 2 * nf],
+           ene_dz = g[4 + 2 * nf];
+    double uu = mom_x / rho, v = mom_y / rho, w = mom_z / rho;
+    double inte = ene / rho - 0.5 * (uu * uu + v * v + w * w);
+    double rt_ratio = (gamma - 1.0) * inte / (P->rt_inf);
+    double mu = (P->mu_inf) * pow(rt_ratio, 1.5) * (1 + (P->c_sth)) / (rt_ratio + (P->c_sth));
+    mu = mu + P->fix_vis * (P->mu_inf - mu);
+    double mu_t = 0.0;
+    double du_dx = (mom_x_dx - rho_dx * uu) / rho;
+    double du_dy = (mom_x_dy - rho_dy * uu) / rho;
+    double du_dz = (mom_x_dz - rho_dz * uu) / rho;
+    double dv_dx = (mom_y_dx - rho_dx * v) / rho;
+    double dv_dy = (mom_y_dy - rho_dy * v) / rho;
+    double dv_dz = (mom_y_dz - rho_dz * v) / rho;
+    double dw_dx = (mom_z_dx - rho_dx * w) / rho;
+    double dw_dy = (mom_z_dy - rho_dy * w) / rho;
+    double dw_dz = (mom_z_dz - rho_dz * w) / rho;
+    double dke_dx = 0.5 * (uu * uu + v * v + w * w) * rho_dx + rho * (uu * du_dx + v * dv_dx + w * dw_dx);
+    double dke_dy = 0.5 * (uu * uu + v * v + w * w) * rho_dy + rho * (uu * du_dy + v * dv_dy + w * dw_dy);
+    double dke_dz = 0.5 * (uu * uu + v * v + w * w) * rho_dz + rho * (uu * du_dz + v * dv_dz + w * dw_dz);
+    double de_dx = (ene_dx - dke_dx - rho_dx * inte) / rho;
+    double de_dy = (ene_dy - dke_dy - rho_dy * inte) / rho;
+    double de_dz = (ene_dz - dke_dz - rho_dz * inte) / rho;
+    double diag = (du_dx + dv_dy + dw_dz) / 3.0;
+    double tauxx = 2.0 * (mu + mu_t) * (du_dx - diag);
+    double tauyy = 2.0 * (mu + mu_t) * (dv_dy - diag);
+    double tauzz = 2.0 * (mu + mu_t) * (dw_dz - diag);
+    double tauxy = (mu + mu_t) * (du_dy + dv_dx);
+    double tauxz = (mu + mu_t) * (du_dz + dw_dx);
+    double tauyz = (mu + mu_t) * (dv_dz + dw_dy);
+    f[0] = 0.0;
+    f[1] = -tauxx;
+    f[2] = -tauxy;
+    f[3] = -tauxz;
+    f[4] = -(uu * tauxx + v * tauxy + w * tauxz + (mu / P->prandtl + 0.0) * (gamma)*de_dx);
+    f[0 + nf] = 0.0;
+    f[1 + nf] = -tauxy;
+    f[2 + nf] = -tauyy;
+    f[3 + nf] = -tauyz;
+    f[4 + nf] = -(uu * tauxy + v * tauyy + w * tauyz + (mu / P->prandtl + 0.0) * (gamma)*de_dy);
+    f[0 + 2 * nf] = 0.0;
+    f[1 + 2 * nf] = -tauxz;
+    f[2 + 2 * nf] = -tauyz;
+    f[3 + 2 * nf] = -tauzz;
+    f[4 + 2 * nf] = -(uu * tauxz + v * tauyz + w * tauzz + (mu / P->prandtl + 0.0) * (gamma)*de_dz);
+  }
+}
+
+/* normal flux fn_x(k) = sum_l f_x(k,l)*norm(l), starting from 0 (the BLAS=NO
+ * branches of src/inters.cpp:288-297, :463-473)                              */
+static void normal_fluxes(int nd, int nf, const double *fl, const double *fr, const double *norm, double *fn_l,
+                          double *fn_r)
+{
+  for (int k = 0; k < nf; k++)
+  {
+    fn_l[k] = 0.;
+    fn_r[k] = 0.;
+    for (int l = 0; l < nd; l++)
+    {
+      fn_l[k] += fl[k + nf * l] * norm[l];
+      fn_r[k] += fr[k + nf * l] * norm[l];
+    }
+  }
+}
+
+/* src/inters.cpp:277-324 */
+void orc_rusanov_flux(int nd, double gamma, const double *ul, const double *ur, const double *fl, const double *fr,
+                      const double *norm, double *fn)
+{
+  const int nf = nd + 2;
+  double fn_l[MAXF], fn_r[MAXF], v_l[MAXD], v_r[MAXD];
+  normal_fluxes(nd, nf, fl, fr, norm, fn_l, fn_r);
+  double vn_l = 0, vn_r = 0, vsq_l = 0, vsq_r = 0;
+  for (int i = 0; i < nd; i++)
+  {
+    v_l[i] = ul[i + 1] / ul[0];
+    v_r[i] = ur[i + 1] / ur[0];
+    vn_l += v_l[i] * norm[i];
+    vn_r += v_r[i] * norm[i];
+    vsq_l += pow(v_l[i], 2.);
+    vsq_r += pow(v_r[i], 2.);
+  }
+  double p_l = (gamma - 1.0) * (ul[nd + 1] - 0.5 * ul[0] * vsq_l);
+  double p_r = (gamma - 1.0) * (ur[nd + 1] - 0.5 * ur[0] * vsq_r);
+  double eig = sqrt(gamma * (p_l + p_r) / (ul[0] + ur[0])) + 0.5 * fabs(vn_l + vn_r);
+  for (int k = 0; k < nf; k++) fn[k] = 0.5 * ((fn_l[k] + fn_r[k]) - eig * (ur[k] - ul[k]));
+}
+
+/* src/inters.cpp:327-437 */
+void orc_roeM_flux(int nd, double gamma, const double *ul, const double *ur, const double *fl, const double *fr,
+                   const double *norm, double *fn)
+{
+  const int nf = nd + 2;
+  double v_l[MAXD], v_r[MAXD], va[MAXD], dv[MAXD];
+  double du[MAXF], bdq[MAXF], fn_l[MAXF], fn_r[MAXF];
+  double vn_l = 0., vsq_l = 0., vn_r = 0., vsq_r = 0.;
+  for (int i = 0; i < nd; i++)
+  {
+    v_l[i] = ul[i + 1] / ul[0];
+    v_r[i] = ur[i + 1] / ur[0];
+    vn_l += v_l[i] * norm[i];
+    vn_r += v_r[i] * norm[i];
+    vsq_l += v_l[i] * v_l[i];
+    vsq_r += v_r[i] * v_r[i];
+    dv[i] = v_r[i] - v_l[i];
+  }
+  double p_l = (gamma - 1.0) * (ul[nd + 1] - 0.5 * ul[0] * vsq_l);
+  double p_r = (gamma - 1.0) * (ur[nd + 1] - 0.5 * ur[0] * vsq_r);
+  double h_l = (ul[nd + 1] + p_l) / ul[0];
+  double h_r = (ur[nd + 1] + p_r) / ur[0];
+  double drho = ur[0] - ul[0];
+  double dp = p_r - p_l;
+  double dh = h_r - h_l;
+  double dvn = vn_r - vn_l;
+  double sq_rho = sqrt(ur[0] / ul[0]);
+  double rrho = 1.0 / (1.0 + sq_rho);
+  double ratr = sq_rho * rrho;
+  double ra = sq_rho * ul[0];
+  double ha = h_l * rrho + h_r * ratr;
+  double qq = 0., va_n = 0.;
+  for (int i = 0; i < nd; i++)
+  {
+    va[i] = v_l[i] * rrho + v_r[i] * ratr;
+    qq += va[i] * va[i];
+    va_n += norm[i] * va[i];
+  }
+  double aa = sqrt((gamma - 1) * (ha - 0.5 * qq));
+  double rcp_aa = 1.0 / aa;
+  double abs_ma = fabs(va_n * rcp_aa);
+  double b1 = fmax(0.0, fmax(va_n + aa, vn_r + aa));
+  double b2 = fmin(0.0, fmin(va_n - aa, vn_l - aa));
+  double b1b2 = b1 * b2;
+  double rcp_b1_b2 = 1.0 / (b1 - b2);
+  b1 = b1 * rcp_b1_b2;
+  b2 = b2 * rcp_b1_b2;
+  b1b2 = b1b2 * rcp_b1_b2;
+  double h = 1.0 - ((p_l < p_r) ? (p_l / p_r) : (p_r / p_l));
+  double f = ((abs_ma != 0) ? pow(abs_ma, h) : 1.);
+  double g = f / (1.0 + abs_ma);
+  for (int i = 0; i < nf - 1; i++) du[i] = ur[i] - ul[i];
+  du[nd + 1] = ur[0] * h_r - ul[0] * h_l;
+  bdq[0] = drho - f * dp * rcp_aa * rcp_aa;
+  bdq[nd + 1] = bdq[0] * ha + ra * dh;
+  for (int i = 0; i < nd; i++) bdq[i + 1] = bdq[0] * va[i] + ra * (dv[i] - norm[i] * dvn);
+  normal_fluxes(nd, nf, fl, fr, norm, fn_l, fn_r);
+  for (int i = 0; i < nf; i++) fn[i] = (b1 * fn_l[i] - b2 * fn_r[i]) + b1b2 * (du[i] - g * bdq[i]);
+}
+
+/* src/inters.cpp:439-532 */
+void orc_hllc_flux(int nd, double gamma, const double *ul, const double *ur, const double *fl, const double *fr,
+                   const double *norm, double *fn)
+{
+  const int nf = nd + 2;
+  double fn_l[MAXF], fn_r[MAXF], v_l[MAXD], v_r[MAXD];
+  double vn_l = 0., vsq_l = 0., vn_r = 0., vsq_r = 0.;
+  for (int i = 0; i < nd; i++)
+  {
+    v_l[i] = ul[i + 1] / ul[0];
+    v_r[i] = ur[i + 1] / ur[0];
+    vn_l += v_l[i] * norm[i];
+    vn_r += v_r[i] * norm[i];
+    vsq_l += v_l[i] * v_l[i];
+    vsq_r += v_r[i] * v_r[i];
+  }
+  double p_l = (gamma - 1.0) * (ul[nd + 1] - 0.5 * ul[0] * vsq_l);
+  double p_r = (gamma - 1.0) * (ur[nd + 1] - 0.5 * ur[0] * vsq_r);
+  double h_l = (ul[nd + 1] + p_l) / ul[0];
+  double h_r = (ur[nd + 1] + p_r) / ur[0];
+  normal_fluxes(nd, nf, fl, fr, norm, fn_l, fn_r);
+  double sq_rho = sqrt(ur[0] / ul[0]);
+  double rrho = 1. / (sq_rho + 1.);
+  double vn_m = rrho * (vn_l + sq_rho * vn_r);
+  double h_m = rrho * (h_l + sq_rho * h_r);
+  double a_m = sqrt((gamma - 1.) * (h_m - 0.5 * vn_m * vn_m));
+  double S_R = vn_m + a_m;
+  double S_L = vn_m - a_m;
+  double S_star = (p_r - p_l + ul[0] * vn_l * (S_L - vn_l) - ur[0] * vn_r * (S_R - vn_r)) /
+                  (ul[0] * (S_L - vn_l) - ur[0] * (S_R - vn_r));
+  if (S_L >= 0)
+    for (int k = 0; k < nf; k++) fn[k] = fn_l[k];
+  else
+  {
+    if (S_star >= 0)
+    {
+      double rcp_star = S_L - S_star;
+      fn[0] = S_star * (S_L * ul[0] - fn_l[0]) / rcp_star;
+      for (int i = 0; i < nd; i++)
+        fn[i + 1] = (S_star * (S_L * ul[i + 1] - fn_l[i + 1]) +
+                     S_L * (p_l + ul[0] * (S_L - vn_l) * (S_star - vn_l)) * norm[i]) /
+                    rcp_star;
+      fn[nd + 1] = (S_star * (S_L * ul[nd + 1] - fn_l[nd + 1]) +
+                    S_L * (p_l + ul[0] * (S_L - vn_l) * (S_star - vn_l)) * S_star) /
+                   rcp_star;
+    }
+    else
+    {
+      if (S_R >= 0)
+      {
+        double rcp_star = S_R - S_star;
+        fn[0] = S_star * (S_R * ur[0] - fn_r[0]) / rcp_star;
+        for (int i = 0; i < nd; i++)
+          fn[i + 1] = (S_star * (S_R * ur[i + 1] - fn_r[i + 1]) +
+                       S_R * (p_r + ur[0] * (S_R - vn_r) * (S_star - vn_r)) * norm[i]) /
+                      rcp_star;
+        fn[nd + 1] = (S_star * (S_R * ur[nd + 1] - fn_r[nd + 1]) +
+                      S_R * (p_r + ur[0] * (S_R - vn_r) * (S_star - vn_r)) * S_star) /
+                     rcp_star;
+      }
+      else
+        for (int k = 0; k < nf; k++) fn[k] = fn_r[k];
+    }
+  }
+}
+
+/* the "consistent switch" of src/inters.cpp:568-581 and :620-633.
+ * NOTE the reference reads norm(2) even in 2-D when n_x = n_y = 0, which a
+ * unit normal can never be, so the third test is only reached in 3-D.       */
+static double ldg_switch(int nd, double ldg_beta, const double *norm)
+{
+  if (ldg_beta != 0.)
+  {
+    if (norm[0] < 0.)
+      ldg_beta = -ldg_beta;
+    else if (norm[0] == 0.)
+    {
+      if ((norm[0] + norm[1]) < 0.)
+        ldg_beta = -ldg_beta;
+      else if ((norm[0] + norm[1]) == 0)
+      {
+        if (nd > 2 && (norm[0] + norm[2]) < 0.) ldg_beta = -ldg_beta;
+      }
+    }
+  }
+  return ldg_beta;
+}
+
+/* src/inters.cpp:561-611 */
+void orc_ldg_flux(int flux_spec, int nd, const double *ul, const double *ur, const double *fl, const double *fr,
+                  const double *norm, double *fn, double ldg_tau, double ldg_beta)
+{
+  const int nf = nd + 2;
+  double f_c[MAXF * MAXD];
+  if (flux_spec == 0)
+  {
+    ldg_beta = ldg_switch(nd, ldg_beta, norm);
+    for (int k = 0; k < nf; k++)
+      for (int i = 0; i < nd; i++)
+        f_c[k + nf * i] = (0.5 + ldg_beta) * fl[k + nf * i] + (0.5 - ldg_beta) * fr[k + nf * i];
+  }
+  else
+  {
+    for (int k = 0; k < nf; k++)
+      for (int i = 0; i < nd; i++) f_c[k + nf * i] = fr[k + nf * i];
+  }
+  for (int k = 0; k < nf; k++)
+  {
+    fn[k] = 0.;
+    for (int l = 0; l < nd; l++) fn[k] += f_c[k + nf * l] * norm[l];
+  }
+  for (int k = 0; k < nf; k++) fn[k] -= ldg_tau * (ur[k] - ul[k]);
+}
+
+/* src/inters.cpp:615-646 */
+void orc_ldg_solution(int flux_spec, int nd, const double *ul, const double *ur, double *uc, double ldg_beta,
+                      const double *norm)
+{
+  const int nf = nd + 2;
+  if (flux_spec == 0)
+  {
+    ldg_beta = ldg_switch(nd, ldg_beta, norm);
+    for (int k = 0; k < nf; k++) uc[k] = 0.5 * (ul[k] + ur[k]) - ldg_beta * (ul[k] - ur[k]);
+  }
+  else
+    for (int k = 0; k < nf; k++) uc[k] = ur[k];
+}
+
+/* ------------------------------------------------------------------------ */
+/* element methods                                                           */
+
+/* src/eles.cpp:1360-1411 : disu_fpts = opp_0 * disu_upts(0) */
+void orc_extrapolate_solution(orc_eles *e)
+{
+  if (e->n_eles == 0) return;
+  orc_dgemm(e->n_fpts, e->n_fields * e->n_eles, e->n_upts, 1.0, 0.0, e->opp_0, e->disu_upts[0], e->disu_fpts);
+}
+
+/* src/eles.cpp:1823-1886 : grad_disu_upts(:,:,:,d) = opp_4[d] * disu_upts(0) */
+void orc_calculate_gradient(orc_eles *e)
+{
+  if (e->n_eles == 0) return;
+  const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
+  for (int d = 0; d < e->n_dims; d++)
+    orc_dgemm(e->n_upts, e->n_fields * e->n_eles, e->n_upts, 1.0, 0.0, e->opp_4[d], e->disu_upts[0],
+              e->grad_disu_upts + d * slab);
+}
+
+/* src/eles.cpp:1415-1478 : pointwise Euler flux, then
+ * tdisf(j,i,k,l) = sum_m JGinv(l,m,j,i) * f(k,m)                             */
+void orc_evaluate_invFlux(orc_eles *e, const orc_params *P)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields, nd = e->n_dims;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j < nu; j++)
+    {
+      double u[MAXF], f[MAXF * MAXD];
+      for (int k = 0; k < nf; k++) u[k] = e->disu_upts[0][j + (long)nu * (i + (long)ne * k)];
+      orc_calc_invf(nd, P->gamma, u, f);
+      const double *JG = e->JGinv_upts + (long)nd * nd * (j + (long)nu * i);
+      for (int k = 0; k < nf; k++)
+        for (int l = 0; l < nd; l++)
+        {
+          double *t = &e->tdisf_upts[j + (long)nu * (i + (long)ne * (k + (long)nf * l))];
+          *t = 0.;
+          for (int m = 0; m < nd; m++) *t += JG[l + nd * m] * f[k + nf * m];
+        }
+    }
+}
+
+/* physical gradient at one point, the BLAS=NO branch of src/eles.cpp:1975-1979:
+ * dgemm(n_dims,n_fields,n_dims, inv_detjac, 0, JGinv^T, g_ref, g_phys)        */
+static void grad_to_physical(int nd, int nf, double inv_detjac, const double *JG, double *base, long stride_field,
+                             long stride_dim)
+{
+  double tg[MAXD * MAXF], cg[MAXD * MAXF];
+  for (int k = 0; k < nf; k++)
+    for (int d = 0; d < nd; d++) tg[d + nd * k] = base[k * stride_field + d * stride_dim];
+  for (int k = 0; k < nf; k++)
+  {
+    for (int d = 0; d < nd; d++) cg[d + nd * k] = 0.;
+    for (int l = 0; l < nd; l++)
+    {
+      double temp = inv_detjac * tg[l + nd * k];
+      /* A(i,l) = temp_JGinv(i,l) = JGinv(l,i) */
+      for (int d = 0; d < nd; d++) cg[d + nd * k] += temp * JG[l + nd * d];
+    }
+  }
+  for (int k = 0; k < nf; k++)
+    for (int d = 0; d < nd; d++) base[k * stride_field + d * stride_dim] = cg[d + nd * k];
+}
+
+/* src/eles.cpp:1890-2052 */
+void orc_correct_gradient(orc_eles *e)
+{
+  if (e->n_eles == 0) return;
+  const int nu = e->n_upts, nfp = e->n_fpts, ne = e->n_eles, nf = e->n_fields, nd = e->n_dims;
+  const long slab_u = (long)nu * ne * nf, slab_f = (long)nfp * ne * nf;
+  for (int d = 0; d < nd; d++)
+    orc_dgemm(nu, nf * ne, nfp, 1.0, 1.0, e->opp_5[d], e->delta_disu_fpts, e->grad_disu_upts + d * slab_u);
+  for (int d = 0; d < nd; d++)
+    orc_dgemm(nfp, nf * ne, nu, 1.0, 0.0, e->opp_6, e->grad_disu_upts + d * slab_u, e->grad_disu_fpts + d * slab_f);
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < ne; i++)
+  {
+    for (int j = 0; j < nu; j++)
+    {
+      double inv_detjac = 1.0 / e->detjac_upts[j + (long)nu * i];
+      grad_to_physical(nd, nf, inv_detjac, e->JGinv_upts + (long)nd * nd * (j + (long)nu * i),
+                       e->grad_disu_upts + j + (long)nu * i, (long)nu * ne, slab_u);
+    }
+    for (int j = 0; j < nfp; j++)
+    {
+      double inv_detjac = 1.0 / e->detjac_fpts[j + (long)nfp * i];
+      grad_to_physical(nd, nf, inv_detjac, e->JGinv_fpts + (long)nd * nd * (j + (long)nfp * i),
+                       e->grad_disu_fpts + j + (long)nfp * i, (long)nfp * ne, slab_f);
+    }
+  }
+}
+
+/* src/eles.cpp:2285-2392 (LES off): tdisf(j,i,k,l) += JGinv(l,m,j,i)*f_v(k,m), m ascending */
+void orc_evaluate_viscFlux(orc_eles *e, const orc_params *P)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields, nd = e->n_dims;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j < nu; j++)
+    {
+      double u[MAXF], g[MAXF * MAXD], f[MAXF * MAXD];
+      for (int k = 0; k < nf; k++)
+      {
+        u[k] = e->disu_upts[0][j + (long)nu * (i + (long)ne * k)];
+        for (int m = 0; m < nd; m++) g[k + nf * m] = e->grad_disu_upts[j + (long)nu * (i + (long)ne * (k + (long)nf * m))];
+      }
+      orc_calc_visf(nd, P, u, g, f);
+      const double *JG = e->JGinv_upts + (long)nd * nd * (j + (long)nu * i);
+      for (int k = 0; k < nf; k++)
+        for (int l = 0; l < nd; l++)
+        {
+          double *t = &e->tdisf_upts[j + (long)nu * (i + (long)ne * (k + (long)nf * l))];
+          for (int m = 0; m < nd; m++) *t += JG[l + nd * m] * f[k + nf * m];
+        }
+    }
+}
+
+/* src/eles.cpp:1549-1620 : norm_tdisf_fpts = sum_d opp_1[d]*tdisf_upts(:,:,:,d) (beta 0 then 1) */
+void orc_extrapolate_totalFlux(orc_eles *e)
+{
+  if (e->n_eles == 0) return;
+  const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
+  orc_dgemm(e->n_fpts, e->n_fields * e->n_eles, e->n_upts, 1.0, 0.0, e->opp_1[0], e->tdisf_upts, e->norm_tdisf_fpts);
+  for (int d = 1; d < e->n_dims; d++)
+    orc_dgemm(e->n_fpts, e->n_fields * e->n_eles, e->n_upts, 1.0, 1.0, e->opp_1[d], e->tdisf_upts + d * slab,
+              e->norm_tdisf_fpts);
+}
+
+/* src/eles.cpp:1651-1725 : div_tconf_upts(0) = sum_d opp_2[d]*tdisf_upts(:,:,:,d) */
+void orc_calculate_divergence(orc_eles *e)
+{
+  if (e->n_eles == 0) return;
+  const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
+  orc_dgemm(e->n_upts, e->n_fields * e->n_eles, e->n_upts, 1.0, 0.0, e->opp_2[0], e->tdisf_upts, e->div_tconf_upts);
+  for (int d = 1; d < e->n_dims; d++)
+    orc_dgemm(e->n_upts, e->n_fields * e->n_eles, e->n_upts, 1.0, 1.0, e->opp_2[d], e->tdisf_upts + d * slab,
+              e->div_tconf_upts);
+}
+
+/* src/eles.cpp:1738-1817 : norm_tconf -= norm_tdisf (daxpy, overwrites norm_tconf);
+ * div_tconf += opp_3*norm_tconf ; NaN scan                                   */
+long orc_calculate_corrected_divergence(orc_eles *e)
+{
+  if (e->n_eles == 0) return -1;
+  const long nfl = (long)e->n_eles * e->n_fields * e->n_fpts;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (long i = 0; i < nfl; i++) e->norm_tconf_fpts[i] += -1.0 * e->norm_tdisf_fpts[i];
+  orc_dgemm(e->n_upts, e->n_fields * e->n_eles, e->n_fpts, 1.0, 1.0, e->opp_3, e->norm_tconf_fpts, e->div_tconf_upts);
+  const long nul = (long)e->n_eles * e->n_upts * e->n_fields;
+  for (long ct = 0; ct < nul; ct++)
+    if (isnan(e->div_tconf_upts[ct])) return ct;
+  return -1;
+}
+
+/* src/eles.cpp:1080-1265 */
+void orc_AdvanceSolution(orc_eles *e, const orc_params *P, int in_step)
+{
+  if (e->n_eles == 0) return;
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields;
+  const long n = (long)nu * ne * nf;
+  double *u0 = e->disu_upts[0], *u1 = e->disu_upts[1];
+  const double *div = e->div_tconf_upts, *dj = e->detjac_upts, *src = e->src_upts;
+  const int adv = P->adv_type;
+  if ((adv == 1 || adv == 2) && in_step == 0) memcpy(u1, u0, sizeof(double) * n); /* disu_upts(1) = disu_upts(0) */
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < nf; i++)
+    for (int ic = 0; ic < ne; ic++)
+      for (int inp = 0; inp < nu; inp++)
+      {
+        const long q = inp + (long)nu * (ic + (long)ne * i);
+        const double s = src ? src[q] : 0.0;
+        const double dt = (P->dt_type == 2) ? e->dt_local[ic] : P->dt;
+        const double dd = div[q] / dj[inp + (long)nu * ic];
+        if (adv == 0)
+          u0[q] -= dt * (dd - s);
+        else if (adv == 1)
+        {
+          if (in_step < 3)
+            u0[q] -= dt / 3.0 * (dd - s);
+          else
+          {
+            double rhs = -dd + s;
+            u0[q] = 3.0 / 4.0 * u0[q] + 1.0 / 4.0 * u1[q] + dt / 4.0 * rhs;
+          }
+        }
+        else if (adv == 2)
+        {
+          if (in_step < 2 || in_step == 3)
+            u0[q] -= dt / 2.0 * (dd - s);
+          else if (in_step == 2)
+          {
+            double rhs = -dd + s;
+            u0[q] = 1.0 / 3.0 * u0[q] + 2.0 / 3.0 * u1[q] + dt / 6.0 * rhs;
+          }
+        }
+        else
+        {
+          double rhs = -dd + s;
+          u1[q] = P->RK_a[in_step] * u1[q] + dt * rhs;
+          u0[q] += P->RK_b[in_step] * u1[q];
+        }
+      }
+}
+
+/* src/eles.cpp:1267-1356 */
+double orc_calc_dt_local(const orc_eles *e, const orc_params *P, int ele, double h_ref, double CFL, int order)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nd = e->n_dims;
+  const double *U = e->disu_upts[0];
+  double lam_inv = 0, lam_visc = 0;
+  for (int i = 0; i < nu; i++)
+  {
+    double rho = U[i + (long)nu * (ele + (long)ne * 0)];
+    double vsq = 0;
+    for (int d = 0; d < nd; d++)
+    {
+      double v = U[i + (long)nu * (ele + (long)ne * (d + 1))] / rho;
+      vsq += v * v;
+    }
+    double p = (P->gamma - 1.0) * (U[i + (long)nu * (ele + (long)ne * (nd + 1))] - 0.5 * rho * vsq);
+    double c = sqrt(P->gamma * p / rho);
+    double inte = p / ((P->gamma - 1.0) * rho);
+    double rt_ratio = (P->gamma - 1.0) * inte / (P->rt_inf);
+    double mu = (P->mu_inf) * pow(rt_ratio, 1.5) * (1. + (P->c_sth)) / (rt_ratio + (P->c_sth));
+    mu = mu + P->fix_vis * (P->mu_inf - mu);
+    double lam_inv_new = sqrt(vsq) + c;
+    double lam_visc_new = fmax(4.0 / 3.0, P->gamma / P->prandtl) * mu / rho;
+    if (lam_inv < lam_inv_new) lam_inv = lam_inv_new;
+    if (lam_visc < lam_visc_new) lam_visc = lam_visc_new;
+  }
+  double dt_visc, dt_inv;
+  if (P->viscous)
+  {
+    dt_visc = (CFL * 0.25 * h_ref * h_ref) / (lam_visc)*1.0 / (2.0 * order + 1.0);
+    dt_inv = CFL * h_ref / lam_inv * 1.0 / (2.0 * order + 1.0);
+  }
+  else
+  {
+    dt_visc = 1e16;
+    dt_inv = CFL * h_ref / lam_inv * 1.0 / (2.0 * order + 1.0);
+  }
+  return fmin(dt_visc, dt_inv);
+}
+
+/* src/eles.cpp:5045-5074 */
+double orc_compute_res_upts(const orc_eles *e, int norm_type, int field)
+{
+  const int nu = e->n_upts, ne = e->n_eles;
+  double sum = 0.;
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j < nu; j++)
+    {
+      const long q = j + (long)nu * (i + (long)ne * field);
+      double s = e->src_upts ? e->src_upts[q] : 0.0;
+      double r = e->div_tconf_upts[q] / e->detjac_upts[j + (long)nu * i] - s;
+      if (norm_type == 0)
+        sum = fmax(sum, fabs(r));
+      else if (norm_type == 1)
+        sum += fabs(r);
+      else
+        sum += r * r;
+    }
+  return sum;
+}
+
+/* ------------------------------------------------------------------------ */
+/* face methods                                                              */
+
+/* src/int_inters.cpp:160-249 */
+void orc_int_calculate_common_invFlux(const orc_int_inters *F, orc_eles *e, const orc_params *P)
+{
+  const int nd = e->n_dims, nf = e->n_fields;
+  const long plane = (long)e->n_fpts * e->n_eles;
+  const int nfi = F->n_fpts_per_inter;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < F->n_inters; i++)
+    for (int j = 0; j < nfi; j++)
+    {
+      const long il = F->L[j + (long)nfi * i], ir = F->R[j + (long)nfi * i];
+      double ul[MAXF], ur[MAXF], fl[MAXF * MAXD], fr[MAXF * MAXD], norm[MAXD], fn[MAXF], uc[MAXF];
+      for (int k = 0; k < nf; k++)
+      {
+        ul[k] = e->disu_fpts[il + k * plane];
+        ur[k] = e->disu_fpts[ir + k * plane];
+      }
+      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      orc_calc_invf(nd, P->gamma, ul, fl);
+      orc_calc_invf(nd, P->gamma, ur, fr);
+      if (P->riemann_solve_type == 0)
+        orc_rusanov_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      else if (P->riemann_solve_type == 2)
+        orc_roeM_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      else
+        orc_hllc_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      for (int k = 0; k < nf; k++)
+      {
+        e->norm_tconf_fpts[il + k * plane] = fn[k] * e->tdA_fpts[il];
+        e->norm_tconf_fpts[ir + k * plane] = -fn[k] * e->tdA_fpts[ir];
+      }
+      if (P->viscous)
+      {
+        orc_ldg_solution(0, nd, ul, ur, uc, P->ldg_beta, norm);
+        for (int k = 0; k < nf; k++)
+        {
+          e->delta_disu_fpts[il + k * plane] = (uc[k] - ul[k]);
+          e->delta_disu_fpts[ir + k * plane] = (uc[k] - ur[k]);
+        }
+      }
+    }
+}
+
+/* src/int_inters.cpp:254-343 (LES off) */
+void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, const orc_params *P)
+{
+  const int nd = e->n_dims, nf = e->n_fields;
+  const long plane = (long)e->n_fpts * e->n_eles;
+  const int nfi = F->n_fpts_per_inter;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < F->n_inters; i++)
+    for (int j = 0; j < nfi; j++)
+    {
+      const long il = F->L[j + (long)nfi * i], ir = F->R[j + (long)nfi * i];
+      double ul[MAXF], ur[MAXF], gl[MAXF * MAXD], gr[MAXF * MAXD], fl[MAXF * MAXD], fr[MAXF * MAXD], norm[MAXD],
+          fn[MAXF];
+      for (int k = 0; k < nf; k++)
+      {
+        ul[k] = e->disu_fpts[il + k * plane];
+        ur[k] = e->disu_fpts[ir + k * plane];
+      }
+      for (int k = 0; k < nd; k++)
+        for (int l = 0; l < nf; l++)
+        {
+          gl[l + nf * k] = e->grad_disu_fpts[il + (l + (long)nf * k) * plane];
+          gr[l + nf * k] = e->grad_disu_fpts[ir + (l + (long)nf * k) * plane];
+        }
+      orc_calc_visf(nd, P, ul, gl, fl);
+      orc_calc_visf(nd, P, ur, gr, fr);
+      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      orc_ldg_flux(0, nd, ul, ur, fl, fr, norm, fn, P->ldg_tau, P->ldg_beta);
+      for (int k = 0; k < nf; k++)
+      {
+        e->norm_tconf_fpts[il + k * plane] += fn[k] * e->tdA_fpts[il];
+        e->norm_tconf_fpts[ir + k * plane] += -fn[k] * e->tdA_fpts[ir];
+      }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/solver.cpp:50-223, single rank, LES / RANS / forcing / over_int off   */
+long orc_CalcResidual(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *P)
+{
+  orc_extrapolate_solution(e);
+  if (P->viscous) orc_calculate_gradient(e);
+  orc_evaluate_invFlux(e, P);
+  for (int b = 0; b < n_face_blocks; b++) orc_int_calculate_common_invFlux(&faces[b], e, P);
+  if (P->viscous)
+  {
+    orc_correct_gradient(e);
+    orc_evaluate_viscFlux(e, P);
+  }
+  orc_extrapolate_totalFlux(e);
+  orc_calculate_divergence(e);
+  if (P->viscous)
+    for (int b = 0; b < n_face_blocks; b++) orc_int_calculate_common_viscFlux(&faces[b], e, P);
+  return orc_calculate_corrected_divergence(e);
+}
+
+/* one time step = the RK-stage loop of src/HiFiLES.cpp:201-217 */
+long orc_rk_step(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *P)
+{
+  int RKSteps = 1;
+  if (P->adv_type == 1 || P->adv_type == 2)
+    RKSteps = 4;
+  else if (P->adv_type == 3)
+    RKSteps = 5;
+  else if (P->adv_type == 4)
+    RKSteps = 14;
+  for (int s = 0; s < RKSteps; s++)
+  {
+    long bad = orc_CalcResidual(e, faces, n_face_blocks, P);
+    if (bad >= 0) return bad;
+    orc_AdvanceSolution(e, P, s);
+  }
+  return -1;
+}

@@ -14,8 +14,8 @@
 //
 // usage: HIFILES_HOME=/root/reference ref_harness <input_file> <out.bin> <n_steps> <level>
 //   level 0: state after every stage only
-//   level 1: + operators, params, face tables, div_tconf of the first residual
-//   level 2: + metrics and every intermediate array of the first CalcResidual
+//   level 1: + operators, params, face tables, metrics, div_tconf of the first residual
+//   level 2: + every intermediate array of the first CalcResidual
 
 #include <cstdio>
 #include <cstdlib>
@@ -227,7 +227,7 @@ int main(int argc, char *argv[])
       put_i(s + "R", R.data(), {nf, ni});
     }
   }
-  if (level >= 2)
+  if (level >= 1)
   {
     put_arr("detjac_upts", E->detjac_upts);
     put_arr("JGinv_upts", E->JGinv_upts);
@@ -303,7 +303,7 @@ int main(int argc, char *argv[])
           res[f] = E->compute_res_upts(1, f);
           res[n_fields + f] = E->compute_res_upts(2, f);
         }
-        put_d("s0_res_sums", res.data(), {2, n_fields});
+        put_d("s0_res_sums", res.data(), {n_fields, 2});
       }
       else
         CalcResidual(FlowSol.ini_iter + step, rk, &FlowSol);

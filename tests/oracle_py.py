@@ -1,0 +1,149 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE (the checker, never the product)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("gamma", "prandtl", "rt_inf", "mu_inf", "c_sth", "fix_vis", "ldg_beta", "ldg_tau", "dt")] + \
+               [(n, C.c_int) for n in
+                ("viscous", "riemann_solve_type", "vis_riemann_solve_type", "adv_type", "dt_type", "n_rk")] + \
+               [("RK_a", C.c_double * 16), ("RK_b", C.c_double * 16)]
+
+
+class Eles(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_eles", "n_upts", "n_fpts", "n_fields", "n_dims")] + [
+        ("opp_0", dp), ("opp_1", dp * 3), ("opp_2", dp * 3), ("opp_3", dp), ("opp_4", dp * 3),
+        ("opp_5", dp * 3), ("opp_6", dp),
+        ("detjac_upts", dp), ("JGinv_upts", dp), ("detjac_fpts", dp), ("JGinv_fpts", dp),
+        ("tdA_fpts", dp), ("norm_fpts", dp),
+        ("disu_upts", dp * 2), ("disu_fpts", dp), ("tdisf_upts", dp), ("norm_tdisf_fpts", dp),
+        ("norm_tconf_fpts", dp), ("div_tconf_upts", dp), ("delta_disu_fpts", dp),
+        ("grad_disu_upts", dp), ("grad_disu_fpts", dp), ("src_upts", dp), ("dt_local", dp)]
+
+
+class IntInters(C.Structure):
+    _fields_ = [("n_inters", C.c_int), ("n_fpts_per_inter", C.c_int), ("L", ip), ("R", ip)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        src = os.path.join(ORACLE_DIR, "oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+        _lib = C.CDLL(so)
+        _lib.orc_CalcResidual.restype = C.c_long
+        _lib.orc_rk_step.restype = C.c_long
+        _lib.orc_calculate_corrected_divergence.restype = C.c_long
+        _lib.orc_compute_res_upts.restype = C.c_double
+        _lib.orc_calc_dt_local.restype = C.c_double
+        _lib.orc_calc_dt_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+    return _lib
+
+
+def fptr(a):
+    assert a.dtype == np.float64 and a.flags.f_contiguous
+    return a.ctypes.data_as(dp)
+
+
+def iptr(a):
+    assert a.dtype == np.int32 and a.flags.f_contiguous
+    return a.ctypes.data_as(ip)
+
+
+def F(shape):
+    return np.zeros(shape, dtype=np.float64, order="F")
+
+
+class Case:
+    """Registration data + state of one single-element-type case, as numpy arrays in hf_array (Fortran) order.
+
+    `data` is a dict with the keys of the golden fixtures (opp_*, metrics, int*_L/R, scalars)."""
+
+    def __init__(self, data, u_init=None):
+        g = lambda k: np.asfortranarray(np.array(data[k], dtype=np.float64))
+        sz = [int(v) for v in data["sizes"]]
+        self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims, self.order = sz[:6]
+        ne, nu, nfp, nf, nd = self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims
+        self.viscous = int(np.ravel(data["viscous"])[0])
+        self.arr = {}
+        for k in ("opp_0", "opp_3", "detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts"):
+            self.arr[k] = g(k)
+        if self.viscous:
+            self.arr["opp_6"] = g("opp_6")
+        for d in range(nd):
+            names = ["opp_1_%d", "opp_2_%d"] + (["opp_4_%d", "opp_5_%d"] if self.viscous else [])
+            for n in names:
+                self.arr[n % d] = g(n % d)
+        u = g("u_init") if u_init is None else np.asfortranarray(np.array(u_init, dtype=np.float64))
+        self.arr["u0"] = u.copy(order="F")
+        self.arr["u1"] = F((nu, ne, nf))
+        self.arr["disu_fpts"] = F((nfp, ne, nf))
+        self.arr["tdisf_upts"] = F((nu, ne, nf, nd))
+        self.arr["norm_tdisf_fpts"] = F((nfp, ne, nf))
+        self.arr["norm_tconf_fpts"] = F((nfp, ne, nf))
+        self.arr["div_tconf_upts"] = F((nu, ne, nf))
+        self.arr["delta_disu_fpts"] = F((nfp, ne, nf))
+        self.arr["grad_disu_upts"] = F((nu, ne, nf, nd))
+        self.arr["grad_disu_fpts"] = F((nfp, ne, nf, nd))
+        # face blocks
+        self.faces = []
+        for t in range(3):
+            if "int%d_L" % t in data:
+                L = np.asfortranarray(np.array(data["int%d_L" % t], dtype=np.int32))
+                R = np.asfortranarray(np.array(data["int%d_R" % t], dtype=np.int32))
+                self.faces.append((L, R))
+        # params
+        s = lambda k, dflt=None: float(np.ravel(data[k])[0]) if k in data else dflt
+        p = Params()
+        for k in ("gamma", "prandtl", "rt_inf", "mu_inf", "c_sth", "fix_vis", "ldg_beta", "ldg_tau", "dt"):
+            setattr(p, k, s(k, 0.0))
+        for k in ("viscous", "riemann_solve_type", "vis_riemann_solve_type", "adv_type", "dt_type"):
+            setattr(p, k, int(s(k, 0)))
+        ra, rb = np.ravel(data["RK_a"]), np.ravel(data["RK_b"])
+        p.n_rk = len(ra)
+        for i in range(len(ra)):
+            p.RK_a[i] = float(ra[i])
+            p.RK_b[i] = float(rb[i])
+        self.params = p
+
+    def c_eles(self):
+        a = self.arr
+        e = Eles()
+        e.n_eles, e.n_upts, e.n_fpts, e.n_fields, e.n_dims = self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims
+        e.opp_0 = fptr(a["opp_0"]); e.opp_3 = fptr(a["opp_3"])
+        if self.viscous:
+            e.opp_6 = fptr(a["opp_6"])
+        for d in range(self.n_dims):
+            e.opp_1[d] = fptr(a["opp_1_%d" % d]); e.opp_2[d] = fptr(a["opp_2_%d" % d])
+            if self.viscous:
+                e.opp_4[d] = fptr(a["opp_4_%d" % d]); e.opp_5[d] = fptr(a["opp_5_%d" % d])
+        for k in ("detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts",
+                  "disu_fpts", "tdisf_upts", "norm_tdisf_fpts", "norm_tconf_fpts", "div_tconf_upts",
+                  "delta_disu_fpts", "grad_disu_upts", "grad_disu_fpts"):
+            setattr(e, k, fptr(a[k]))
+        e.disu_upts[0] = fptr(a["u0"]); e.disu_upts[1] = fptr(a["u1"])
+        self._e = e
+        return e
+
+    def c_faces(self):
+        arr = (IntInters * max(1, len(self.faces)))()
+        for i, (L, R) in enumerate(self.faces):
+            arr[i].n_fpts_per_inter, arr[i].n_inters = L.shape
+            arr[i].L = iptr(L); arr[i].R = iptr(R)
+        self._f = arr
+        return arr, len(self.faces)

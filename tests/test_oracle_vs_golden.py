@@ -1,0 +1,107 @@
+"""Pin the oracle (oracle/oracle.c) against fixtures captured from the GENUINE reference.
+
+The fixtures under tests/golden were produced by oracle/capture_golden.py driving
+oracle/_ref/ref_harness (the reference compiled from /root/reference/src).  Inputs
+(operators, metrics, face tables, initial state, parameters) and expected outputs are
+both the reference's; the oracle must reproduce every intermediate of one residual
+evaluation and the state after each RK stage.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hex_*.npz")))
+
+# The oracle repeats the reference's operation order; remaining differences are compiler-level
+# (x87-free SSE2 both sides, no FMA) so the tolerance is a few ulps of the array's scale.
+RTOL = 1e-13
+
+
+def relerr(a, b):
+    scale = np.abs(b).max()
+    return np.abs(a - b).max() / (scale if scale > 0 else 1.0)
+
+
+def needs_metrics(d):
+    return "detjac_upts" in d
+
+
+@pytest.mark.parametrize("name", [n for n in ALL])
+def test_stage_states(oracle, name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if not needs_metrics(d):
+        pytest.skip("fixture has no metrics (covered by the host-setup tests)")
+    c = O.Case(d)
+    e = c.c_eles()
+    f, nfb = c.c_faces()
+    nstage = int(d["sizes"][7])
+    steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
+    for st in steps:
+        for rk in range(nstage):
+            bad = oracle.orc_CalcResidual(C.byref(e), f, nfb, C.byref(c.params))
+            assert bad == -1
+            if st == 0 and rk == 0:
+                assert relerr(c.arr["div_tconf_upts"], d["s0_div_tconf_upts"]) < RTOL
+                for fld in range(c.n_fields):
+                    for nt in (1, 2):
+                        got = oracle.orc_compute_res_upts(C.byref(e), nt, fld)
+                        want = d["s0_res_sums"][fld, nt - 1]
+                        assert abs(got - want) <= 1e-12 * abs(want)
+            oracle.orc_AdvanceSolution(C.byref(e), C.byref(c.params), rk)
+            key = "u_step%d_stage%d" % (st, rk)
+            if key in d:
+                assert relerr(c.arr["u0"], d[key]) < RTOL, key
+
+
+def test_every_intermediate(oracle):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p2_n3_deformed.npz")))
+    c = O.Case(d)
+    e = c.c_eles()
+    f, nfb = c.c_faces()
+    P = C.byref(c.params)
+    E = C.byref(e)
+    a = c.arr
+    oracle.orc_extrapolate_solution(E)
+    assert relerr(a["disu_fpts"], d["s0_disu_fpts"]) < RTOL
+    oracle.orc_calculate_gradient(E)
+    assert relerr(a["grad_disu_upts"], d["s0_grad_disu_upts_ref"]) < RTOL
+    oracle.orc_evaluate_invFlux(E, P)
+    assert relerr(a["tdisf_upts"], d["s0_tdisf_upts_inv"]) < RTOL
+    for b in range(nfb):
+        oracle.orc_int_calculate_common_invFlux(C.byref(f[b]), E, P)
+    assert relerr(a["norm_tconf_fpts"], d["s0_norm_tconf_fpts_inv"]) < RTOL
+    assert relerr(a["delta_disu_fpts"], d["s0_delta_disu_fpts"]) < RTOL
+    oracle.orc_correct_gradient(E)
+    assert relerr(a["grad_disu_upts"], d["s0_grad_disu_upts"]) < RTOL
+    assert relerr(a["grad_disu_fpts"], d["s0_grad_disu_fpts"]) < RTOL
+    oracle.orc_evaluate_viscFlux(E, P)
+    assert relerr(a["tdisf_upts"], d["s0_tdisf_upts"]) < RTOL
+    oracle.orc_extrapolate_totalFlux(E)
+    assert relerr(a["norm_tdisf_fpts"], d["s0_norm_tdisf_fpts"]) < RTOL
+    oracle.orc_calculate_divergence(E)
+    assert relerr(a["div_tconf_upts"], d["s0_div_tconf_upts_disc"]) < RTOL
+    for b in range(nfb):
+        oracle.orc_int_calculate_common_viscFlux(C.byref(f[b]), E, P)
+    assert relerr(a["norm_tconf_fpts"], d["s0_norm_tconf_fpts"]) < RTOL
+    assert oracle.orc_calculate_corrected_divergence(E) == -1
+    assert relerr(a["div_tconf_upts"], d["s0_div_tconf_upts"]) < RTOL
+
+
+def test_threads_do_not_change_results(oracle):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p2_n3_deformed.npz")))
+    outs = []
+    for nt in (1, 4):
+        oracle.orc_set_threads(nt)
+        c = O.Case(d)
+        e = c.c_eles()
+        f, nfb = c.c_faces()
+        assert oracle.orc_rk_step(C.byref(e), f, nfb, C.byref(c.params)) == -1
+        outs.append(c.arr["u0"].copy())
+    oracle.orc_set_threads(1)
+    assert np.array_equal(outs[0], outs[1])
