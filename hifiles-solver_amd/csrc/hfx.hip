@@ -1,0 +1,792 @@
+// hfx.hip -- C ABI of libhfx (include/hfx.h): handles, registration, per-method
+// launchers mirroring eles::* / int_inters::* of the reference, and the
+// CalcResidual / RK-loop drivers.  gfx950 only.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+#include "fused_hex.hpp"
+#include "hfx_internal.hpp"
+#include "kernels_ops.hpp"
+#include "kernels_point.hpp"
+
+namespace hfx
+{
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+static int dev_alloc_copy(double **dst, const double *src, long n)
+{
+  HFX_HIP(hipMalloc((void **)dst, sizeof(double) * (size_t)std::max<long>(n, 1)));
+  if (src) HFX_HIP(hipMemcpy(*dst, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ---- operator registration -------------------------------------------------
+static int make_operator(Operator &op, const double *host, int m, int k)
+{
+  op.m = m;
+  op.k = k;
+  if (dev_alloc_copy(&op.dense, host, (long)m * k)) return 1;
+  // ELL: exact non-zeros, ascending column
+  int nnz_max = 0;
+  long total = 0;
+  std::vector<int> cnt(m, 0);
+  for (int r = 0; r < m; r++)
+  {
+    for (int c = 0; c < k; c++)
+      if (host[r + (long)m * c] != 0.0) cnt[r]++;
+    nnz_max = std::max(nnz_max, cnt[r]);
+    total += cnt[r];
+  }
+  op.nnz_max = nnz_max;
+  op.nnz_total = total;
+  const int w = std::max(nnz_max, 1);
+  std::vector<double> val((size_t)m * w, 0.0);
+  std::vector<int> idx((size_t)m * w, 0);
+  for (int r = 0; r < m; r++)
+  {
+    int q = 0, first = 0;
+    for (int c = 0; c < k; c++)
+      if (host[r + (long)m * c] != 0.0)
+      {
+        if (q == 0) first = c;
+        val[r + (size_t)m * q] = host[r + (long)m * c];
+        idx[r + (size_t)m * q] = c;
+        q++;
+      }
+    for (; q < w; q++)
+    {
+      val[r + (size_t)m * q] = 0.0;
+      idx[r + (size_t)m * q] = first;
+    }
+  }
+  HFX_HIP(hipMalloc((void **)&op.ell_val, sizeof(double) * val.size()));
+  HFX_HIP(hipMalloc((void **)&op.ell_idx, sizeof(int) * idx.size()));
+  HFX_HIP(hipMemcpy(op.ell_val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
+  HFX_HIP(hipMemcpy(op.ell_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static void free_operator(Operator &op)
+{
+  if (op.dense) (void)hipFree(op.dense);
+  if (op.ell_val) (void)hipFree(op.ell_val);
+  if (op.ell_idx) (void)hipFree(op.ell_idx);
+  op = Operator();
+}
+
+constexpr int ELL_MAX_NNZ = 8;
+
+// sparse when every term has <= ELL_MAX_NNZ non-zeros per row (tensor-product
+// collocation gives <= order+2); anything else is a genuinely dense operator
+static bool use_sparse(const hfx_ctx *ctx, const Operator *const *ops, int n)
+{
+  if (ctx->contract_mode == HFX_CONTRACT_DENSE) return false;
+  for (int i = 0; i < n; i++)
+    if (ops[i]->nnz_max > ELL_MAX_NNZ) return false;
+  return true;
+}
+
+template <int NNZ, int NT, int NO>
+static int launch_ell_t(hfx_ctx *ctx, EllArgs<NT, NO> &a)
+{
+  // threads: rg row groups of m rows, rounded up to whole waves
+  const int m = a.m;
+  int best_rg = 1, best_bd = ((m + 63) / 64) * 64;
+  double best_eff = (double)m / best_bd;
+  for (int rg = 2; rg <= 16; rg++)
+  {
+    const int bd = ((rg * m + 63) / 64) * 64;
+    if (bd > 512) break;
+    const double eff = (double)(rg * m) / bd;
+    if (eff > best_eff + 1e-9)
+    {
+      best_eff = eff;
+      best_rg = rg;
+      best_bd = bd;
+    }
+  }
+  HFX_CHECK(best_bd <= 1024, "operator with %d rows does not fit one workgroup", m);
+  a.rg = best_rg;
+  // columns per tile: ~40 kB of LDS for the input tile(s), a multiple of rg
+  const long bytes_per_col = (long)NT * a.k * sizeof(double);
+  int ct = (int)std::max<long>(1, (40 * 1024) / bytes_per_col);
+  ct = std::max(best_rg, (ct / best_rg) * best_rg);
+  ct = (int)std::min<long>(ct, std::max<long>(a.ncols, 1));
+  a.ct = ct;
+  const size_t lds = (size_t)NT * a.k * ct * sizeof(double);
+  HFX_CHECK(lds <= 160 * 1024, "ELL tile does not fit LDS");
+  const long nblk = (a.ncols + ct - 1) / ct;
+  if (nblk == 0) return 0;
+  if (lds > 48 * 1024)
+    HFX_HIP(hipFuncSetAttribute((const void *)ell_apply_kernel<NNZ, NT, NO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+  hipLaunchKernelGGL((ell_apply_kernel<NNZ, NT, NO>), dim3((unsigned)nblk), dim3(best_bd), lds, ctx->stream, a);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int NT, int NO>
+static int launch_ell(hfx_ctx *ctx, EllArgs<NT, NO> &a, int nnz)
+{
+  switch (std::max(nnz, 1))
+  {
+  case 1: return launch_ell_t<1, NT, NO>(ctx, a);
+  case 2: return launch_ell_t<2, NT, NO>(ctx, a);
+  case 3: return launch_ell_t<3, NT, NO>(ctx, a);
+  case 4: return launch_ell_t<4, NT, NO>(ctx, a);
+  case 5: return launch_ell_t<5, NT, NO>(ctx, a);
+  case 6: return launch_ell_t<6, NT, NO>(ctx, a);
+  case 7: return launch_ell_t<7, NT, NO>(ctx, a);
+  case 8: return launch_ell_t<8, NT, NO>(ctx, a);
+  }
+  set_error("launch_ell: nnz %d out of range", nnz);
+  return 1;
+}
+
+static int launch_dense(hfx_ctx *ctx, const Operator &op, const double *B, double *C, long ncols, int beta,
+                        const double *sub = nullptr, double *wb = nullptr, unsigned long long *nan_flag = nullptr)
+{
+  DenseArgs a;
+  a.m = op.m;
+  a.k = op.k;
+  a.ncols = ncols;
+  a.beta = beta;
+  a.A = op.dense;
+  a.B = B;
+  a.C = C;
+  a.sub = sub;
+  a.in_writeback = wb;
+  a.nan_flag = nan_flag;
+  const int kpad = (op.k + 3) & ~3;
+  const size_t lds = (size_t)kpad * (DENSE_CT + 1) * sizeof(double);
+  HFX_CHECK(lds <= 160 * 1024, "dense contraction: k = %d does not fit LDS", op.k);
+  const long nblk = (ncols + DENSE_CT - 1) / DENSE_CT;
+  if (nblk == 0) return 0;
+  if (lds > 48 * 1024)
+    HFX_HIP(hipFuncSetAttribute((const void *)dense_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(dense_mfma_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, a);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+// out = [beta out] + sum_t op[t] * in[t]   (NT terms; in[t] are slabs of k x ncols)
+static int contract_multi_in(hfx_ctx *ctx, const Operator *const *ops, int nt, const double *const *in, double *out,
+                             long ncols, int beta, const double *sub = nullptr, double *wb = nullptr,
+                             unsigned long long *nan_flag = nullptr)
+{
+  if (use_sparse(ctx, ops, nt))
+  {
+    int nnz = 0;
+    for (int t = 0; t < nt; t++) nnz = std::max(nnz, ops[t]->nnz_max);
+    // pad terms with fewer non-zeros: their ELL arrays are only nnz_max(t) wide, so
+    // fall back to one launch per term when widths differ
+    bool same = true;
+    for (int t = 0; t < nt; t++) same = same && (std::max(ops[t]->nnz_max, 1) == std::max(nnz, 1));
+    if (same && nt == 1)
+    {
+      EllArgs<1, 1> a{};
+      a.m = ops[0]->m; a.k = ops[0]->k; a.ncols = ncols; a.beta = beta;
+      a.val[0] = ops[0]->ell_val; a.idx[0] = ops[0]->ell_idx; a.in[0] = in[0]; a.out[0] = out;
+      a.sub = sub; a.in_writeback = wb; a.nan_flag = nan_flag;
+      return launch_ell<1, 1>(ctx, a, nnz);
+    }
+    if (same && nt == 2 && !sub)
+    {
+      EllArgs<2, 1> a{};
+      a.m = ops[0]->m; a.k = ops[0]->k; a.ncols = ncols; a.beta = beta;
+      for (int t = 0; t < 2; t++) { a.val[t] = ops[t]->ell_val; a.idx[t] = ops[t]->ell_idx; a.in[t] = in[t]; }
+      a.out[0] = out; a.nan_flag = nan_flag;
+      return launch_ell<2, 1>(ctx, a, nnz);
+    }
+    if (same && nt == 3 && !sub)
+    {
+      EllArgs<3, 1> a{};
+      a.m = ops[0]->m; a.k = ops[0]->k; a.ncols = ncols; a.beta = beta;
+      for (int t = 0; t < 3; t++) { a.val[t] = ops[t]->ell_val; a.idx[t] = ops[t]->ell_idx; a.in[t] = in[t]; }
+      a.out[0] = out; a.nan_flag = nan_flag;
+      return launch_ell<3, 1>(ctx, a, nnz);
+    }
+    for (int t = 0; t < nt; t++)
+    {
+      EllArgs<1, 1> a{};
+      a.m = ops[t]->m; a.k = ops[t]->k; a.ncols = ncols; a.beta = (t == 0) ? beta : 1;
+      a.val[0] = ops[t]->ell_val; a.idx[0] = ops[t]->ell_idx; a.in[0] = in[t]; a.out[0] = out;
+      if (t == 0) { a.sub = sub; a.in_writeback = wb; }
+      if (t == nt - 1) a.nan_flag = nan_flag;
+      if (launch_ell<1, 1>(ctx, a, ops[t]->nnz_max)) return 1;
+    }
+    return 0;
+  }
+  for (int t = 0; t < nt; t++)
+    if (launch_dense(ctx, *ops[t], in[t], out, ncols, (t == 0) ? beta : 1, (t == 0) ? sub : nullptr,
+                     (t == 0) ? wb : nullptr, (t == nt - 1) ? nan_flag : nullptr))
+      return 1;
+  return 0;
+}
+
+// out[o] = [beta out[o]] + op[o] * in   (NO outputs share one input)
+static int contract_multi_out(hfx_ctx *ctx, const Operator *const *ops, int no, const double *in, double *const *out,
+                              long ncols, int beta)
+{
+  if (use_sparse(ctx, ops, no))
+  {
+    int nnz = 0;
+    for (int o = 0; o < no; o++) nnz = std::max(nnz, ops[o]->nnz_max);
+    bool same = true;
+    for (int o = 0; o < no; o++) same = same && (std::max(ops[o]->nnz_max, 1) == std::max(nnz, 1));
+    if (same && no == 2)
+    {
+      EllArgs<1, 2> a{};
+      a.m = ops[0]->m; a.k = ops[0]->k; a.ncols = ncols; a.beta = beta; a.in[0] = in;
+      for (int o = 0; o < 2; o++) { a.val[o] = ops[o]->ell_val; a.idx[o] = ops[o]->ell_idx; a.out[o] = out[o]; }
+      return launch_ell<1, 2>(ctx, a, nnz);
+    }
+    if (same && no == 3)
+    {
+      EllArgs<1, 3> a{};
+      a.m = ops[0]->m; a.k = ops[0]->k; a.ncols = ncols; a.beta = beta; a.in[0] = in;
+      for (int o = 0; o < 3; o++) { a.val[o] = ops[o]->ell_val; a.idx[o] = ops[o]->ell_idx; a.out[o] = out[o]; }
+      return launch_ell<1, 3>(ctx, a, nnz);
+    }
+    for (int o = 0; o < no; o++)
+    {
+      EllArgs<1, 1> a{};
+      a.m = ops[o]->m; a.k = ops[o]->k; a.ncols = ncols; a.beta = beta;
+      a.val[0] = ops[o]->ell_val; a.idx[0] = ops[o]->ell_idx; a.in[0] = in; a.out[0] = out[o];
+      if (launch_ell<1, 1>(ctx, a, ops[o]->nnz_max)) return 1;
+    }
+    return 0;
+  }
+  for (int o = 0; o < no; o++)
+    if (launch_dense(ctx, *ops[o], in, out[o], ncols, beta)) return 1;
+  return 0;
+}
+
+static inline unsigned nblocks(long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+} // namespace hfx
+
+using namespace hfx;
+
+// ===========================================================================
+extern "C" {
+
+const char *hfx_last_error(void) { return g_err.c_str(); }
+int hfx_version(void) { return 1; }
+
+int hfx_ctx_create(int device, hfx_ctx **out)
+{
+  HFX_CHECK(out != nullptr, "hfx_ctx_create: out is NULL");
+  int n = 0;
+  HFX_HIP(hipGetDeviceCount(&n));
+  HFX_CHECK(device >= 0 && device < n, "hfx_ctx_create: device %d of %d", device, n);
+  HFX_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HFX_HIP(hipGetDeviceProperties(&prop, device));
+  HFX_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0,
+            "libhfx is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+  hfx_ctx *c = new hfx_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  HFX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  *out = c;
+  return 0;
+}
+
+int hfx_ctx_destroy(hfx_ctx *ctx)
+{
+  if (!ctx) return 0;
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int hfx_ctx_set_params(hfx_ctx *ctx, const hfx_params *p)
+{
+  HFX_CHECK(ctx && p, "hfx_ctx_set_params: NULL argument");
+  HFX_CHECK(p->riemann_solve_type == 0 || p->riemann_solve_type == 2 || p->riemann_solve_type == 3,
+            "Riemann solver not implemented"); /* src/int_inters.cpp:210 */
+  HFX_CHECK(p->vis_riemann_solve_type == 0, "Viscous Riemann solver not implemented"); /* src/int_inters.cpp:233 */
+  HFX_CHECK(p->adv_type >= 0 && p->adv_type <= 4, "ERROR: Time integration type not recognised ... "); /* src/eles.cpp:1262 */
+  HFX_CHECK(p->n_rk >= 0 && p->n_rk <= 16, "hfx_ctx_set_params: n_rk out of range");
+  ctx->params = *p;
+  ctx->have_params = true;
+  return 0;
+}
+
+int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode)
+{
+  HFX_CHECK(ctx, "NULL ctx");
+  HFX_CHECK(mode >= 0 && mode <= 2, "hfx_ctx_set_contract_mode: bad mode %d", mode);
+  ctx->contract_mode = mode;
+  return 0;
+}
+
+int hfx_ctx_synchronize(hfx_ctx *ctx)
+{
+  HFX_CHECK(ctx, "NULL ctx");
+  HFX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+void *hfx_ctx_stream(hfx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------
+int hfx_eles_create(hfx_ctx *ctx, const hfx_eles_desc *d, hfx_eles **out)
+{
+  HFX_CHECK(ctx && d && out, "hfx_eles_create: NULL argument");
+  HFX_CHECK(d->n_dims == 2 || d->n_dims == 3, "Invalid number of dimensions!"); /* src/eles.cpp:1446 */
+  HFX_CHECK(d->n_fields == d->n_dims + 2, "hfx_eles_create: n_fields must be n_dims+2 (Euler / Navier-Stokes)");
+  HFX_CHECK(d->n_eles >= 0 && d->n_upts > 0 && d->n_fpts > 0, "hfx_eles_create: bad sizes");
+  HFX_CHECK(d->opp_0 && d->opp_3 && d->detjac_upts && d->JGinv_upts && d->tdA_fpts && d->norm_fpts,
+            "hfx_eles_create: missing operator or metric");
+  HFX_HIP(hipSetDevice(ctx->device));
+  hfx_eles *e = new hfx_eles();
+  e->ctx = ctx;
+  e->n_eles = d->n_eles; e->n_upts = d->n_upts; e->n_fpts = d->n_fpts; e->n_fields = d->n_fields;
+  e->n_dims = d->n_dims; e->ele_type = d->ele_type; e->order = d->order;
+  const int nu = d->n_upts, nfp = d->n_fpts, nd = d->n_dims, nf = d->n_fields;
+  const long ne = d->n_eles;
+  e->viscous_ops = d->opp_4[0] != nullptr;
+  if (make_operator(e->opp_0, d->opp_0, nfp, nu)) return 1;
+  if (make_operator(e->opp_3, d->opp_3, nu, nfp)) return 1;
+  for (int i = 0; i < nd; i++)
+  {
+    HFX_CHECK(d->opp_1[i] && d->opp_2[i], "hfx_eles_create: missing opp_1/opp_2");
+    if (make_operator(e->opp_1[i], d->opp_1[i], nfp, nu)) return 1;
+    if (make_operator(e->opp_2[i], d->opp_2[i], nu, nu)) return 1;
+    if (e->viscous_ops)
+    {
+      HFX_CHECK(d->opp_4[i] && d->opp_5[i] && d->opp_6, "hfx_eles_create: missing opp_4/5/6");
+      if (make_operator(e->opp_4[i], d->opp_4[i], nu, nu)) return 1;
+      if (make_operator(e->opp_5[i], d->opp_5[i], nu, nfp)) return 1;
+    }
+  }
+  if (e->viscous_ops)
+  {
+    HFX_CHECK(d->detjac_fpts && d->JGinv_fpts, "hfx_eles_create: missing flux-point metrics");
+    if (make_operator(e->opp_6, d->opp_6, nfp, nu)) return 1;
+  }
+  if (dev_alloc_copy(&e->detjac_upts, d->detjac_upts, nu * ne)) return 1;
+  if (dev_alloc_copy(&e->JGinv_upts, d->JGinv_upts, (long)nd * nd * nu * ne)) return 1;
+  if (d->detjac_fpts && dev_alloc_copy(&e->detjac_fpts, d->detjac_fpts, nfp * ne)) return 1;
+  if (d->JGinv_fpts && dev_alloc_copy(&e->JGinv_fpts, d->JGinv_fpts, (long)nd * nd * nfp * ne)) return 1;
+  if (dev_alloc_copy(&e->tdA_fpts, d->tdA_fpts, nfp * ne)) return 1;
+  if (dev_alloc_copy(&e->norm_fpts, d->norm_fpts, (long)nfp * ne * nd)) return 1;
+
+  const long pu = nu * ne, pf = nfp * ne;
+  long len[HFX_N_ARRAYS];
+  len[HFX_DISU_UPTS0] = pu * nf; len[HFX_DISU_UPTS1] = pu * nf; len[HFX_DISU_FPTS] = pf * nf;
+  len[HFX_TDISF_UPTS] = pu * nf * nd; len[HFX_NORM_TDISF_FPTS] = pf * nf; len[HFX_NORM_TCONF_FPTS] = pf * nf;
+  len[HFX_DIV_TCONF_UPTS] = pu * nf; len[HFX_DELTA_DISU_FPTS] = pf * nf;
+  len[HFX_GRAD_DISU_UPTS] = pu * nf * nd; len[HFX_GRAD_DISU_FPTS] = pf * nf * nd;
+  len[HFX_SRC_UPTS] = pu * nf; len[HFX_DT_LOCAL] = ne;
+  for (int i = 0; i < HFX_N_ARRAYS; i++)
+  {
+    e->arr_len[i] = len[i];
+    if (i == HFX_SRC_UPTS || i == HFX_DT_LOCAL) continue; // allocated on first upload
+    HFX_HIP(hipMalloc((void **)&e->arr[i], sizeof(double) * (size_t)std::max<long>(len[i], 1)));
+    // the reference zero-initialises its arrays (hf_array::setup + initialize_to_zero, src/eles.cpp:100-215)
+    HFX_HIP(hipMemset(e->arr[i], 0, sizeof(double) * (size_t)std::max<long>(len[i], 1)));
+  }
+  HFX_HIP(hipMalloc((void **)&e->nan_flag, sizeof(unsigned long long)));
+  HFX_HIP(hipMemset(e->nan_flag, 0xff, sizeof(unsigned long long)));
+  e->red_blocks = 1024;
+  HFX_HIP(hipMalloc((void **)&e->red_buf, sizeof(double) * e->red_blocks));
+  *out = e;
+  return 0;
+}
+
+int hfx_eles_destroy(hfx_eles *e)
+{
+  if (!e) return 0;
+  free_operator(e->opp_0); free_operator(e->opp_3); free_operator(e->opp_6);
+  for (int i = 0; i < 3; i++)
+  {
+    free_operator(e->opp_1[i]); free_operator(e->opp_2[i]); free_operator(e->opp_4[i]); free_operator(e->opp_5[i]);
+  }
+  double *m[] = {e->detjac_upts, e->JGinv_upts, e->detjac_fpts, e->JGinv_fpts, e->tdA_fpts, e->norm_fpts};
+  for (double *p : m)
+    if (p) (void)hipFree(p);
+  for (int i = 0; i < HFX_N_ARRAYS; i++)
+    if (e->arr[i]) (void)hipFree(e->arr[i]);
+  if (e->nan_flag) (void)hipFree(e->nan_flag);
+  if (e->red_buf) (void)hipFree(e->red_buf);
+  fused_destroy(e);
+  delete e;
+  return 0;
+}
+
+int hfx_eles_upload(hfx_eles *e, int id, const double *host)
+{
+  HFX_CHECK(e && host, "hfx_eles_upload: NULL argument");
+  HFX_CHECK(id >= 0 && id < HFX_N_ARRAYS, "hfx_eles_upload: bad array id %d", id);
+  if (!e->arr[id]) HFX_HIP(hipMalloc((void **)&e->arr[id], sizeof(double) * (size_t)std::max<long>(e->arr_len[id], 1)));
+  HFX_HIP(hipStreamSynchronize(e->ctx->stream));
+  HFX_HIP(hipMemcpy(e->arr[id], host, sizeof(double) * (size_t)e->arr_len[id], hipMemcpyHostToDevice));
+  if (id == HFX_SRC_UPTS) e->src_nonzero = true;
+  return 0;
+}
+
+int hfx_eles_download(hfx_eles *e, int id, double *host)
+{
+  HFX_CHECK(e && host, "hfx_eles_download: NULL argument");
+  HFX_CHECK(id >= 0 && id < HFX_N_ARRAYS, "hfx_eles_download: bad array id %d", id);
+  HFX_CHECK(e->arr[id] != nullptr, "hfx_eles_download: array %d was never uploaded", id);
+  HFX_HIP(hipStreamSynchronize(e->ctx->stream));
+  HFX_HIP(hipMemcpy(host, e->arr[id], sizeof(double) * (size_t)e->arr_len[id], hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int hfx_eles_device_ptr(hfx_eles *e, int id, double **dev)
+{
+  HFX_CHECK(e && dev, "hfx_eles_device_ptr: NULL argument");
+  HFX_CHECK(id >= 0 && id < HFX_N_ARRAYS, "hfx_eles_device_ptr: bad array id %d", id);
+  *dev = e->arr[id];
+  return 0;
+}
+
+// ---- eles::* ----------------------------------------------------------------
+int hfx_eles_extrapolate_solution(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0; /* src/eles.cpp:1362 */
+  const Operator *ops[1] = {&e->opp_0};
+  const double *in[1] = {e->arr[HFX_DISU_UPTS0]};
+  return contract_multi_in(e->ctx, ops, 1, in, e->arr[HFX_DISU_FPTS], (long)e->n_eles * e->n_fields, 0);
+}
+
+int hfx_eles_calculate_gradient(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  HFX_CHECK(e->viscous_ops, "calculate_gradient: block was registered without opp_4");
+  const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
+  const Operator *ops[3] = {&e->opp_4[0], &e->opp_4[1], &e->opp_4[2]};
+  double *out[3] = {e->arr[HFX_GRAD_DISU_UPTS], e->arr[HFX_GRAD_DISU_UPTS] + slab, e->arr[HFX_GRAD_DISU_UPTS] + 2 * slab};
+  return contract_multi_out(e->ctx, ops, e->n_dims, e->arr[HFX_DISU_UPTS0], out, (long)e->n_eles * e->n_fields, 0);
+}
+
+int hfx_eles_evaluate_invFlux(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  const long plane = (long)e->n_upts * e->n_eles;
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(invflux_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane,
+                       e->ctx->params.gamma, e->arr[HFX_DISU_UPTS0], e->JGinv_upts, e->arr[HFX_TDISF_UPTS]);
+  else
+    hipLaunchKernelGGL(invflux_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane,
+                       e->ctx->params.gamma, e->arr[HFX_DISU_UPTS0], e->JGinv_upts, e->arr[HFX_TDISF_UPTS]);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+int hfx_eles_correct_gradient(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  HFX_CHECK(e->viscous_ops, "correct_gradient: block was registered without opp_5/opp_6");
+  hfx_ctx *ctx = e->ctx;
+  const long slab_u = (long)e->n_upts * e->n_eles * e->n_fields;
+  const long ncols = (long)e->n_eles * e->n_fields;
+  // (i) grad_disu_upts(:,:,:,d) += opp_5[d] * delta_disu_fpts
+  {
+    const Operator *ops[3] = {&e->opp_5[0], &e->opp_5[1], &e->opp_5[2]};
+    double *out[3] = {e->arr[HFX_GRAD_DISU_UPTS], e->arr[HFX_GRAD_DISU_UPTS] + slab_u, e->arr[HFX_GRAD_DISU_UPTS] + 2 * slab_u};
+    if (contract_multi_out(ctx, ops, e->n_dims, e->arr[HFX_DELTA_DISU_FPTS], out, ncols, 1)) return 1;
+  }
+  // (ii) grad_disu_fpts(:,:,:,d) = opp_6 * grad_disu_upts(:,:,:,d): the dim slabs are contiguous -> one launch
+  {
+    const Operator *ops[1] = {&e->opp_6};
+    const double *in[1] = {e->arr[HFX_GRAD_DISU_UPTS]};
+    if (contract_multi_in(ctx, ops, 1, in, e->arr[HFX_GRAD_DISU_FPTS], ncols * e->n_dims, 0)) return 1;
+  }
+  // (iii) reference -> physical, in place, at solution and flux points
+  const long pu = (long)e->n_upts * e->n_eles, pf = (long)e->n_fpts * e->n_eles;
+  if (e->n_dims == 2)
+  {
+    hipLaunchKernelGGL(grad_transform_kernel<2>, dim3(nblocks(pu, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, pu,
+                       e->detjac_upts, e->JGinv_upts, e->arr[HFX_GRAD_DISU_UPTS]);
+    hipLaunchKernelGGL(grad_transform_kernel<2>, dim3(nblocks(pf, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, pf,
+                       e->detjac_fpts, e->JGinv_fpts, e->arr[HFX_GRAD_DISU_FPTS]);
+  }
+  else
+  {
+    hipLaunchKernelGGL(grad_transform_kernel<3>, dim3(nblocks(pu, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, pu,
+                       e->detjac_upts, e->JGinv_upts, e->arr[HFX_GRAD_DISU_UPTS]);
+    hipLaunchKernelGGL(grad_transform_kernel<3>, dim3(nblocks(pf, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, pf,
+                       e->detjac_fpts, e->JGinv_fpts, e->arr[HFX_GRAD_DISU_FPTS]);
+  }
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+int hfx_eles_evaluate_viscFlux(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  const long plane = (long)e->n_upts * e->n_eles;
+  const Phys P = e->ctx->phys();
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(viscflux_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane, P,
+                       e->arr[HFX_DISU_UPTS0], e->arr[HFX_GRAD_DISU_UPTS], e->JGinv_upts, e->arr[HFX_TDISF_UPTS]);
+  else
+    hipLaunchKernelGGL(viscflux_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane, P,
+                       e->arr[HFX_DISU_UPTS0], e->arr[HFX_GRAD_DISU_UPTS], e->JGinv_upts, e->arr[HFX_TDISF_UPTS]);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+int hfx_eles_extrapolate_totalFlux(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
+  const Operator *ops[3] = {&e->opp_1[0], &e->opp_1[1], &e->opp_1[2]};
+  const double *in[3] = {e->arr[HFX_TDISF_UPTS], e->arr[HFX_TDISF_UPTS] + slab, e->arr[HFX_TDISF_UPTS] + 2 * slab};
+  return contract_multi_in(e->ctx, ops, e->n_dims, in, e->arr[HFX_NORM_TDISF_FPTS], (long)e->n_eles * e->n_fields, 0);
+}
+
+int hfx_eles_calculate_divergence(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
+  const Operator *ops[3] = {&e->opp_2[0], &e->opp_2[1], &e->opp_2[2]};
+  const double *in[3] = {e->arr[HFX_TDISF_UPTS], e->arr[HFX_TDISF_UPTS] + slab, e->arr[HFX_TDISF_UPTS] + 2 * slab};
+  return contract_multi_in(e->ctx, ops, e->n_dims, in, e->arr[HFX_DIV_TCONF_UPTS], (long)e->n_eles * e->n_fields, 0);
+}
+
+int hfx_eles_calculate_corrected_divergence(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  // norm_tconf -= norm_tdisf (overwriting norm_tconf, src/eles.cpp:1746) is fused into the tile load;
+  // div_tconf += opp_3 * norm_tconf; NaN scan -> device flag
+  const Operator *ops[1] = {&e->opp_3};
+  const double *in[1] = {e->arr[HFX_NORM_TCONF_FPTS]};
+  return contract_multi_in(e->ctx, ops, 1, in, e->arr[HFX_DIV_TCONF_UPTS], (long)e->n_eles * e->n_fields, 1,
+                           e->arr[HFX_NORM_TDISF_FPTS], e->arr[HFX_NORM_TCONF_FPTS], e->nan_flag);
+}
+
+int hfx_eles_AdvanceSolution(hfx_eles *e, int in_step, int adv_type)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  hfx_ctx *ctx = e->ctx;
+  HFX_CHECK(ctx->have_params, "parameters not set");
+  HFX_CHECK(adv_type >= 0 && adv_type <= 4, "ERROR: Time integration type not recognised ... ");
+  const int nst = (adv_type == 0) ? 1 : (adv_type <= 2) ? 4 : (adv_type == 3) ? 5 : 14;
+  HFX_CHECK(in_step >= 0 && in_step < nst, "AdvanceSolution: stage %d out of range for adv_type %d", in_step, adv_type);
+  AdvArgs a;
+  a.n = (long)e->n_upts * e->n_eles * e->n_fields;
+  a.plane = (long)e->n_upts * e->n_eles;
+  a.n_upts = e->n_upts;
+  a.adv_type = adv_type;
+  a.in_step = in_step;
+  a.dt_local_on = (ctx->params.dt_type == 2);
+  HFX_CHECK(!a.dt_local_on || e->arr[HFX_DT_LOCAL], "dt_type 2 needs HFX_DT_LOCAL uploaded");
+  a.dt = ctx->params.dt;
+  a.rk_a = (adv_type >= 3) ? ctx->params.RK_a[in_step] : 0.0;
+  a.rk_b = (adv_type >= 3) ? ctx->params.RK_b[in_step] : 0.0;
+  a.u0 = e->arr[HFX_DISU_UPTS0];
+  a.u1 = e->arr[HFX_DISU_UPTS1];
+  a.div = e->arr[HFX_DIV_TCONF_UPTS];
+  a.detjac = e->detjac_upts;
+  a.src = e->src_nonzero ? e->arr[HFX_SRC_UPTS] : nullptr;
+  a.dt_local = e->arr[HFX_DT_LOCAL];
+  hipLaunchKernelGGL(advance_kernel, dim3(nblocks(a.n, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, a);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+int hfx_eles_check_nan(hfx_eles *e, long *first_nan)
+{
+  HFX_CHECK(e && first_nan, "NULL argument");
+  unsigned long long v = 0;
+  HFX_HIP(hipStreamSynchronize(e->ctx->stream));
+  HFX_HIP(hipMemcpy(&v, e->nan_flag, sizeof v, hipMemcpyDeviceToHost));
+  *first_nan = (v == ~0ull) ? -1 : (long)v;
+  if (v != ~0ull) HFX_HIP(hipMemset(e->nan_flag, 0xff, sizeof(unsigned long long)));
+  return 0;
+}
+
+int hfx_eles_compute_res_upts(hfx_eles *e, int norm_type, int field, double *out)
+{
+  HFX_CHECK(e && out, "NULL argument");
+  HFX_CHECK(norm_type >= 0 && norm_type <= 2, "compute_res_upts: bad norm type");
+  HFX_CHECK(field >= 0 && field < e->n_fields, "compute_res_upts: bad field");
+  const long plane = (long)e->n_upts * e->n_eles;
+  const int nb = (int)std::min<long>(e->red_blocks, std::max<long>(1, (plane + PT_BLOCK - 1) / PT_BLOCK));
+  hipLaunchKernelGGL(res_partial_kernel, dim3(nb), dim3(PT_BLOCK), 0, e->ctx->stream, plane, norm_type,
+                     e->arr[HFX_DIV_TCONF_UPTS] + field * plane, e->detjac_upts,
+                     e->src_nonzero ? e->arr[HFX_SRC_UPTS] + field * plane : nullptr, e->red_buf);
+  HFX_HIP(hipGetLastError());
+  std::vector<double> part(nb);
+  HFX_HIP(hipStreamSynchronize(e->ctx->stream));
+  HFX_HIP(hipMemcpy(part.data(), e->red_buf, sizeof(double) * nb, hipMemcpyDeviceToHost));
+  double s = 0.0;
+  for (int i = 0; i < nb; i++) s = (norm_type == 0) ? std::max(s, part[i]) : s + part[i];
+  *out = s;
+  return 0;
+}
+
+// ---- int_inters -----------------------------------------------------------------
+int hfx_int_inters_create(hfx_ctx *ctx, hfx_eles *left, hfx_eles *right, int n_inters, int nfpi, const int *L,
+                          const int *R, hfx_inters **out)
+{
+  HFX_CHECK(ctx && left && right && out, "hfx_int_inters_create: NULL argument");
+  HFX_CHECK(n_inters >= 0 && nfpi > 0, "hfx_int_inters_create: bad sizes");
+  HFX_CHECK(n_inters == 0 || (L && R), "hfx_int_inters_create: NULL table");
+  HFX_CHECK(left->n_dims == right->n_dims && left->n_fields == right->n_fields, "left/right blocks differ in n_dims");
+  const long np = (long)n_inters * nfpi;
+  const long pl = (long)left->n_fpts * left->n_eles, pr = (long)right->n_fpts * right->n_eles;
+  // validate the tables on the host before any kernel dereferences them, and check that
+  // every flux point is owned by at most one face side (race-free scatter)
+  {
+    std::vector<unsigned char> seen_l(pl, 0), seen_r(left == right ? 0 : pr, 0);
+    std::vector<unsigned char> &sr = (left == right) ? seen_l : seen_r;
+    for (long q = 0; q < np; q++)
+    {
+      HFX_CHECK(L[q] >= 0 && L[q] < pl, "face table L[%ld] = %d out of range", q, L[q]);
+      HFX_CHECK(R[q] >= 0 && R[q] < pr, "face table R[%ld] = %d out of range", q, R[q]);
+      HFX_CHECK(!seen_l[L[q]], "flux point %d appears on two face sides", L[q]);
+      seen_l[L[q]] = 1;
+      HFX_CHECK(!sr[R[q]], "flux point %d appears on two face sides", R[q]);
+      sr[R[q]] = 1;
+    }
+  }
+  hfx_inters *f = new hfx_inters();
+  f->ctx = ctx; f->left = left; f->right = right; f->n_inters = n_inters; f->n_fpts_per_inter = nfpi;
+  f->hL.assign(L, L + np);
+  f->hR.assign(R, R + np);
+  HFX_HIP(hipMalloc((void **)&f->L, sizeof(int) * (size_t)std::max<long>(np, 1)));
+  HFX_HIP(hipMalloc((void **)&f->R, sizeof(int) * (size_t)std::max<long>(np, 1)));
+  HFX_HIP(hipMemcpy(f->L, L, sizeof(int) * (size_t)np, hipMemcpyHostToDevice));
+  HFX_HIP(hipMemcpy(f->R, R, sizeof(int) * (size_t)np, hipMemcpyHostToDevice));
+  left->faces_attached.push_back(f);
+  if (right != left) right->faces_attached.push_back(f);
+  fused_invalidate(left);
+  fused_invalidate(right);
+  *out = f;
+  return 0;
+}
+
+int hfx_inters_destroy(hfx_inters *f)
+{
+  if (!f) return 0;
+  for (hfx_eles *e : {f->left, f->right})
+    if (e)
+    {
+      auto &v = e->faces_attached;
+      v.erase(std::remove(v.begin(), v.end(), f), v.end());
+      fused_invalidate(e);
+    }
+  if (f->L) (void)hipFree(f->L);
+  if (f->R) (void)hipFree(f->R);
+  delete f;
+  return 0;
+}
+
+static FaceArgs face_args(hfx_inters *f)
+{
+  FaceArgs a;
+  hfx_eles *l = f->left, *r = f->right;
+  a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
+  a.L = f->L; a.R = f->R;
+  a.plane_l = (long)l->n_fpts * l->n_eles; a.plane_r = (long)r->n_fpts * r->n_eles;
+  a.disu_l = l->arr[HFX_DISU_FPTS]; a.disu_r = r->arr[HFX_DISU_FPTS];
+  a.norm_l = l->norm_fpts;
+  a.tdA_l = l->tdA_fpts; a.tdA_r = r->tdA_fpts;
+  a.tconf_l = l->arr[HFX_NORM_TCONF_FPTS]; a.tconf_r = r->arr[HFX_NORM_TCONF_FPTS];
+  a.delta_l = l->arr[HFX_DELTA_DISU_FPTS]; a.delta_r = r->arr[HFX_DELTA_DISU_FPTS];
+  a.grad_l = l->arr[HFX_GRAD_DISU_FPTS]; a.grad_r = r->arr[HFX_GRAD_DISU_FPTS];
+  return a;
+}
+
+int hfx_int_inters_calculate_common_invFlux(hfx_inters *f)
+{
+  HFX_CHECK(f, "NULL inters");
+  if (f->n_inters == 0) return 0;
+  HFX_CHECK(f->ctx->have_params, "parameters not set");
+  const FaceArgs a = face_args(f);
+  const Phys P = f->ctx->phys();
+  if (f->left->n_dims == 2)
+    hipLaunchKernelGGL(common_invflux_kernel<2>, dim3(nblocks(a.npairs, PT_BLOCK)), dim3(PT_BLOCK), 0, f->ctx->stream, a, P);
+  else
+    hipLaunchKernelGGL(common_invflux_kernel<3>, dim3(nblocks(a.npairs, PT_BLOCK)), dim3(PT_BLOCK), 0, f->ctx->stream, a, P);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f)
+{
+  HFX_CHECK(f, "NULL inters");
+  if (f->n_inters == 0) return 0;
+  HFX_CHECK(f->ctx->have_params, "parameters not set");
+  const FaceArgs a = face_args(f);
+  const Phys P = f->ctx->phys();
+  if (f->left->n_dims == 2)
+    hipLaunchKernelGGL(common_viscflux_kernel<2>, dim3(nblocks(a.npairs, PT_BLOCK)), dim3(PT_BLOCK), 0, f->ctx->stream, a, P);
+  else
+    hipLaunchKernelGGL(common_viscflux_kernel<3>, dim3(nblocks(a.npairs, PT_BLOCK)), dim3(PT_BLOCK), 0, f->ctx->stream, a, P);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the caller contract -----------------------------------------------------------
+int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
+{
+  HFX_CHECK(e, "NULL eles");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  const int viscous = e->ctx->params.viscous;
+  /* the call order of src/solver.cpp:65-216 */
+  if (hfx_eles_extrapolate_solution(e)) return 1;
+  if (viscous && hfx_eles_calculate_gradient(e)) return 1;
+  if (hfx_eles_evaluate_invFlux(e)) return 1;
+  for (int b = 0; b < nfb; b++)
+    if (hfx_int_inters_calculate_common_invFlux(faces[b])) return 1;
+  if (viscous)
+  {
+    if (hfx_eles_correct_gradient(e)) return 1;
+    if (hfx_eles_evaluate_viscFlux(e)) return 1;
+  }
+  if (hfx_eles_extrapolate_totalFlux(e)) return 1;
+  if (hfx_eles_calculate_divergence(e)) return 1;
+  if (viscous)
+    for (int b = 0; b < nfb; b++)
+      if (hfx_int_inters_calculate_common_viscFlux(faces[b])) return 1;
+  return hfx_eles_calculate_corrected_divergence(e);
+}
+
+int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int fused)
+{
+  HFX_CHECK(e, "NULL eles");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  const int adv = e->ctx->params.adv_type;
+  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14; /* src/HiFiLES.cpp:143-150 */
+  if (fused) return fused_run_steps(e, faces, nfb, n_steps);
+  for (int s = 0; s < n_steps; s++)
+    for (int rk = 0; rk < nst; rk++)
+    {
+      if (hfx_CalcResidual(e, faces, nfb)) return 1;
+      if (hfx_eles_AdvanceSolution(e, rk, adv)) return 1;
+    }
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,111 @@
+// hfx_internal.hpp -- internal types of libhfx (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/hfx.h"
+#include "physics.hpp"
+
+namespace hfx
+{
+
+void set_error(const char *fmt, ...);
+
+#define HFX_HIP(call)                                                                          \
+  do                                                                                           \
+  {                                                                                            \
+    hipError_t _e = (call);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+    {                                                                                          \
+      hfx::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      return 1;                                                                                \
+    }                                                                                          \
+  } while (0)
+
+#define HFX_CHECK(cond, ...)       \
+  do                               \
+  {                                \
+    if (!(cond))                   \
+    {                              \
+      hfx::set_error(__VA_ARGS__); \
+      return 1;                    \
+    }                              \
+  } while (0)
+
+// One registered operator matrix (m x k, column-major) on the device, in the
+// forms the contraction kernels consume.
+struct Operator
+{
+  int m = 0, k = 0;
+  double *dense = nullptr; // (m,k) column-major
+  // ELL form: exact non-zeros of every row in ASCENDING column order (the
+  // reference dgemm sums l ascending, src/funcs.cpp:110-117), padded with
+  // (val 0, col = first column of the row).  Row-interleaved: entry q of row r
+  // at [r + m*q].
+  int nnz_max = 0;
+  double *ell_val = nullptr;
+  int *ell_idx = nullptr;
+  long nnz_total = 0;
+  bool present() const { return dense != nullptr; }
+};
+
+} // namespace hfx
+
+struct hfx_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hfx_params params{};
+  bool have_params = false;
+  int contract_mode = HFX_CONTRACT_AUTO;
+  int n_cu = 256;
+  hfx::Phys phys() const
+  {
+    hfx::Phys P;
+    P.gamma = params.gamma;
+    P.prandtl = params.prandtl;
+    P.rt_inf = params.rt_inf;
+    P.mu_inf = params.mu_inf;
+    P.c_sth = params.c_sth;
+    P.fix_vis = params.fix_vis;
+    P.ldg_beta = params.ldg_beta;
+    P.ldg_tau = params.ldg_tau;
+    P.riemann = params.riemann_solve_type;
+    P.viscous = params.viscous;
+    return P;
+  }
+};
+
+struct hfx_eles
+{
+  hfx_ctx *ctx = nullptr;
+  int n_eles = 0, n_upts = 0, n_fpts = 0, n_fields = 0, n_dims = 0, ele_type = 0, order = 0;
+  bool viscous_ops = false;
+  hfx::Operator opp_0, opp_1[3], opp_2[3], opp_3, opp_4[3], opp_5[3], opp_6;
+  // metrics
+  double *detjac_upts = nullptr, *JGinv_upts = nullptr, *detjac_fpts = nullptr, *JGinv_fpts = nullptr,
+         *tdA_fpts = nullptr, *norm_fpts = nullptr;
+  // state / work arrays, indexed by hfx_array_id
+  double *arr[HFX_N_ARRAYS] = {};
+  long arr_len[HFX_N_ARRAYS] = {};
+  bool src_nonzero = false;
+  unsigned long long *nan_flag = nullptr; // device: smallest flat index of a NaN in div_tconf, or ~0
+  double *red_buf = nullptr;              // device partial sums for reductions
+  int red_blocks = 0;
+  // fused-path private data (built lazily)
+  struct FusedData *fused = nullptr;
+  std::vector<struct hfx_inters *> faces_attached;
+};
+
+struct hfx_inters
+{
+  hfx_ctx *ctx = nullptr;
+  hfx_eles *left = nullptr, *right = nullptr;
+  int n_inters = 0, n_fpts_per_inter = 0;
+  int *L = nullptr, *R = nullptr; // device (n_fpts_per_inter, n_inters)
+  std::vector<int> hL, hR;        // host copies (for building per-element tables)
+};

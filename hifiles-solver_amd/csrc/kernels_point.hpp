@@ -1,0 +1,291 @@
+// kernels_point.hpp -- per-point, per-face-point and per-DOF kernels of the hot path.
+//
+//   evaluate_invFlux      /root/reference/src/eles.cpp:1415-1478
+//   gradient transform    /root/reference/src/eles.cpp:1958-2011 (second half of correct_gradient)
+//   evaluate_viscFlux     /root/reference/src/eles.cpp:2285-2392
+//   common inviscid flux  /root/reference/src/int_inters.cpp:160-249
+//   common viscous flux   /root/reference/src/int_inters.cpp:254-343
+//   AdvanceSolution       /root/reference/src/eles.cpp:1080-1265
+//   compute_res_upts      /root/reference/src/eles.cpp:5045-5074
+//
+// Layout notes (hf_array, first index fastest): fields of one point are a
+// whole (pt,ele) plane apart, so consecutive lanes = consecutive points give
+// coalesced loads/stores per field.  The 3x3 JGinv block of a point is AoS
+// (9 consecutive doubles); a wave reads 64 consecutive blocks = one contiguous
+// 4.6 kB run.
+#pragma once
+#include "hfx_internal.hpp"
+
+namespace hfx
+{
+
+constexpr int PT_BLOCK = 256;
+
+// ---- eles::evaluate_invFlux ------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void invflux_kernel(long plane, const double gamma, const double *__restrict__ U,
+                                                           const double *__restrict__ JGinv, double *__restrict__ tdisf)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double u[NF], f[NF * ND], JG[ND * ND];
+#pragma unroll
+  for (int k = 0; k < NF; k++) u[k] = U[p + k * plane];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) JG[q] = JGinv[p * (ND * ND) + q];
+  calc_invf<ND>(gamma, u, f);
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < ND; m++) t += JG[l + ND * m] * f[k + NF * m];
+      tdisf[p + (k + NF * l) * plane] = t;
+    }
+}
+
+// ---- second half of eles::correct_gradient: reference -> physical gradient, in place
+// g_phys(d,k) = sum_l (inv_detjac * g_ref(l,k)) * JGinv(l,d)
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void grad_transform_kernel(long plane, const double *__restrict__ detjac,
+                                                                  const double *__restrict__ JGinv, double *G)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double JG[ND * ND];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) JG[q] = JGinv[p * (ND * ND) + q];
+  const double inv_detjac = 1.0 / detjac[p];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    double tg[ND], cg[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) tg[d] = G[p + (k + NF * d) * plane];
+#pragma unroll
+    for (int d = 0; d < ND; d++) cg[d] = 0.0;
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      const double temp = inv_detjac * tg[l];
+#pragma unroll
+      for (int d = 0; d < ND; d++) cg[d] += temp * JG[l + ND * d];
+    }
+#pragma unroll
+    for (int d = 0; d < ND; d++) G[p + (k + NF * d) * plane] = cg[d];
+  }
+}
+
+// ---- eles::evaluate_viscFlux (LES off): tdisf += JGinv * F_v -------------------
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void viscflux_kernel(long plane, const Phys P, const double *__restrict__ U,
+                                                            const double *__restrict__ G,
+                                                            const double *__restrict__ JGinv, double *tdisf)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double u[NF], g[NF * ND], f[NF * ND], JG[ND * ND];
+#pragma unroll
+  for (int k = 0; k < NF; k++) u[k] = U[p + k * plane];
+#pragma unroll
+  for (int q = 0; q < NF * ND; q++) g[q] = G[p + q * plane];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) JG[q] = JGinv[p * (ND * ND) + q];
+  calc_visf<ND>(P, u, g, f);
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      double t = tdisf[p + (k + NF * l) * plane];
+#pragma unroll
+      for (int m = 0; m < ND; m++) t += JG[l + ND * m] * f[k + NF * m];
+      tdisf[p + (k + NF * l) * plane] = t;
+    }
+}
+
+// ---- int_inters::calculate_common_invFlux ------------------------------------
+struct FaceArgs
+{
+  long npairs; // n_fpts_per_inter * n_inters
+  const int *L, *R;
+  long plane_l, plane_r; // n_fpts*n_eles of the left / right element block
+  const double *disu_l, *disu_r;
+  const double *norm_l; // left block norm_fpts (fpt,ele,dim)
+  const double *tdA_l, *tdA_r;
+  double *tconf_l, *tconf_r;
+  double *delta_l, *delta_r;
+  const double *grad_l, *grad_r;
+};
+
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void common_invflux_kernel(const FaceArgs a, const Phys P)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long il = a.L[q], ir = a.R[q];
+  double ul[NF], ur[NF], n[ND], fn[NF];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu_l[il + k * a.plane_l];
+    ur[k] = a.disu_r[ir + k * a.plane_r];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.norm_l[il + m * a.plane_l];
+  riemann_flux<ND>(P, ul, ur, n, fn);
+  const double tl = a.tdA_l[il], tr = a.tdA_r[ir];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    a.tconf_l[il + k * a.plane_l] = fn[k] * tl;
+    a.tconf_r[ir + k * a.plane_r] = -fn[k] * tr;
+  }
+  if (P.viscous)
+  {
+    const double beta = ldg_switch<ND>(P.ldg_beta, n);
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      const double uc = 0.5 * (ul[k] + ur[k]) - beta * (ul[k] - ur[k]);
+      a.delta_l[il + k * a.plane_l] = uc - ul[k];
+      a.delta_r[ir + k * a.plane_r] = uc - ur[k];
+    }
+  }
+}
+
+// ---- int_inters::calculate_common_viscFlux (LES off) ---------------------------
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void common_viscflux_kernel(const FaceArgs a, const Phys P)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long il = a.L[q], ir = a.R[q];
+  double ul[NF], ur[NF], gl[NF * ND], gr[NF * ND], fl[NF * ND], fr[NF * ND], n[ND];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu_l[il + k * a.plane_l];
+    ur[k] = a.disu_r[ir + k * a.plane_r];
+  }
+#pragma unroll
+  for (int s = 0; s < NF * ND; s++)
+  {
+    gl[s] = a.grad_l[il + s * a.plane_l];
+    gr[s] = a.grad_r[ir + s * a.plane_r];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.norm_l[il + m * a.plane_l];
+  calc_visf<ND>(P, ul, gl, fl);
+  calc_visf<ND>(P, ur, gr, fr);
+  const double beta = ldg_switch<ND>(P.ldg_beta, n);
+  const double tl = a.tdA_l[il], tr = a.tdA_r[ir];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    double fn = 0.0;
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      const double fc = (0.5 + beta) * fl[k + NF * l] + (0.5 - beta) * fr[k + NF * l];
+      fn += fc * n[l];
+    }
+    fn -= P.ldg_tau * (ur[k] - ul[k]);
+    a.tconf_l[il + k * a.plane_l] += fn * tl;
+    a.tconf_r[ir + k * a.plane_r] += -fn * tr;
+  }
+}
+
+// ---- eles::AdvanceSolution ------------------------------------------------------
+struct AdvArgs
+{
+  long n;     // n_upts*n_eles*n_fields
+  long plane; // n_upts*n_eles
+  int n_upts;
+  int adv_type, in_step, dt_local_on;
+  double dt, rk_a, rk_b;
+  double *u0, *u1;
+  const double *div, *detjac, *src, *dt_local;
+};
+
+__global__ __launch_bounds__(PT_BLOCK) void advance_kernel(const AdvArgs a)
+{
+  const long q = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (q >= a.n) return;
+  const long p = q % a.plane;
+  const double s = a.src ? a.src[q] : 0.0;
+  const double dt = a.dt_local_on ? a.dt_local[p / a.n_upts] : a.dt;
+  const double dd = a.div[q] / a.detjac[p];
+  double u = a.u0[q];
+  if (a.adv_type == 0)
+    u -= dt * (dd - s);
+  else if (a.adv_type == 1)
+  {
+    if (a.in_step == 0) a.u1[q] = u; // disu_upts(1) = disu_upts(0)
+    if (a.in_step < 3)
+      u -= dt / 3.0 * (dd - s);
+    else
+    {
+      const double rhs = -dd + s;
+      const double r1 = (a.in_step == 0) ? u : a.u1[q];
+      u = 3.0 / 4.0 * u + 1.0 / 4.0 * r1 + dt / 4.0 * rhs;
+    }
+  }
+  else if (a.adv_type == 2)
+  {
+    if (a.in_step == 0) a.u1[q] = u;
+    if (a.in_step < 2 || a.in_step == 3)
+      u -= dt / 2.0 * (dd - s);
+    else if (a.in_step == 2)
+    {
+      const double rhs = -dd + s;
+      u = 1.0 / 3.0 * u + 2.0 / 3.0 * a.u1[q] + dt / 6.0 * rhs;
+    }
+  }
+  else
+  {
+    const double rhs = -dd + s;
+    const double r1 = a.rk_a * a.u1[q] + dt * rhs;
+    a.u1[q] = r1;
+    u += a.rk_b * r1;
+  }
+  a.u0[q] = u;
+}
+
+// ---- eles::compute_res_upts: deterministic two-level reduction -----------------------
+// level 1: one partial per workgroup (fixed tree), level 2 on the host in block order
+__global__ __launch_bounds__(PT_BLOCK) void res_partial_kernel(long plane, int norm_type, const double *__restrict__ div,
+                                                               const double *__restrict__ detjac,
+                                                               const double *__restrict__ src, double *partial)
+{
+  __shared__ double sm[PT_BLOCK];
+  double acc = 0.0;
+  for (long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x; p < plane; p += (long)gridDim.x * PT_BLOCK)
+  {
+    const double r = div[p] / detjac[p] - (src ? src[p] : 0.0);
+    if (norm_type == 0)
+      acc = fmax(acc, fabs(r));
+    else if (norm_type == 1)
+      acc += fabs(r);
+    else
+      acc += r * r;
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = PT_BLOCK / 2; s > 0; s >>= 1)
+  {
+    if (threadIdx.x < s)
+      sm[threadIdx.x] = (norm_type == 0) ? fmax(sm[threadIdx.x], sm[threadIdx.x + s]) : sm[threadIdx.x] + sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+} // namespace hfx

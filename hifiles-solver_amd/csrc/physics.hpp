@@ -1,0 +1,305 @@
+// physics.hpp -- point physics of the HiFiLES hot path as gfx950 device functions.
+//
+// Restated from the behaviour of the reference's CPU branch:
+//   inviscid / viscous point fluxes   /root/reference/src/flux.cpp:33,74,129,257
+//   Rusanov / RoeM / HLLC             /root/reference/src/inters.cpp:277,327,439
+//   LDG common solution / flux        /root/reference/src/inters.cpp:561,615
+// All values live in registers (fully unrolled small arrays); ND is a template
+// parameter so the 2-D and 3-D variants are separate straight-line code.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hfx
+{
+
+// physics scalars handed to kernels by value (a snapshot of the reference's
+// global `run_input`, include/input.h)
+struct Phys
+{
+  double gamma, prandtl, rt_inf, mu_inf, c_sth, fix_vis, ldg_beta, ldg_tau;
+  int riemann, viscous;
+};
+
+// f(k,m) = f[k + NF*m]
+template <int ND>
+__device__ __forceinline__ void calc_invf(const double gamma, const double (&u)[ND + 2], double (&f)[(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+  const double rrho = u[0];
+  double v[ND];
+  double vsq = 0.0;
+#pragma unroll
+  for (int d = 0; d < ND; d++)
+  {
+    v[d] = u[d + 1] / rrho;
+  }
+  // ((vx*vx)+(vy*vy))+(vz*vz), the reference's association (flux.cpp:43,87)
+  vsq = v[0] * v[0] + v[1] * v[1];
+  if (ND == 3) vsq = vsq + v[ND - 1] * v[ND - 1];
+  const double p = (gamma - 1.0) * (u[ND + 1] - (0.5 * u[0] * vsq));
+#pragma unroll
+  for (int m = 0; m < ND; m++)
+  {
+    f[0 + NF * m] = u[m + 1];
+#pragma unroll
+    for (int d = 0; d < ND; d++)
+    {
+      const double mom = u[d + 1] * v[m];
+      f[(d + 1) + NF * m] = (d == m) ? (p + mom) : mom;
+    }
+    f[(ND + 1) + NF * m] = v[m] * (u[ND + 1] + p);
+  }
+}
+
+// viscosity law shared by flux and time-step code (flux.cpp:319-321)
+__device__ __forceinline__ double viscosity(const Phys &P, const double inte)
+{
+  const double rt_ratio = (P.gamma - 1.0) * inte / P.rt_inf;
+  double mu = P.mu_inf * pow(rt_ratio, 1.5) * (1.0 + P.c_sth) / (rt_ratio + P.c_sth);
+  mu = mu + P.fix_vis * (P.mu_inf - mu);
+  return mu;
+}
+
+// grad_u(k,m) = g[k + NF*m]; RANS off (mu_t = 0)
+template <int ND>
+__device__ __forceinline__ void calc_visf(const Phys &P, const double (&u)[ND + 2], const double (&g)[(ND + 2) * ND],
+                                          double (&f)[(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+  const double rho = u[0];
+  double v[ND];
+  double ke2 = 0.0; // u*u+v*v+w*w
+#pragma unroll
+  for (int d = 0; d < ND; d++) v[d] = u[d + 1] / rho;
+  ke2 = v[0] * v[0] + v[1] * v[1];
+  if (ND == 3) ke2 = ke2 + v[ND - 1] * v[ND - 1];
+  const double inte = u[ND + 1] / rho - 0.5 * ke2;
+  const double mu = viscosity(P, inte);
+
+  // velocity gradients dv[d][m] = d v_d / d x_m
+  double dv[ND][ND];
+#pragma unroll
+  for (int d = 0; d < ND; d++)
+#pragma unroll
+    for (int m = 0; m < ND; m++) dv[d][m] = (g[(d + 1) + NF * m] - g[0 + NF * m] * v[d]) / rho;
+
+  double de[ND];
+#pragma unroll
+  for (int m = 0; m < ND; m++)
+  {
+    double conv = v[0] * dv[0][m] + v[1] * dv[1][m];
+    if (ND == 3) conv = conv + v[ND - 1] * dv[ND - 1][m];
+    const double dke = 0.5 * ke2 * g[0 + NF * m] + rho * conv;
+    de[m] = (g[(ND + 1) + NF * m] - dke - g[0 + NF * m] * inte) / rho;
+  }
+
+  double divv = dv[0][0] + dv[1][1];
+  if (ND == 3) divv = divv + dv[ND - 1][ND - 1];
+  const double diag = divv / 3.0;
+
+  double tau[ND][ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++)
+#pragma unroll
+    for (int b = 0; b < ND; b++)
+      tau[a][b] = (a == b) ? 2.0 * mu * (dv[a][a] - diag) : mu * ((a < b) ? (dv[a][b] + dv[b][a]) : (dv[b][a] + dv[a][b]));
+
+  const double kap = (mu / P.prandtl) * P.gamma;
+#pragma unroll
+  for (int m = 0; m < ND; m++)
+  {
+    f[0 + NF * m] = 0.0;
+#pragma unroll
+    for (int d = 0; d < ND; d++) f[(d + 1) + NF * m] = -tau[d][m];
+    double work = v[0] * tau[0][m] + v[1] * tau[1][m];
+    if (ND == 3) work = work + v[ND - 1] * tau[ND - 1][m];
+    f[(ND + 1) + NF * m] = -(work + kap * de[m]);
+  }
+}
+
+template <int ND>
+__device__ __forceinline__ void normal_flux(const double (&f)[(ND + 2) * ND], const double (&n)[ND], double (&fn)[ND + 2])
+{
+  constexpr int NF = ND + 2;
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < ND; l++) s += f[k + NF * l] * n[l];
+    fn[k] = s;
+  }
+}
+
+// left/right primitive helpers
+template <int ND>
+struct Side
+{
+  double v[ND], vn, vsq, p, h;
+};
+
+template <int ND>
+__device__ __forceinline__ Side<ND> side_state(const double gamma, const double (&u)[ND + 2], const double (&n)[ND])
+{
+  Side<ND> s;
+  s.vn = 0.0;
+  s.vsq = 0.0;
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+  {
+    s.v[i] = u[i + 1] / u[0];
+    s.vn += s.v[i] * n[i];
+    s.vsq += s.v[i] * s.v[i];
+  }
+  s.p = (gamma - 1.0) * (u[ND + 1] - 0.5 * u[0] * s.vsq);
+  s.h = (u[ND + 1] + s.p) / u[0];
+  return s;
+}
+
+// inters.cpp:277-324
+template <int ND>
+__device__ __forceinline__ void rusanov_flux(const double gamma, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
+                                             const double (&fnl)[ND + 2], const double (&fnr)[ND + 2],
+                                             const double (&n)[ND], double (&fn)[ND + 2])
+{
+  const Side<ND> L = side_state<ND>(gamma, ul, n), R = side_state<ND>(gamma, ur, n);
+  const double eig = sqrt(gamma * (L.p + R.p) / (ul[0] + ur[0])) + 0.5 * fabs(L.vn + R.vn);
+#pragma unroll
+  for (int k = 0; k < ND + 2; k++) fn[k] = 0.5 * ((fnl[k] + fnr[k]) - eig * (ur[k] - ul[k]));
+}
+
+// inters.cpp:327-437
+template <int ND>
+__device__ __forceinline__ void roeM_flux(const double gamma, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
+                                          const double (&fnl)[ND + 2], const double (&fnr)[ND + 2],
+                                          const double (&n)[ND], double (&fn)[ND + 2])
+{
+  constexpr int NF = ND + 2;
+  const Side<ND> L = side_state<ND>(gamma, ul, n), R = side_state<ND>(gamma, ur, n);
+  const double drho = ur[0] - ul[0], dp = R.p - L.p, dh = R.h - L.h, dvn = R.vn - L.vn;
+  const double sq_rho = sqrt(ur[0] / ul[0]);
+  const double rrho = 1.0 / (1.0 + sq_rho);
+  const double ratr = sq_rho * rrho;
+  const double ra = sq_rho * ul[0];
+  const double ha = L.h * rrho + R.h * ratr;
+  double va[ND], qq = 0.0, va_n = 0.0;
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+  {
+    va[i] = L.v[i] * rrho + R.v[i] * ratr;
+    qq += va[i] * va[i];
+    va_n += n[i] * va[i];
+  }
+  const double aa = sqrt((gamma - 1.0) * (ha - 0.5 * qq));
+  const double rcp_aa = 1.0 / aa;
+  const double abs_ma = fabs(va_n * rcp_aa);
+  double b1 = fmax(0.0, fmax(va_n + aa, R.vn + aa));
+  double b2 = fmin(0.0, fmin(va_n - aa, L.vn - aa));
+  double b1b2 = b1 * b2;
+  const double rcp = 1.0 / (b1 - b2);
+  b1 = b1 * rcp;
+  b2 = b2 * rcp;
+  b1b2 = b1b2 * rcp;
+  const double hh = 1.0 - ((L.p < R.p) ? (L.p / R.p) : (R.p / L.p));
+  const double ff = (abs_ma != 0.0) ? pow(abs_ma, hh) : 1.0;
+  const double gg = ff / (1.0 + abs_ma);
+  double du[NF], bdq[NF];
+#pragma unroll
+  for (int i = 0; i < NF - 1; i++) du[i] = ur[i] - ul[i];
+  du[ND + 1] = ur[0] * R.h - ul[0] * L.h;
+  bdq[0] = drho - ff * dp * rcp_aa * rcp_aa;
+  bdq[ND + 1] = bdq[0] * ha + ra * dh;
+#pragma unroll
+  for (int i = 0; i < ND; i++) bdq[i + 1] = bdq[0] * va[i] + ra * ((R.v[i] - L.v[i]) - n[i] * dvn);
+#pragma unroll
+  for (int i = 0; i < NF; i++) fn[i] = (b1 * fnl[i] - b2 * fnr[i]) + b1b2 * (du[i] - gg * bdq[i]);
+}
+
+// inters.cpp:439-532.  NOTE a_m uses the NORMAL Roe velocity only (inters.cpp:497) -- kept as is.
+template <int ND>
+__device__ __forceinline__ void hllc_flux(const double gamma, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
+                                          const double (&fnl)[ND + 2], const double (&fnr)[ND + 2],
+                                          const double (&n)[ND], double (&fn)[ND + 2])
+{
+  const Side<ND> L = side_state<ND>(gamma, ul, n), R = side_state<ND>(gamma, ur, n);
+  const double sq_rho = sqrt(ur[0] / ul[0]);
+  const double rrho = 1.0 / (sq_rho + 1.0);
+  const double vn_m = rrho * (L.vn + sq_rho * R.vn);
+  const double h_m = rrho * (L.h + sq_rho * R.h);
+  const double a_m = sqrt((gamma - 1.0) * (h_m - 0.5 * vn_m * vn_m));
+  const double S_R = vn_m + a_m;
+  const double S_L = vn_m - a_m;
+  const double S_star = (R.p - L.p + ul[0] * L.vn * (S_L - L.vn) - ur[0] * R.vn * (S_R - R.vn)) /
+                        (ul[0] * (S_L - L.vn) - ur[0] * (S_R - R.vn));
+  if (S_L >= 0)
+  {
+#pragma unroll
+    for (int k = 0; k < ND + 2; k++) fn[k] = fnl[k];
+  }
+  else if (S_star >= 0)
+  {
+    const double rcp_star = S_L - S_star;
+    const double pst = S_L * (L.p + ul[0] * (S_L - L.vn) * (S_star - L.vn));
+    fn[0] = S_star * (S_L * ul[0] - fnl[0]) / rcp_star;
+#pragma unroll
+    for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_L * ul[i + 1] - fnl[i + 1]) + pst * n[i]) / rcp_star;
+    fn[ND + 1] = (S_star * (S_L * ul[ND + 1] - fnl[ND + 1]) + pst * S_star) / rcp_star;
+  }
+  else if (S_R >= 0)
+  {
+    const double rcp_star = S_R - S_star;
+    const double pst = S_R * (R.p + ur[0] * (S_R - R.vn) * (S_star - R.vn));
+    fn[0] = S_star * (S_R * ur[0] - fnr[0]) / rcp_star;
+#pragma unroll
+    for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_R * ur[i + 1] - fnr[i + 1]) + pst * n[i]) / rcp_star;
+    fn[ND + 1] = (S_star * (S_R * ur[ND + 1] - fnr[ND + 1]) + pst * S_star) / rcp_star;
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < ND + 2; k++) fn[k] = fnr[k];
+  }
+}
+
+// Riemann dispatch (int_inters.cpp:185-205); fnl/fnr are the normal point fluxes of the two states
+template <int ND>
+__device__ __forceinline__ void riemann_flux(const Phys &P, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
+                                             const double (&n)[ND], double (&fn)[ND + 2])
+{
+  constexpr int NF = ND + 2;
+  double fl[NF * ND], fr[NF * ND], fnl[NF], fnr[NF];
+  calc_invf<ND>(P.gamma, ul, fl);
+  calc_invf<ND>(P.gamma, ur, fr);
+  normal_flux<ND>(fl, n, fnl);
+  normal_flux<ND>(fr, n, fnr);
+  if (P.riemann == 0)
+    rusanov_flux<ND>(P.gamma, ul, ur, fnl, fnr, n, fn);
+  else if (P.riemann == 2)
+    roeM_flux<ND>(P.gamma, ul, ur, fnl, fnr, n, fn);
+  else
+    hllc_flux<ND>(P.gamma, ul, ur, fnl, fnr, n, fn);
+}
+
+// the "consistent switch" (inters.cpp:568-581, :620-633): exact floating-point
+// zero tests on the LEFT element's unit normal.
+template <int ND>
+__device__ __forceinline__ double ldg_switch(double beta, const double (&n)[ND])
+{
+  if (beta != 0.0)
+  {
+    if (n[0] < 0.0)
+      beta = -beta;
+    else if (n[0] == 0.0)
+    {
+      if ((n[0] + n[1]) < 0.0)
+        beta = -beta;
+      else if ((n[0] + n[1]) == 0.0)
+      {
+        if (ND == 3 && (n[0] + n[ND - 1]) < 0.0) beta = -beta;
+      }
+    }
+  }
+  return beta;
+}
+
+} // namespace hfx

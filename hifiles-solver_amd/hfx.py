@@ -1,0 +1,227 @@
+"""ctypes binding of libhfx.so (the C ABI declared in include/hfx.h).
+
+Plumbing only: every call goes straight to the HIP library; there is no CPU
+fallback.  If the shared library is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libhfx.so")
+HEADER = os.path.join(ROOT, "include", "hfx.h")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+(DISU_UPTS0, DISU_UPTS1, DISU_FPTS, TDISF_UPTS, NORM_TDISF_FPTS, NORM_TCONF_FPTS, DIV_TCONF_UPTS,
+ DELTA_DISU_FPTS, GRAD_DISU_UPTS, GRAD_DISU_FPTS, SRC_UPTS, DT_LOCAL) = range(12)
+CONTRACT_AUTO, CONTRACT_DENSE, CONTRACT_SPARSE = 0, 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("gamma", "prandtl", "rt_inf", "mu_inf", "c_sth", "fix_vis", "ldg_beta", "ldg_tau", "dt")] + \
+               [(n, C.c_int) for n in
+                ("viscous", "riemann_solve_type", "vis_riemann_solve_type", "adv_type", "dt_type", "n_rk")] + \
+               [("RK_a", C.c_double * 16), ("RK_b", C.c_double * 16)]
+
+
+class ElesDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_eles", "n_upts", "n_fpts", "n_fields", "n_dims", "ele_type", "order")] + [
+        ("opp_0", dp), ("opp_1", dp * 3), ("opp_2", dp * 3), ("opp_3", dp), ("opp_4", dp * 3),
+        ("opp_5", dp * 3), ("opp_6", dp),
+        ("detjac_upts", dp), ("JGinv_upts", dp), ("detjac_fpts", dp), ("JGinv_fpts", dp),
+        ("tdA_fpts", dp), ("norm_fpts", dp)]
+
+
+def declared_symbols():
+    """Names of every function include/hfx.h declares."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hfx_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+class HfxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HfxError("libhfx.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.hfx_last_error.restype = C.c_char_p
+        _lib.hfx_ctx_stream.restype = C.c_void_p
+        _lib.hfx_ctx_stream.argtypes = [C.c_void_p]
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HfxError(lib().hfx_last_error().decode())
+
+
+def _f(a):
+    a = np.asfortranarray(np.array(a, dtype=np.float64))
+    return a
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        check(lib().hfx_ctx_create(C.c_int(device), C.byref(self.h)))
+
+    def set_params(self, p):
+        self.params = p
+        check(lib().hfx_ctx_set_params(self.h, C.byref(p)))
+
+    def set_contract_mode(self, mode):
+        check(lib().hfx_ctx_set_contract_mode(self.h, C.c_int(mode)))
+
+    def synchronize(self):
+        check(lib().hfx_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().hfx_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib().hfx_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Eles:
+    """One element block; `data` maps the names of hfx_eles_desc to numpy arrays (hf_array / Fortran order)."""
+
+    def __init__(self, ctx, sizes, data, ele_type=4, order=0):
+        self.ctx = ctx
+        self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims = [int(s) for s in sizes]
+        d = ElesDesc()
+        d.n_eles, d.n_upts, d.n_fpts, d.n_fields, d.n_dims = self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims
+        d.ele_type, d.order = ele_type, order
+        keep = []
+
+        def ptr(name):
+            if name not in data:
+                return None
+            a = _f(data[name])
+            keep.append(a)
+            return a.ctypes.data_as(dp)
+
+        d.opp_0 = ptr("opp_0"); d.opp_3 = ptr("opp_3"); d.opp_6 = ptr("opp_6")
+        for i in range(self.n_dims):
+            d.opp_1[i] = ptr("opp_1_%d" % i); d.opp_2[i] = ptr("opp_2_%d" % i)
+            d.opp_4[i] = ptr("opp_4_%d" % i); d.opp_5[i] = ptr("opp_5_%d" % i)
+        for k in ("detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts"):
+            setattr(d, k, ptr(k))
+        self.h = C.c_void_p()
+        check(lib().hfx_eles_create(ctx.h, C.byref(d), C.byref(self.h)))
+        nu, nfp, ne, nf, nd = self.n_upts, self.n_fpts, self.n_eles, self.n_fields, self.n_dims
+        self.shapes = {
+            DISU_UPTS0: (nu, ne, nf), DISU_UPTS1: (nu, ne, nf), DISU_FPTS: (nfp, ne, nf),
+            TDISF_UPTS: (nu, ne, nf, nd), NORM_TDISF_FPTS: (nfp, ne, nf), NORM_TCONF_FPTS: (nfp, ne, nf),
+            DIV_TCONF_UPTS: (nu, ne, nf), DELTA_DISU_FPTS: (nfp, ne, nf), GRAD_DISU_UPTS: (nu, ne, nf, nd),
+            GRAD_DISU_FPTS: (nfp, ne, nf, nd), SRC_UPTS: (nu, ne, nf), DT_LOCAL: (ne,)}
+
+    def upload(self, array_id, a):
+        a = _f(a)
+        assert a.shape == self.shapes[array_id], (a.shape, self.shapes[array_id])
+        check(lib().hfx_eles_upload(self.h, C.c_int(array_id), a.ctypes.data_as(dp)))
+
+    def download(self, array_id):
+        a = np.zeros(self.shapes[array_id], dtype=np.float64, order="F")
+        check(lib().hfx_eles_download(self.h, C.c_int(array_id), a.ctypes.data_as(dp)))
+        return a
+
+    def device_ptr(self, array_id):
+        p = dp()
+        check(lib().hfx_eles_device_ptr(self.h, C.c_int(array_id), C.byref(p)))
+        return C.cast(p, C.c_void_p).value
+
+    def _call(self, name, *args):
+        check(getattr(lib(), name)(self.h, *args))
+
+    def extrapolate_solution(self): self._call("hfx_eles_extrapolate_solution")
+    def calculate_gradient(self): self._call("hfx_eles_calculate_gradient")
+    def evaluate_invFlux(self): self._call("hfx_eles_evaluate_invFlux")
+    def correct_gradient(self): self._call("hfx_eles_correct_gradient")
+    def evaluate_viscFlux(self): self._call("hfx_eles_evaluate_viscFlux")
+    def extrapolate_totalFlux(self): self._call("hfx_eles_extrapolate_totalFlux")
+    def calculate_divergence(self): self._call("hfx_eles_calculate_divergence")
+    def calculate_corrected_divergence(self): self._call("hfx_eles_calculate_corrected_divergence")
+
+    def AdvanceSolution(self, in_step, adv_type):
+        self._call("hfx_eles_AdvanceSolution", C.c_int(in_step), C.c_int(adv_type))
+
+    def check_nan(self):
+        v = C.c_long(0)
+        check(lib().hfx_eles_check_nan(self.h, C.byref(v)))
+        return v.value
+
+    def compute_res_upts(self, norm_type, field):
+        v = C.c_double(0)
+        check(lib().hfx_eles_compute_res_upts(self.h, C.c_int(norm_type), C.c_int(field), C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.h:
+            lib().hfx_eles_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class IntInters:
+    def __init__(self, ctx, left, right, L, R):
+        L = np.asfortranarray(np.array(L, dtype=np.int32))
+        R = np.asfortranarray(np.array(R, dtype=np.int32))
+        self.n_fpts_per_inter, self.n_inters = L.shape
+        self.h = C.c_void_p()
+        check(lib().hfx_int_inters_create(ctx.h, left.h, right.h, C.c_int(self.n_inters), C.c_int(self.n_fpts_per_inter),
+                                          L.ctypes.data_as(ip), R.ctypes.data_as(ip), C.byref(self.h)))
+
+    def calculate_common_invFlux(self): check(lib().hfx_int_inters_calculate_common_invFlux(self.h))
+    def calculate_common_viscFlux(self): check(lib().hfx_int_inters_calculate_common_viscFlux(self.h))
+
+    def close(self):
+        if self.h:
+            lib().hfx_inters_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def _face_array(faces):
+    arr = (C.c_void_p * max(1, len(faces)))()
+    for i, f in enumerate(faces):
+        arr[i] = f.h
+    return arr
+
+
+def CalcResidual(eles, faces):
+    check(lib().hfx_CalcResidual(eles.h, _face_array(faces), C.c_int(len(faces))))
+
+
+def run_steps(eles, faces, n_steps, fused=False):
+    check(lib().hfx_run_steps(eles.h, _face_array(faces), C.c_int(len(faces)), C.c_int(n_steps), C.c_int(1 if fused else 0)))
+
+
+def params_from(data):
+    """hfx Params from a dict holding the scalar names of the fixtures / host setup."""
+    s = lambda k, dflt=0.0: float(np.ravel(data[k])[0]) if k in data else dflt
+    p = Params()
+    for k in ("gamma", "prandtl", "rt_inf", "mu_inf", "c_sth", "fix_vis", "ldg_beta", "ldg_tau", "dt"):
+        setattr(p, k, s(k))
+    for k in ("viscous", "riemann_solve_type", "vis_riemann_solve_type", "adv_type", "dt_type"):
+        setattr(p, k, int(s(k)))
+    ra, rb = np.ravel(data["RK_a"]), np.ravel(data["RK_b"])
+    p.n_rk = len(ra)
+    for i in range(len(ra)):
+        p.RK_a[i] = float(ra[i])
+        p.RK_b[i] = float(rb[i])
+    return p

@@ -1,0 +1,159 @@
+/* hfx.h -- C ABI of libhfx: the MI355X (gfx950) implementation of the HiFiLES
+ * per-RK-stage hot path.
+ *
+ * The reference has no FFI: the seam this library sits behind is the C++ class
+ * API of `eles`, `int_inters` (`bdy_inters`, `mpi_inters`) that
+ * CalcResidual (/root/reference/src/solver.cpp:50-223) and the RK loop
+ * (/root/reference/src/HiFiLES.cpp:201-217) call, plus the legacy `_GPU` seam
+ * (include/cuda_kernels.h:31-120, hf_array::cp_cpu_gpu / cp_gpu_cpu
+ * include/hf_array.h:541-580).  Every entry point below names the reference
+ * method it replaces.  All arrays are `double`, column-major in the hf_array
+ * layout (include/hf_array.h:303-325): a(i,j,k,l) = data[i + d0*(j + d1*(k + d2*l))].
+ *
+ * Conventions
+ *  - plain pointers and sizes only; opaque handles own all device state
+ *  - every function returns 0 on success, non-zero on error; the message is
+ *    available from hfx_last_error() (the reference's FatalError = print + exit,
+ *    include/error.h:33-43; the adapter maps non-zero to FatalError)
+ *  - not re-entrant per context; one context <-> one device (the reference is
+ *    single-threaded per rank, one rank <-> one device, src/geometry.cpp:97)
+ *  - the authoritative copy of the state lives on the device between explicit
+ *    hfx_eles_download() calls (placed where the legacy code had cp_*_gpu_cpu,
+ *    src/eles.cpp:998-1062)
+ */
+#ifndef HFX_H
+#define HFX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hfx_ctx hfx_ctx;
+typedef struct hfx_eles hfx_eles;
+typedef struct hfx_inters hfx_inters;
+
+/* Frozen scalars the path reads from the reference's global `run_input`
+ * (include/input.h; src/input.cpp:138-187,596-614; data/RK_coeff.dat). */
+typedef struct hfx_params
+{
+  double gamma, prandtl, rt_inf, mu_inf, c_sth, fix_vis;
+  double ldg_beta, ldg_tau;
+  double dt;
+  int viscous;
+  int riemann_solve_type;     /* 0 Rusanov, 2 RoeM, 3 HLLC (src/int_inters.cpp:185-205) */
+  int vis_riemann_solve_type; /* 0 LDG (the only one the reference implements) */
+  int adv_type;               /* 0 Euler, 1 RK24, 2 RK34, 3 RK45, 4 RK414 (src/eles.cpp:1080) */
+  int dt_type;                /* 0/1 one dt for all elements, 2 per-element dt_local */
+  int n_rk;
+  double RK_a[16], RK_b[16];
+} hfx_params;
+
+/* Registration data of one element class = what a constructed reference
+ * `eles` object holds (include/eles.h:659-899).  Host pointers; copied once. */
+typedef struct hfx_eles_desc
+{
+  int n_eles, n_upts, n_fpts, n_fields, n_dims;
+  int ele_type; /* 0 tri, 1 quad, 2 tet, 3 pri, 4 hex (include/eles.h "ele_type") */
+  int order;
+  const double *opp_0;    /* (n_fpts,n_upts)  src/eles.cpp:3074 */
+  const double *opp_1[3]; /* (n_fpts,n_upts)  :3145 */
+  const double *opp_2[3]; /* (n_upts,n_upts)  :3230 */
+  const double *opp_3;    /* (n_upts,n_fpts)  :3320 */
+  const double *opp_4[3]; /* (n_upts,n_upts)  :3375 ; NULL when inviscid */
+  const double *opp_5[3]; /* (n_upts,n_fpts)  :3455 ; NULL when inviscid */
+  const double *opp_6;    /* (n_fpts,n_upts)  :3540 ; NULL when inviscid */
+  const double *detjac_upts; /* (n_upts,n_eles)               src/eles.cpp:4048 */
+  const double *JGinv_upts;  /* (n_dims,n_dims,n_upts,n_eles)  :4050 */
+  const double *detjac_fpts; /* (n_fpts,n_eles)               :4230 */
+  const double *JGinv_fpts;  /* (n_dims,n_dims,n_fpts,n_eles)  :4233 */
+  const double *tdA_fpts;    /* (n_fpts,n_eles)               :4234 */
+  const double *norm_fpts;   /* (n_fpts,n_eles,n_dims)        :4235 */
+} hfx_eles_desc;
+
+/* arrays of an element block addressable by upload/download */
+enum hfx_array_id
+{
+  HFX_DISU_UPTS0 = 0,   /* disu_upts(0)      (n_upts,n_eles,n_fields) */
+  HFX_DISU_UPTS1 = 1,   /* disu_upts(1) */
+  HFX_DISU_FPTS = 2,    /* (n_fpts,n_eles,n_fields) */
+  HFX_TDISF_UPTS = 3,   /* (n_upts,n_eles,n_fields,n_dims) */
+  HFX_NORM_TDISF_FPTS = 4,
+  HFX_NORM_TCONF_FPTS = 5,
+  HFX_DIV_TCONF_UPTS = 6, /* div_tconf_upts(0) */
+  HFX_DELTA_DISU_FPTS = 7,
+  HFX_GRAD_DISU_UPTS = 8, /* (n_upts,n_eles,n_fields,n_dims) */
+  HFX_GRAD_DISU_FPTS = 9, /* (n_fpts,n_eles,n_fields,n_dims) */
+  HFX_SRC_UPTS = 10,      /* (n_upts,n_eles,n_fields); zero unless uploaded */
+  HFX_DT_LOCAL = 11,      /* (n_eles) */
+  HFX_N_ARRAYS = 12
+};
+
+/* which implementation the operator contractions use */
+enum hfx_contract_mode
+{
+  HFX_CONTRACT_AUTO = 0,   /* sparse when the registered operator is sparse enough, else dense */
+  HFX_CONTRACT_DENSE = 1,  /* dense FP64 MFMA GEMM, as the reference's sparse_* = 0 */
+  HFX_CONTRACT_SPARSE = 2  /* exact-zero skipping, as the reference's sparse_* = 1 (src/eles.cpp:3114) */
+};
+
+const char *hfx_last_error(void);
+int hfx_version(void);
+
+/* ---- context ---------------------------------------------------------- */
+int hfx_ctx_create(int device, hfx_ctx **out);
+int hfx_ctx_destroy(hfx_ctx *ctx);
+int hfx_ctx_set_params(hfx_ctx *ctx, const hfx_params *p);
+int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode);
+int hfx_ctx_synchronize(hfx_ctx *ctx);
+/* the HIP stream (hipStream_t) all kernels of this context are launched on */
+void *hfx_ctx_stream(hfx_ctx *ctx);
+
+/* ---- element blocks (reference class eles) ----------------------------- */
+int hfx_eles_create(hfx_ctx *ctx, const hfx_eles_desc *desc, hfx_eles **out);
+int hfx_eles_destroy(hfx_eles *e);
+/* replaces hf_array::cp_cpu_gpu / cp_gpu_cpu (include/hf_array.h:541-580) */
+int hfx_eles_upload(hfx_eles *e, int array_id, const double *host);
+int hfx_eles_download(hfx_eles *e, int array_id, double *host);
+/* raw device pointer of an array (for zero-copy interop with a resident caller) */
+int hfx_eles_device_ptr(hfx_eles *e, int array_id, double **dev);
+
+int hfx_eles_extrapolate_solution(hfx_eles *e);           /* eles::extrapolate_solution           src/eles.cpp:1360 */
+int hfx_eles_calculate_gradient(hfx_eles *e);             /* eles::calculate_gradient             :1823 */
+int hfx_eles_evaluate_invFlux(hfx_eles *e);               /* eles::evaluate_invFlux               :1415 */
+int hfx_eles_correct_gradient(hfx_eles *e);               /* eles::correct_gradient               :1890 */
+int hfx_eles_evaluate_viscFlux(hfx_eles *e);              /* eles::evaluate_viscFlux              :2285 */
+int hfx_eles_extrapolate_totalFlux(hfx_eles *e);          /* eles::extrapolate_totalFlux          :1549 */
+int hfx_eles_calculate_divergence(hfx_eles *e);           /* eles::calculate_divergence           :1651 */
+int hfx_eles_calculate_corrected_divergence(hfx_eles *e); /* eles::calculate_corrected_divergence :1738 */
+int hfx_eles_AdvanceSolution(hfx_eles *e, int in_step, int adv_type); /* eles::AdvanceSolution    :1080 */
+/* the NaN scan of src/eles.cpp:1781-1795 as a device flag: *first_nan = flat index
+ * into div_tconf_upts(0) of a NaN seen since the last call, or -1.  Synchronizes. */
+int hfx_eles_check_nan(hfx_eles *e, long *first_nan);
+/* eles::compute_res_upts (src/eles.cpp:5045): norm_type 0 max, 1 L1 sum, 2 L2 sum */
+int hfx_eles_compute_res_upts(hfx_eles *e, int norm_type, int field, double *out);
+
+/* ---- interior faces (reference class int_inters) ----------------------- */
+/* L, R: (n_fpts_per_inter, n_inters) offsets `fpt + n_fpts*ele` into the
+ * (fpt,ele) plane of the left / right element block: the hf_array<double*>
+ * tables of include/inters.h:86-116 minus the owning array base, with the
+ * flux-point permutation `lut` (src/inters.cpp:153-262) already applied to R,
+ * exactly as int_inters::set_interior (src/int_inters.cpp:67-121) wires them. */
+int hfx_int_inters_create(hfx_ctx *ctx, hfx_eles *left, hfx_eles *right, int n_inters, int n_fpts_per_inter,
+                          const int *L, const int *R, hfx_inters **out);
+int hfx_inters_destroy(hfx_inters *f);
+int hfx_int_inters_calculate_common_invFlux(hfx_inters *f);  /* int_inters::calculate_common_invFlux  src/int_inters.cpp:160 */
+int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f); /* int_inters::calculate_common_viscFlux src/int_inters.cpp:254 */
+
+/* ---- the caller contract ---------------------------------------------- */
+/* CalcResidual (src/solver.cpp:50-223) for one element block and its interior
+ * face blocks, LES / RANS / forcing off; same call order as the reference. */
+int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
+/* n_steps time steps = the RK-stage loop of src/HiFiLES.cpp:194-217:
+ * for each stage CalcResidual + AdvanceSolution.  `fused` != 0 selects the
+ * fused per-stage kernels (same results to rounding), 0 the per-method path. */
+int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,173 @@
+"""GPU parity of the per-method path (libhfx through its C ABI) against the genuine reference's
+fixtures and against the oracle, on the same inputs.
+
+Tolerance: FP64; the HIP kernels use FMA contraction and (dense mode) the MFMA's internal 4-term
+sums, the reference's CPU branch does neither, so agreement is to rounding: 1e-12 relative to the
+array's largest magnitude for one residual, 1e-11 after a full RK step.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import hfx
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hex_*.npz")))
+RTOL1 = 1e-12
+RTOLS = 1e-11
+
+
+def relerr(a, b):
+    scale = np.abs(b).max()
+    return np.abs(a - b).max() / (scale if scale > 0 else 1.0)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hfx.Context(0)
+    yield c
+    c.close()
+
+
+def build(ctx, d, mode=hfx.CONTRACT_AUTO):
+    ctx.set_params(hfx.params_from(d))
+    ctx.set_contract_mode(mode)
+    sz = [int(v) for v in d["sizes"]]
+    e = hfx.Eles(ctx, sz[:5], d, ele_type=sz[6], order=sz[5])
+    faces = []
+    for t in range(3):
+        if "int%d_L" % t in d:
+            faces.append(hfx.IntInters(ctx, e, e, d["int%d_L" % t], d["int%d_R" % t]))
+    e.upload(hfx.DISU_UPTS0, d["u_init"])
+    return e, faces
+
+
+@pytest.mark.parametrize("mode", [hfx.CONTRACT_SPARSE, hfx.CONTRACT_DENSE])
+def test_every_intermediate(ctx, mode):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p2_n3_deformed.npz")))
+    e, faces = build(ctx, d, mode)
+    e.extrapolate_solution()
+    assert relerr(e.download(hfx.DISU_FPTS), d["s0_disu_fpts"]) < RTOL1
+    e.calculate_gradient()
+    assert relerr(e.download(hfx.GRAD_DISU_UPTS), d["s0_grad_disu_upts_ref"]) < RTOL1
+    e.evaluate_invFlux()
+    assert relerr(e.download(hfx.TDISF_UPTS), d["s0_tdisf_upts_inv"]) < RTOL1
+    for f in faces:
+        f.calculate_common_invFlux()
+    assert relerr(e.download(hfx.NORM_TCONF_FPTS), d["s0_norm_tconf_fpts_inv"]) < RTOL1
+    assert relerr(e.download(hfx.DELTA_DISU_FPTS), d["s0_delta_disu_fpts"]) < RTOL1
+    e.correct_gradient()
+    assert relerr(e.download(hfx.GRAD_DISU_UPTS), d["s0_grad_disu_upts"]) < RTOL1
+    assert relerr(e.download(hfx.GRAD_DISU_FPTS), d["s0_grad_disu_fpts"]) < RTOL1
+    e.evaluate_viscFlux()
+    assert relerr(e.download(hfx.TDISF_UPTS), d["s0_tdisf_upts"]) < RTOL1
+    e.extrapolate_totalFlux()
+    assert relerr(e.download(hfx.NORM_TDISF_FPTS), d["s0_norm_tdisf_fpts"]) < RTOL1
+    e.calculate_divergence()
+    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts_disc"]) < RTOL1
+    for f in faces:
+        f.calculate_common_viscFlux()
+    assert relerr(e.download(hfx.NORM_TCONF_FPTS), d["s0_norm_tconf_fpts"]) < RTOL1
+    e.calculate_corrected_divergence()
+    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOL1
+    # norm_tconf is left overwritten with norm_tconf - norm_tdisf (src/eles.cpp:1746)
+    assert relerr(e.download(hfx.NORM_TCONF_FPTS), d["s0_norm_tconf_fpts"] - d["s0_norm_tdisf_fpts"]) < RTOL1
+    assert e.check_nan() == -1
+    for fld in range(e.n_fields):
+        for nt in (1, 2):
+            got = e.compute_res_upts(nt, fld)
+            want = d["s0_res_sums"][fld, nt - 1]
+            assert abs(got - want) <= 1e-11 * abs(want)
+    for f in faces:
+        f.close()
+    e.close()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_stage_states_vs_reference(ctx, name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e, faces = build(ctx, d)
+    nstage = int(d["sizes"][7])
+    adv = int(np.ravel(d["adv_type"])[0])
+    steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
+    for st in steps:
+        for rk in range(nstage):
+            hfx.CalcResidual(e, faces)
+            if st == 0 and rk == 0:
+                assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOL1
+            e.AdvanceSolution(rk, adv)
+            key = "u_step%d_stage%d" % (st, rk)
+            if key in d:
+                assert relerr(e.download(hfx.DISU_UPTS0), d[key]) < RTOLS, key
+    assert e.check_nan() == -1
+    for f in faces:
+        f.close()
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["hex_p4_n3_deformed", "hex_p3_n3_deformed", "hex_p1_roem"])
+def test_dense_mfma_path_vs_reference(ctx, name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e, faces = build(ctx, d, hfx.CONTRACT_DENSE)
+    hfx.run_steps(e, faces, 1)
+    nstage = int(d["sizes"][7])
+    assert relerr(e.download(hfx.DISU_UPTS0), d["u_step0_stage%d" % (nstage - 1)]) < RTOLS
+    for f in faces:
+        f.close()
+    e.close()
+
+
+def test_run_steps_matches_oracle_two_steps(ctx, oracle):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p3_n3_deformed.npz")))
+    e, faces = build(ctx, d)
+    hfx.run_steps(e, faces, 2)
+    c = O.Case(d)
+    ce = c.c_eles()
+    cf, nb = c.c_faces()
+    for _ in range(2):
+        assert oracle.orc_rk_step(C.byref(ce), cf, nb, C.byref(c.params)) == -1
+    assert relerr(e.download(hfx.DISU_UPTS0), c.arr["u0"]) < RTOLS
+    assert relerr(e.download(hfx.DISU_UPTS1), c.arr["u1"]) < 1e-9  # RK register: small numbers, looser
+    for f in faces:
+        f.close()
+    e.close()
+
+
+def test_nan_flag_reports_first_index(ctx):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p1_rusanov.npz")))
+    e, faces = build(ctx, d)
+    u = np.array(d["u_init"], order="F")
+    u[3, 5, 0] = np.nan
+    e.upload(hfx.DISU_UPTS0, u)
+    hfx.CalcResidual(e, faces)
+    bad = e.check_nan()
+    div = e.download(hfx.DIV_TCONF_UPTS)
+    assert bad == int(np.flatnonzero(np.isnan(div.ravel(order="F")))[0])
+    assert e.check_nan() == -1  # flag is cleared by the read
+    for f in faces:
+        f.close()
+    e.close()
+
+
+def test_error_convention(ctx):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p1_rusanov.npz")))
+    e, faces = build(ctx, d)
+    with pytest.raises(hfx.HfxError):
+        e.AdvanceSolution(7, 3)  # stage out of range for RK45
+    L = np.array(d["int2_L"], order="F").copy()
+    L[0, 0] = 10 ** 8
+    with pytest.raises(hfx.HfxError):
+        hfx.IntInters(ctx, e, e, L, d["int2_R"])
+    p = hfx.params_from(d)
+    p.riemann_solve_type = 1
+    with pytest.raises(hfx.HfxError):
+        ctx.set_params(p)
+    for f in faces:
+        f.close()
+    e.close()
