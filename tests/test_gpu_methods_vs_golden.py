@@ -3,7 +3,8 @@ fixtures and against the oracle, on the same inputs.
 
 Tolerance: FP64; the HIP kernels use FMA contraction and (dense mode) the MFMA's internal 4-term
 sums, the reference's CPU branch does neither, so agreement is to rounding: 1e-12 relative to the
-array's largest magnitude for one residual, 1e-11 after a full RK step.
+array's largest magnitude for one residual (5e-11 for the divergence), 1e-11 after a full RK step.
+BASELINE.json's stated bar is 1e-10 on conserved residuals.
 """
 import ctypes as C
 import glob
@@ -20,6 +21,9 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hex_*.npz")))
 RTOL1 = 1e-12
+# div_tconf is a difference of terms ~1e3 times larger than itself (pressure-dominated energy
+# flux), so its relative rounding error is correspondingly larger
+RTOLD = 5e-11
 RTOLS = 1e-11
 
 
@@ -70,12 +74,12 @@ def test_every_intermediate(ctx, mode):
     e.extrapolate_totalFlux()
     assert relerr(e.download(hfx.NORM_TDISF_FPTS), d["s0_norm_tdisf_fpts"]) < RTOL1
     e.calculate_divergence()
-    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts_disc"]) < RTOL1
+    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts_disc"]) < RTOLD
     for f in faces:
         f.calculate_common_viscFlux()
     assert relerr(e.download(hfx.NORM_TCONF_FPTS), d["s0_norm_tconf_fpts"]) < RTOL1
     e.calculate_corrected_divergence()
-    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOL1
+    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOLD
     # norm_tconf is left overwritten with norm_tconf - norm_tdisf (src/eles.cpp:1746)
     assert relerr(e.download(hfx.NORM_TCONF_FPTS), d["s0_norm_tconf_fpts"] - d["s0_norm_tdisf_fpts"]) < RTOL1
     assert e.check_nan() == -1
@@ -100,7 +104,7 @@ def test_stage_states_vs_reference(ctx, name):
         for rk in range(nstage):
             hfx.CalcResidual(e, faces)
             if st == 0 and rk == 0:
-                assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOL1
+                assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOLD
             e.AdvanceSolution(rk, adv)
             key = "u_step%d_stage%d" % (st, rk)
             if key in d:
