@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- DOF-updates/s and ms/RK-stage of the HiFiLES hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n CELLS] [--order P] [--mode fused|methods|dense]
+
+One "step" is one time step = 5 RK stages (RK45), each stage = CalcResidual + AdvanceSolution
+(/root/reference/src/HiFiLES.cpp:201-217) over the whole mesh.  Workload at N=1: BASELINE.json
+configs[1], the Taylor-Green vortex on a generated periodic 32^3 hexahedral mesh, P4, Navier-Stokes,
+HLLC + LDG, fixed dt; inputs are resident in HBM before the timed region.
+For N>1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank advances its own
+32^3-element block (weak scaling).
+
+Prints ONE JSON line (rank 0).  The oracle under oracle/ is used only for the `cpu_baseline` leg.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "hifiles-solver_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak
+
+METHOD_NAMES = ["extrapolate_solution", "calculate_gradient", "evaluate_invFlux", "common_invFlux", "correct_gradient",
+                "evaluate_viscFlux", "extrapolate_totalFlux", "calculate_divergence", "common_viscFlux",
+                "calculate_corrected_divergence", "AdvanceSolution"]
+
+
+def method_bytes(c):
+    """ALGORITHMIC HBM bytes per element of each per-method entry point (compulsory reads + writes
+    of the arrays the method consumes / produces; operators are cache resident)."""
+    nu, nfp, nf, nd = c.n_upts, c.n_fpts, c.n_fields, c.n_dims
+    d = 8.0
+    b = {
+        "extrapolate_solution": d * (nu * nf + nfp * nf),
+        "calculate_gradient": d * (nu * nf + nu * nf * nd),
+        "evaluate_invFlux": d * (nu * nf + nu * nd * nd + nu * nf * nd),
+        # per flux point (each belongs to one face side): u, normal (left only -> 1/2), tdA, tconf, delta, 4-byte index
+        "common_invFlux": d * nfp * (nf + 0.5 * nd + 1 + nf + nf) + 4 * nfp,
+        # opp_5: delta + r/w grad_upts ; opp_6: grad_upts -> grad_fpts ; two in-place transforms with metrics
+        "correct_gradient": d * (nfp * nf + 2 * nu * nf * nd + nu * nf * nd + nfp * nf * nd
+                                 + 2 * nu * nf * nd + nu * (nd * nd + 1) + 2 * nfp * nf * nd + nfp * (nd * nd + 1)),
+        "evaluate_viscFlux": d * (nu * nf + nu * nf * nd + nu * nd * nd + 2 * nu * nf * nd),
+        "extrapolate_totalFlux": d * (nu * nf * nd + nfp * nf),
+        "calculate_divergence": d * (nu * nf * nd + nu * nf),
+        "common_viscFlux": d * nfp * (nf + nf * nd + 0.5 * nd + 1 + 2 * nf) + 4 * nfp,
+        "calculate_corrected_divergence": d * (2 * nfp * nf + nfp * nf + 2 * nu * nf),
+        "AdvanceSolution": d * (nu * nf + nu + 4 * nu * nf),
+    }
+    return b
+
+
+def stage_algorithmic_bytes(c):
+    """Compulsory HBM traffic of one fused RK stage per element (generalised):
+    state r/w u0,u1; volume metrics; disu_fpts write + own + neighbour read; grad_disu_fpts likewise;
+    face metrics."""
+    nu, nfp, nf, nd = c.n_upts, c.n_fpts, c.n_fields, c.n_dims
+    dbl = 4 * nu * nf + nu * (nd * nd + 1) + 3 * nfp * nf + 3 * nfp * nf * nd + nfp * (nd + 1 + nd * nd + 1)
+    return 8.0 * dbl
+
+
+def cpu_baseline(order, threads):
+    """The oracle (oracle/liboracle.so, the CPU restatement pinned against the genuine reference)
+    timed on this host: the same TGV case on a bounded sample mesh."""
+    import hfx_host as H
+    import oracle_py as O
+    orc = O.load()
+    out = {}
+    for label, n_cells, nthr, nsteps in (("1core", 8, 1, 1), ("allcores", 16, threads, 2)):
+        case = H.Case(n_cells, order=order)
+        reg = case.registration()
+        oc = O.Case(reg)
+        e = oc.c_eles()
+        f, nb = oc.c_faces()
+        orc.orc_set_threads(nthr)
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            assert orc.orc_rk_step(C.byref(e), f, nb, C.byref(oc.params)) == -1
+        dt = time.perf_counter() - t0
+        dofs = case.n_eles * case.n_upts * case.n_fields * case.n_stages * nsteps
+        out[label] = dict(value=dofs / dt, seconds=dt, n_cells=n_cells, steps=nsteps, threads=nthr)
+        case.close()
+    orc.orc_set_threads(1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=32, help="cells per direction per GPU")
+    ap.add_argument("--order", type=int, default=4)
+    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "methods", "dense"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+
+    import hfx
+    import hfx_host as H
+
+    case = H.Case(args.n, order=args.order)
+    case.to_device(local_rank)
+    ctx, e, faces, nb = case.handles()
+    lib = hfx.lib()
+
+    mode = args.mode
+    fused_ok = False
+    if mode in ("auto", "fused"):
+        rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(1))
+        fused_ok = (rc == 0)
+        if mode == "fused" and not fused_ok:
+            raise SystemExit("fused path unavailable: " + lib.hfx_last_error().decode())
+        mode = "fused" if fused_ok else "methods"
+    if mode == "dense":
+        hfx.check(lib.hfx_ctx_set_contract_mode(ctx, C.c_int(hfx.CONTRACT_DENSE)))
+    fused = 1 if mode == "fused" else 0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def run(nsteps):
+        hfx.check(lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(nsteps), C.c_int(fused)))
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # state sanity: the run must not have produced NaNs (src/eles.cpp:1781-1795)
+    bad = C.c_long(0)
+    hfx.check(lib.hfx_eles_check_nan(e, C.byref(bad)))
+    assert bad.value == -1, "NaN in the residual at flat index %d" % bad.value
+
+    n_stages = case.n_stages
+    dof_per_rank = case.n_eles * case.n_upts * case.n_fields
+    total_updates = dof_per_rank * world * n_stages * args.steps
+    value = total_updates / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    ms_per_stage = ms_per_step / n_stages
+
+    roof = None
+    cpu = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, timed live with HIP events on the library's stream
+        if fused:
+            kt = (C.c_double * 8)()
+            names = (C.c_char * 256)()
+            hfx.check(lib.hfx_time_fused_kernels(e, faces, C.c_int(nb), C.c_int(10), kt, names))
+            kn = names.value.decode().split(",")
+            times = {n: kt[i] for i, n in enumerate(kn) if n}
+            dom = max(times, key=times.get)
+            per_ele = stage_algorithmic_bytes(case)
+            # the stage's compulsory bytes are shared by the fused kernels in proportion to what each touches
+            share = (C.c_double * 8)()
+            hfx.check(lib.hfx_fused_kernel_bytes(e, share))
+            bytes_launch = share[kn.index(dom)]
+            achieved = bytes_launch / (times[dom] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, kernel_ms=times[dom],
+                        kernels_ms=times, stage_algorithmic_bytes_per_element=per_ele,
+                        stage_hbm_frac=per_ele * case.n_eles / (ms_per_stage * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        else:
+            ms = (C.c_double * 11)()
+            hfx.check(lib.hfx_time_methods(e, faces, C.c_int(nb), C.c_int(10), ms))
+            mb = method_bytes(case)
+            times = {n: ms[i] for i, n in enumerate(METHOD_NAMES)}
+            if mode == "dense":
+                # dense FP64 MFMA contractions: price the heaviest contraction method against the MFMA roof
+                nu, nfp, nf, nd = case.n_upts, case.n_fpts, case.n_fields, case.n_dims
+                flops = {"extrapolate_solution": 2.0 * nfp * nu * nf, "calculate_gradient": 2.0 * nu * nu * nf * nd,
+                         "correct_gradient": 2.0 * (nu * nfp + nfp * nu) * nf * nd,
+                         "extrapolate_totalFlux": 2.0 * nfp * nu * nf * nd, "calculate_divergence": 2.0 * nu * nu * nf * nd,
+                         "calculate_corrected_divergence": 2.0 * nu * nfp * nf}
+                dom = max(flops, key=lambda k: times[k])
+                achieved = flops[dom] * case.n_eles / (times[dom] * 1e-3) / 1e12
+                roof = dict(bound="mfma", kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=achieved / FP64_PEAK_TFLOPS, traffic=None, kernel_ms=times[dom], methods_ms=times)
+            else:
+                dom = max(times, key=times.get)
+                achieved = mb[dom] * case.n_eles / (times[dom] * 1e-3) / 1e9
+                roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=achieved / HBM_PEAK_GBS, traffic=None, kernel_ms=times[dom], methods_ms=times)
+        if world == 1 and not args.no_cpu:
+            # the GPU box gives one job a 16-CPU share whatever os.cpu_count() says
+            threads = max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
+            cb = cpu_baseline(args.order, threads)
+            cpu = dict(value=cb["allcores"]["value"], unit="DOF-updates/s", cores=threads, kind="port",
+                       sample="oracle (C restatement of the reference CPU path, OpenMP over elements) on a %d^3 "
+                              "P%d TGV mesh, %d time steps; 1 core on %d^3: %.3g DOF-updates/s" %
+                              (cb["allcores"]["n_cells"], args.order, cb["allcores"]["steps"], cb["1core"]["n_cells"],
+                               cb["1core"]["value"]),
+                       value_1core=cb["1core"]["value"])
+
+    if rank == 0:
+        line = {
+            "metric": "DOF-updates/sec", "value": value, "unit": "DOF-updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_rk_stage": ms_per_stage, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Taylor-Green vortex, %d^3 hexa per GPU, P%d, Navier-Stokes, HLLC+LDG, RK45, "
+                                   "1 step = %d RK stages" % (args.n, args.order, n_stages),
+                       "n_eles_per_gpu": case.n_eles, "dof_per_gpu": dof_per_rank, "path": mode,
+                       "multi_gpu": "none" if world == 1 else "independent periodic blocks per rank (weak)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    case.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -789,4 +789,57 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, i
   return 0;
 }
 
+int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double ms[HFX_N_TIMED_METHODS])
+{
+  HFX_CHECK(e && ms && reps > 0, "hfx_time_methods: bad argument");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  hipStream_t st = e->ctx->stream;
+  const int adv = e->ctx->params.adv_type;
+  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
+  const int viscous = e->ctx->params.viscous;
+  hipEvent_t ev[HFX_N_TIMED_METHODS + 1];
+  for (auto &x : ev) HFX_HIP(hipEventCreate(&x));
+  for (int i = 0; i < HFX_N_TIMED_METHODS; i++) ms[i] = 0.0;
+  for (int r = 0; r < reps; r++)
+  {
+    int k = 0;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (hfx_eles_extrapolate_solution(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (viscous && hfx_eles_calculate_gradient(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (hfx_eles_evaluate_invFlux(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    for (int b = 0; b < nfb; b++)
+      if (hfx_int_inters_calculate_common_invFlux(faces[b])) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (viscous && hfx_eles_correct_gradient(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (viscous && hfx_eles_evaluate_viscFlux(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (hfx_eles_extrapolate_totalFlux(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (hfx_eles_calculate_divergence(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (viscous)
+      for (int b = 0; b < nfb; b++)
+        if (hfx_int_inters_calculate_common_viscFlux(faces[b])) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (hfx_eles_calculate_corrected_divergence(e)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    if (hfx_eles_AdvanceSolution(e, r % nst, adv)) return 1;
+    HFX_HIP(hipEventRecord(ev[k++], st));
+    HFX_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < HFX_N_TIMED_METHODS; i++)
+    {
+      float t = 0;
+      HFX_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      ms[i] += t;
+    }
+  }
+  for (int i = 0; i < HFX_N_TIMED_METHODS; i++) ms[i] /= reps;
+  for (auto &x : ev) (void)hipEventDestroy(x);
+  return 0;
+}
+
 } // extern "C"

@@ -1,0 +1,182 @@
+// capi.cpp -- small extern "C" facade over the host-side mirror so that the Python test and
+// bench plumbing (ctypes) can build a case, read its host arrays and drive it.  Declared in
+// include/hfx_host.h.
+#include "../../../include/hfx_host.h"
+
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "solver.hpp"
+
+struct hfxh_case
+{
+  solution S;
+  box_mesh mesh;
+  std::vector<hfx_inters *> faces;
+  std::string err;
+};
+
+static thread_local std::string g_err;
+extern "C" const char *hfxh_last_error(void) { return g_err.c_str(); }
+
+static eles *the_eles(hfxh_case *c) { return c->S.n_dims == 3 ? (eles *)&c->S.mesh_eles_hexas : (eles *)&c->S.mesh_eles_quads; }
+static int_inters *the_faces(hfxh_case *c) { return &c->S.mesh_int_inters(c->S.n_dims == 3 ? 2 : 0); }
+
+extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
+{
+  if (!d || !out) { g_err = "hfxh_case_create: NULL argument"; return 1; }
+  hfxh_case *c = new hfxh_case();
+  input &in = c->S.run_input;
+  in.equation = 0;
+  in.viscous = d->viscous; in.order = d->order;
+  in.riemann_solve_type = d->riemann_solve_type; in.vis_riemann_solve_type = 0;
+  in.ic_form = d->ic_form; in.adv_type = d->adv_type; in.dt_type = 0; in.dt = d->dt;
+  in.ldg_tau = d->ldg_tau; in.ldg_beta = d->ldg_beta;
+  in.upts_type_hexa = in.upts_type_quad = d->upts_type;
+  in.vcjh_scheme_hexa = in.vcjh_scheme_quad = d->vcjh_scheme;
+  in.eta_hexa = in.eta_quad = d->eta;
+  in.gamma = d->gamma; in.prandtl = d->prandtl; in.S_gas = d->S_gas; in.T_gas = d->T_gas; in.R_gas = d->R_gas;
+  in.mu_gas = d->mu_gas; in.fix_vis = d->fix_vis;
+  in.Mach_free_stream = d->Mach_free_stream; in.L_free_stream = d->L_free_stream;
+  in.T_free_stream = d->T_free_stream; in.rho_free_stream = d->rho_free_stream;
+  in.Mach_c_ic = d->Mach_c_ic; in.T_c_ic = d->T_c_ic; in.rho_c_ic = d->rho_c_ic;
+  in.u_c_ic = d->u_c_ic; in.v_c_ic = d->v_c_ic; in.w_c_ic = d->w_c_ic; in.p_c_ic = d->p_c_ic;
+  in.dx_cyclic = in.dy_cyclic = in.dz_cyclic = d->length;
+  if (d->loc_1d_upts)
+  {
+    in.loc_1d_upts_override.setup(d->order + 1);
+    for (int i = 0; i <= d->order; i++) in.loc_1d_upts_override(i) = d->loc_1d_upts[i];
+  }
+  if (in.setup_params(g_err)) { delete c; return 1; }
+
+  c->mesh.dims = d->dims;
+  for (int i = 0; i < 3; i++) c->mesh.n[i] = d->n[i];
+  c->mesh.length = d->length;
+  c->mesh.amp = d->amp;
+  if (d->xv)
+    c->mesh.xv.assign(d->xv, d->xv + (size_t)c->mesh.nv() * d->dims);
+  else
+    c->mesh.generate();
+  if (GeoPreprocess_box(&c->S, c->mesh)) { g_err = c->S.err; delete c; return 1; }
+  if (InitSolution(&c->S)) { g_err = c->S.err; delete c; return 1; }
+  *out = c;
+  return 0;
+}
+
+extern "C" int hfxh_case_destroy(hfxh_case *c)
+{
+  delete c;
+  return 0;
+}
+
+extern "C" int hfxh_case_sizes(hfxh_case *c, int sizes[8])
+{
+  eles *E = the_eles(c);
+  sizes[0] = E->n_eles; sizes[1] = E->n_upts_per_ele; sizes[2] = E->n_fpts_per_ele; sizes[3] = E->n_fields;
+  sizes[4] = E->n_dims; sizes[5] = E->order; sizes[6] = E->ele_type; sizes[7] = c->S.run_input.n_rk_stages();
+  return 0;
+}
+
+extern "C" int hfxh_case_params(hfxh_case *c, hfx_params *p)
+{
+  c->S.run_input.fill(*p);
+  return 0;
+}
+
+extern "C" int hfxh_case_get_array(hfxh_case *c, const char *name, const double **ptr, int dims[4])
+{
+  eles *E = the_eles(c);
+  std::string n(name);
+  hf_array<double> *a = nullptr;
+  if (n == "opp_0") a = &E->opp_0;
+  else if (n == "opp_3") a = &E->opp_3;
+  else if (n == "opp_6") a = &E->opp_6;
+  else if (n.rfind("opp_", 0) == 0 && n.size() == 7)
+  {
+    const int which = n[4] - '0', d = n[6] - '0';
+    if (d < 0 || d >= E->n_dims) { g_err = "bad operator dimension"; return 1; }
+    if (which == 1) a = &E->opp_1(d);
+    else if (which == 2) a = &E->opp_2(d);
+    else if (which == 4 && E->viscous) a = &E->opp_4(d);
+    else if (which == 5 && E->viscous) a = &E->opp_5(d);
+  }
+  else if (n == "detjac_upts") a = &E->detjac_upts;
+  else if (n == "JGinv_upts") a = &E->JGinv_upts;
+  else if (n == "detjac_fpts") a = &E->detjac_fpts;
+  else if (n == "JGinv_fpts") a = &E->JGinv_fpts;
+  else if (n == "tdA_fpts") a = &E->tdA_fpts;
+  else if (n == "norm_fpts") a = &E->norm_fpts;
+  else if (n == "pos_upts") a = &E->pos_upts;
+  else if (n == "pos_fpts") a = &E->pos_fpts;
+  else if (n == "shape") a = &E->shape;
+  else if (n == "loc_upts") a = &E->loc_upts;
+  else if (n == "tloc_fpts") a = &E->tloc_fpts;
+  else if (n == "tnorm_fpts") a = &E->tnorm_fpts;
+  else if (n == "loc_1d_upts") a = &E->loc_1d_upts;
+  else if (n == "disu_upts0") a = &E->disu_upts(0);
+  else if (n == "disu_upts1") a = &E->disu_upts(1);
+  else if (n == "div_tconf_upts") a = &E->div_tconf_upts(0);
+  else if (n == "grad_disu_upts") a = &E->grad_disu_upts;
+  else if (n == "h_ref") a = &E->h_ref;
+  if (!a) { g_err = "hfxh_case_get_array: unknown array " + n; return 1; }
+  *ptr = a->get_ptr_cpu();
+  for (int i = 0; i < 4; i++) dims[i] = a->get_dim(i);
+  return 0;
+}
+
+extern "C" int hfxh_case_get_faces(hfxh_case *c, const int **L, const int **R, int *n_fpts_per_inter, int *n_inters)
+{
+  int_inters *I = the_faces(c);
+  *L = I->disu_fpts_l.get_ptr_cpu();
+  *R = I->disu_fpts_r.get_ptr_cpu();
+  *n_fpts_per_inter = I->n_fpts_per_inter;
+  *n_inters = I->n_inters;
+  return 0;
+}
+
+extern "C" int hfxh_case_to_device(hfxh_case *c, int device)
+{
+  if (MoveToDevice(&c->S, device)) { g_err = c->S.err; return 1; }
+  c->faces.clear();
+  for (int i = 0; i < c->S.n_int_inter_types; i++)
+    if (c->S.mesh_int_inters(i).device()) c->faces.push_back(c->S.mesh_int_inters(i).device());
+  return 0;
+}
+
+extern "C" int hfxh_case_handles(hfxh_case *c, hfx_ctx **ctx, hfx_eles **e, hfx_inters ***faces, int *n_face_blocks)
+{
+  if (!c->S.ctx) { g_err = "case is not on the device"; return 1; }
+  *ctx = c->S.ctx;
+  *e = the_eles(c)->device();
+  *faces = c->faces.data();
+  *n_face_blocks = (int)c->faces.size();
+  return 0;
+}
+
+extern "C" int hfxh_case_CalcResidual(hfxh_case *c)
+{
+  CalcResidual(0, 0, &c->S);
+  eles *E = the_eles(c);
+  if (E->failed()) { g_err = E->last_error(); return 1; }
+  if (the_faces(c)->failed()) { g_err = the_faces(c)->last_error(); return 1; }
+  return 0;
+}
+
+extern "C" int hfxh_case_run(hfxh_case *c, int n_steps)
+{
+  if (RunSteps(&c->S, n_steps)) { g_err = c->S.err; return 1; }
+  return 0;
+}
+
+extern "C" int hfxh_case_sync_host(hfxh_case *c)
+{
+  eles *E = the_eles(c);
+  if (E->cp_disu_upts_gpu_cpu() || E->cp_div_tconf_upts_gpu_cpu() || E->cp_array_gpu_cpu(HFX_DISU_UPTS1, E->disu_upts(1)))
+  {
+    g_err = E->last_error();
+    return 1;
+  }
+  if (E->viscous && E->cp_grad_disu_upts_gpu_cpu()) { g_err = E->last_error(); return 1; }
+  return 0;
+}

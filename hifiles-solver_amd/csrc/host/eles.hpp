@@ -1,0 +1,122 @@
+// eles.hpp -- host-side mirror of the reference's element classes for the hot path.
+//
+// Same public method names, argument meaning and array layouts as
+// /root/reference/include/eles.h:55-125 (eles), eles_hexas.h, eles_quads.h, so that a
+// CalcResidual written against the reference's interface (src/solver.cpp:50-223) drives
+// this implementation unchanged.  The per-stage methods do no arithmetic on the host:
+// they call the C ABI of libhfx (include/hfx.h), which owns the device copy of every array.
+// The setup methods (operators, metrics, initial condition) are host code, as in the reference.
+#pragma once
+#include <string>
+
+#include "../../../include/hfx.h"
+#include "hf_array.hpp"
+#include "input.hpp"
+
+class eles
+{
+public:
+  eles();
+  virtual ~eles();
+
+  // ---- setup (reference: eles::setup src/eles.cpp:66-235) -------------------------
+  // returns 0 or non-zero with last_error() set (the reference calls FatalError)
+  int setup(int in_n_eles, int in_max_n_spts_per_ele, input *in_run_input);
+  void set_shape_node(int in_spt, int in_ele, const hf_array<double> &in_pos); // src/eles.cpp set_shape_node
+  int set_transforms();                                                          // src/eles.cpp:4015
+  int set_ics(double &time);                                                     // src/eles.cpp:237
+
+  // ---- device residency (replaces mv_all_cpu_gpu / cp_*_gpu_cpu, src/eles.cpp:930-1062)
+  int mv_all_cpu_gpu(hfx_ctx *ctx);
+  void free_device();
+  int cp_disu_upts_gpu_cpu();
+  int cp_disu_upts_cpu_gpu();
+  int cp_div_tconf_upts_gpu_cpu();
+  int cp_grad_disu_upts_gpu_cpu();
+  int cp_array_gpu_cpu(int hfx_id, hf_array<double> &dst);
+
+  // ---- the per-stage methods CalcResidual calls (src/solver.cpp:65-216) -------------
+  void extrapolate_solution();
+  void calculate_gradient();
+  void evaluate_invFlux();
+  void correct_gradient();
+  void evaluate_viscFlux();
+  void extrapolate_totalFlux();
+  void calculate_divergence();
+  void calculate_corrected_divergence();
+  void AdvanceSolution(int in_step, int adv_type);
+  double calc_dt_local(int in_ele); // host evaluation on the host copy of disu_upts(0), src/eles.cpp:1267
+  double compute_res_upts(int in_norm_type, int in_field);
+
+  // ---- getters used by face wiring (src/eles.cpp:4638-4949 return pointers; here: offsets)
+  int get_n_eles() const { return n_eles; }
+  int get_n_dims() const { return n_dims; }
+  int get_n_fields() const { return n_fields; }
+  int get_n_fpts_per_inter(int f) const { return n_fpts_per_inter(f); }
+  // offset `fpt + n_fpts*ele` of local flux point `in_fpt` of local face `in_inter` of element `in_ele`
+  int get_fpt_offset(int in_ele, int in_inter, int in_fpt) const;
+  hfx_eles *device() { return dev; }
+  const std::string &last_error() const { return err; }
+  bool failed() const { return !err.empty(); }
+
+  // ---- data (public here; protected in the reference: include/eles.h:470-935) --------
+  input *run_input = nullptr;
+  int n_eles = 0, n_dims = 0, n_fields = 0, order = 0, ele_type = -1, viscous = 0;
+  int n_upts_per_ele = 0, n_fpts_per_ele = 0, n_inters_per_ele = 0, upts_type = 0;
+  hf_array<int> n_fpts_per_inter, n_spts_per_ele;
+  hf_array<double> loc_1d_upts, loc_upts, tloc_fpts, tnorm_fpts;
+  hf_array<double> shape; // (n_dims, max_n_spts, n_eles)
+  hf_array<double> opp_0, opp_3, opp_6;
+  hf_array<hf_array<double>> opp_1, opp_2, opp_4, opp_5;
+  hf_array<double> detjac_upts, JGinv_upts, detjac_fpts, JGinv_fpts, tdA_fpts, norm_fpts, pos_upts, pos_fpts;
+  hf_array<hf_array<double>> disu_upts;      // host copies, valid after cp_*_gpu_cpu
+  hf_array<hf_array<double>> div_tconf_upts;
+  hf_array<double> grad_disu_upts;
+  hf_array<double> h_ref, dt_local;
+
+protected:
+  virtual int setup_ele_type_specific() = 0;
+  virtual double eval_nodal_basis(int in_index, const hf_array<double> &in_loc) = 0;
+  virtual double eval_d_nodal_basis(int in_index, int in_cpnt, const hf_array<double> &in_loc) = 0;
+  virtual void fill_opp_3(hf_array<double> &opp_3) = 0;
+  virtual double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) = 0;
+  virtual void eval_d_nodal_s_basis(hf_array<double> &d_nodal_s_basis, const hf_array<double> &in_loc, int in_n_spts) = 0;
+
+  void set_opp_0();
+  void set_opp_1();
+  void set_opp_2();
+  void set_opp_3();
+  void set_opp_4();
+  void set_opp_5();
+  void set_opp_6();
+  void calc_pos(const hf_array<double> &in_loc, int in_ele, hf_array<double> &out_pos);
+  void calc_d_pos(const hf_array<double> &in_loc, int in_ele, hf_array<double> &out_d_pos);
+  int set_transforms_pts(bool at_fpts);
+  void fail(const std::string &msg);
+
+  hfx_eles *dev = nullptr;
+  std::string err;
+  int max_n_spts_per_ele = 0;
+};
+
+class eles_hexas : public eles
+{
+protected:
+  int setup_ele_type_specific() override;
+  double eval_nodal_basis(int in_index, const hf_array<double> &in_loc) override;
+  double eval_d_nodal_basis(int in_index, int in_cpnt, const hf_array<double> &in_loc) override;
+  void fill_opp_3(hf_array<double> &opp_3) override;
+  double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
+  void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
+};
+
+class eles_quads : public eles
+{
+protected:
+  int setup_ele_type_specific() override;
+  double eval_nodal_basis(int in_index, const hf_array<double> &in_loc) override;
+  double eval_d_nodal_basis(int in_index, int in_cpnt, const hf_array<double> &in_loc) override;
+  void fill_opp_3(hf_array<double> &opp_3) override;
+  double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
+  void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
+};

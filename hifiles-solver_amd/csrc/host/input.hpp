@@ -1,0 +1,46 @@
+// input.hpp -- the frozen subset of the reference's run_input that the hot path and its
+// setup read (/root/reference/include/input.h; keys of src/input.cpp:62-327), plus the
+// non-dimensionalisation of input::setup_params (src/input.cpp:527-720).
+// Not a global: each `solution` owns one.
+#pragma once
+#include <string>
+
+#include "../../../include/hfx.h"
+#include "hf_array.hpp"
+
+struct input
+{
+  // ---- solver
+  int equation = 0, viscous = 1, order = 4;
+  int riemann_solve_type = 3, vis_riemann_solve_type = 0;
+  int ic_form = 7, adv_type = 3, dt_type = 0, n_steps = 1;
+  double dt = 0.0, CFL = 0.0;
+  double ldg_tau = 0.0, ldg_beta = 0.5;
+  // ---- element parameters
+  int upts_type_hexa = 0, vcjh_scheme_hexa = 1;
+  double eta_hexa = 0.0;
+  int upts_type_quad = 0, vcjh_scheme_quad = 1;
+  double eta_quad = 0.0;
+  // ---- gas
+  double gamma = 1.4, prandtl = 0.72, S_gas = 120.0, T_gas = 291.15, R_gas = 286.9, mu_gas = 1.827e-5;
+  int fix_vis = 1;
+  double Mach_free_stream = 1.0, L_free_stream = 1.0, T_free_stream = 300.0, rho_free_stream = 1.17723946;
+  // ---- initial condition (dimensional on input, like the reference)
+  double Mach_c_ic = 0.0, nx_c_ic = 1.0, ny_c_ic = 0.0, nz_c_ic = 0.0, T_c_ic = 0.0, rho_c_ic = 0.0;
+  double u_c_ic = 0.0, v_c_ic = 0.0, w_c_ic = 0.0, p_c_ic = 0.0; // inviscid inputs
+  // optional override of the 1-D solution points (order+1 values); empty: computed
+  hf_array<double> loc_1d_upts_override;
+  // ---- periodic box
+  double dx_cyclic = 0.0, dy_cyclic = 0.0, dz_cyclic = 0.0;
+
+  // ---- derived by setup_params()
+  double T_ref = 0, L_ref = 0, rho_ref = 0, uvw_ref = 0, p_ref = 0, mu_ref = 0, time_ref = 0, R_ref = 0;
+  double c_sth = 0, mu_inf = 0, rt_inf = 0, uvw_c_ic = 0, mu_c_ic = 0;
+  hf_array<double> RK_a, RK_b, RK_c;
+  double time = 0.0;
+
+  // returns 0 or sets err (the reference's FatalError texts)
+  int setup_params(std::string &err);
+  int n_rk_stages() const { return adv_type == 0 ? 1 : (adv_type <= 2 ? 4 : (adv_type == 3 ? 5 : 14)); }
+  void fill(hfx_params &p) const;
+};

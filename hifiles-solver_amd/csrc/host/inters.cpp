@@ -1,0 +1,108 @@
+#include "inters.hpp"
+
+#include "solver.hpp"
+
+int_inters::~int_inters()
+{
+  if (dev) hfx_inters_destroy(dev);
+}
+
+void int_inters::setup(int in_n_inters, int in_inter_type, input *in)
+{
+  n_inters = in_n_inters;
+  inters_type = in_inter_type;
+  order = in->order;
+  viscous = in->viscous;
+  if (inters_type == 0)
+  {
+    n_fpts_per_inter = order + 1;
+    n_dims = 2;
+  }
+  else if (inters_type == 1)
+  {
+    n_fpts_per_inter = (order + 2) * (order + 1) / 2;
+    n_dims = 3;
+  }
+  else
+  {
+    n_fpts_per_inter = (order + 1) * (order + 1);
+    n_dims = 3;
+  }
+  n_fields = n_dims + 2;
+  disu_fpts_l.setup(n_fpts_per_inter, n_inters);
+  disu_fpts_r.setup(n_fpts_per_inter, n_inters);
+  lut.setup(n_fpts_per_inter);
+}
+
+void int_inters::get_lut(int rot)
+{
+  const int N = order + 1;
+  if (inters_type == 0)
+  {
+    for (int i = 0; i < n_fpts_per_inter; i++) lut(i) = n_fpts_per_inter - i - 1;
+  }
+  else if (inters_type == 2)
+  {
+    // i = slow, j = fast index of the left face's (k,j) frame
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++)
+      {
+        int v;
+        if (rot == 0) v = (N - 1 - j) + N * i;
+        else if (rot == 1) v = n_fpts_per_inter - (N - 1 - j) - N * i - 1;
+        else if (rot == 2) v = N * j + i;
+        else v = n_fpts_per_inter - N * j - i - 1;
+        lut(i * N + j) = v;
+      }
+  }
+  else
+  {
+    if (err.empty()) err = "ERROR: Invalid interface type ... (triangular faces are not built yet)";
+  }
+}
+
+void int_inters::set_interior(int in_inter, int in_ele_type_l, int in_ele_type_r, int in_ele_l, int in_ele_r,
+                              int in_local_inter_l, int in_local_inter_r, int rot_tag, struct solution *FlowSol)
+{
+  if (ele_type_l < 0)
+  {
+    ele_type_l = in_ele_type_l;
+    ele_type_r = in_ele_type_r;
+  }
+  if (ele_type_l != in_ele_type_l || ele_type_r != in_ele_type_r)
+  {
+    if (err.empty()) err = "int_inters: one face block must connect one pair of element classes";
+    return;
+  }
+  get_lut(rot_tag);
+  eles *el = FlowSol->mesh_eles(in_ele_type_l), *er = FlowSol->mesh_eles(in_ele_type_r);
+  for (int j = 0; j < n_fpts_per_inter; j++)
+  {
+    const int j_rhs = lut(j);
+    disu_fpts_l(j, in_inter) = el->get_fpt_offset(in_ele_l, in_local_inter_l, j);
+    disu_fpts_r(j, in_inter) = er->get_fpt_offset(in_ele_r, in_local_inter_r, j_rhs);
+  }
+}
+
+int int_inters::mv_all_cpu_gpu(hfx_ctx *ctx, struct solution *FlowSol)
+{
+  if (n_inters == 0) return 0;
+  eles *el = FlowSol->mesh_eles(ele_type_l), *er = FlowSol->mesh_eles(ele_type_r);
+  if (hfx_int_inters_create(ctx, el->device(), er->device(), n_inters, n_fpts_per_inter, disu_fpts_l.get_ptr_cpu(),
+                            disu_fpts_r.get_ptr_cpu(), &dev))
+  {
+    err = hfx_last_error();
+    return 1;
+  }
+  return 0;
+}
+
+void int_inters::calculate_common_invFlux()
+{
+  if (n_inters != 0 && hfx_int_inters_calculate_common_invFlux(dev) && err.empty()) err = hfx_last_error();
+}
+
+void int_inters::calculate_common_viscFlux()
+{
+  if (n_inters != 0 && hfx_int_inters_calculate_common_viscFlux(dev) && err.empty()) err = hfx_last_error();
+}

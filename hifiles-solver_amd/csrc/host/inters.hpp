@@ -1,0 +1,44 @@
+// inters.hpp -- host-side mirror of the reference's interior-face class.
+//
+// /root/reference/include/inters.h:40-126 + int_inters.h:40-75: the reference keeps
+// hf_array<double*> tables of host pointers into the element arrays; a device library
+// cannot take host pointers, so the same tables are kept as OFFSETS `fpt + n_fpts*ele`
+// into the (fpt,ele) plane of the owning element block -- the registration form of
+// hfx_int_inters_create (include/hfx.h).
+#pragma once
+#include <string>
+
+#include "eles.hpp"
+
+struct solution;
+
+class int_inters
+{
+public:
+  ~int_inters();
+  // inters::setup_inters + int_inters::setup (src/inters.cpp:60-150, src/int_inters.cpp:48-65)
+  // in_inter_type: 0 segment, 1 triangle, 2 quadrilateral
+  void setup(int in_n_inters, int in_inter_type, input *in_run_input);
+  // int_inters::set_interior (src/int_inters.cpp:67-121): same arguments
+  void set_interior(int in_inter, int in_ele_type_l, int in_ele_type_r, int in_ele_l, int in_ele_r, int in_local_inter_l,
+                    int in_local_inter_r, int rot_tag, struct solution *FlowSol);
+  // look-up table of the flux-point permutation for a rotation tag (src/inters.cpp:153-262)
+  void get_lut(int in_rot_tag);
+  int mv_all_cpu_gpu(hfx_ctx *ctx, struct solution *FlowSol);
+  void calculate_common_invFlux();  // src/int_inters.cpp:160
+  void calculate_common_viscFlux(); // src/int_inters.cpp:254
+
+  int get_n_inters() const { return n_inters; }
+  hfx_inters *device() { return dev; }
+  const std::string &last_error() const { return err; }
+  bool failed() const { return !err.empty(); }
+
+  int inters_type = 0, order = 0, viscous = 0, n_inters = 0, n_fpts_per_inter = 0, n_fields = 0, n_dims = 0;
+  int ele_type_l = -1, ele_type_r = -1; // one face block connects one pair of element classes
+  hf_array<int> disu_fpts_l, disu_fpts_r; // (n_fpts_per_inter, n_inters) offsets; the other tables share them
+  hf_array<int> lut;
+
+private:
+  hfx_inters *dev = nullptr;
+  std::string err;
+};

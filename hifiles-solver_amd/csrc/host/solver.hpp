@@ -1,0 +1,53 @@
+// solver.hpp -- `struct solution`, the stage scheduler CalcResidual and the box-mesh setup.
+//
+// struct solution mirrors /root/reference/include/solution.h:44-96; CalcResidual has the
+// call order of /root/reference/src/solver.cpp:50-223 (single rank, LES / RANS / forcing off)
+// and calls only the public eles / int_inters methods, like the reference's.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "eles.hpp"
+#include "inters.hpp"
+
+struct solution
+{
+  int rank = 0, nproc = 1;
+  double time = 0.0;
+  int n_ele_types = 5; // 0 tri, 1 quad, 2 tet, 3 pri, 4 hex (src/geometry.cpp:135)
+  int n_dims = 0;
+  int num_cells_global = 0, ini_iter = 0;
+  hf_array<eles *> mesh_eles; // entries of classes this build does not carry are NULL
+  eles_quads mesh_eles_quads;
+  eles_hexas mesh_eles_hexas;
+  int n_int_inter_types = 3;
+  hf_array<int_inters> mesh_int_inters;
+  input run_input;
+  hfx_ctx *ctx = nullptr;
+  std::string err;
+  ~solution();
+};
+
+// periodic box [0,length]^dims of n[0] x n[1] (x n[2]) quads / hexes, optional smooth periodic
+// deformation (same formula as oracle/gen_neu_mesh.py) or caller-supplied vertices
+// xv[v + nv*d], v = ix + (nx+1)*(iy + (ny+1)*iz).
+struct box_mesh
+{
+  int dims = 3, n[3] = {1, 1, 1};
+  double length = 0.0, amp = 0.0;
+  std::vector<double> xv; // (nv, dims) column-major
+  int nv() const { return (n[0] + 1) * (n[1] + 1) * (dims == 3 ? n[2] + 1 : 1); }
+  int ne() const { return n[0] * n[1] * (dims == 3 ? n[2] : 1); }
+  void generate();
+};
+
+// the part of GeoPreprocess + InitSolution the hot path needs (src/geometry.cpp:106-915,
+// src/solver.cpp:321): elements, shapes, transforms, interior (periodic) faces, initial state
+int GeoPreprocess_box(solution *FlowSol, const box_mesh &mesh);
+int InitSolution(solution *FlowSol);
+// move everything to the device (the reference's mv_all_cpu_gpu calls, src/geometry.cpp:310-320,552-557)
+int MoveToDevice(solution *FlowSol, int device);
+
+void CalcResidual(int in_file_num, int in_rk_stage, solution *FlowSol);
+// RK loop of src/HiFiLES.cpp:194-221 through the mirrored class methods
+int RunSteps(solution *FlowSol, int n_steps);

@@ -1,0 +1,164 @@
+"""ctypes binding of libhfx_host.so (include/hfx_host.h): the host-side mirror of the reference's
+eles / int_inters / solver interface.  Setup is host code; every per-stage call ends in libhfx."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import hfx
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhfx_host.so")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+class CaseDesc(C.Structure):
+    _fields_ = [("dims", C.c_int), ("n", C.c_int * 3), ("order", C.c_int), ("length", C.c_double), ("amp", C.c_double),
+                ("xv", dp), ("loc_1d_upts", dp),
+                ("viscous", C.c_int), ("riemann_solve_type", C.c_int), ("adv_type", C.c_int), ("ic_form", C.c_int),
+                ("upts_type", C.c_int), ("vcjh_scheme", C.c_int), ("eta", C.c_double), ("fix_vis", C.c_int),
+                ("dt", C.c_double), ("ldg_beta", C.c_double), ("ldg_tau", C.c_double)] + \
+               [(k, C.c_double) for k in ("gamma", "prandtl", "S_gas", "T_gas", "R_gas", "mu_gas",
+                                          "Mach_free_stream", "rho_free_stream", "L_free_stream", "T_free_stream",
+                                          "rho_c_ic", "Mach_c_ic", "T_c_ic", "u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic")]
+
+
+# the shipped Taylor-Green case (/root/reference/testcases/navier-stokes/Taylor_Green_vortex/input_TGV_SD_hex)
+TGV = dict(dims=3, order=4, length=6.2831853071795862, amp=0.0, viscous=1, riemann_solve_type=3, adv_type=3, ic_form=7,
+           upts_type=0, vcjh_scheme=1, eta=0.0, fix_vis=1, dt=0.00001440389, ldg_beta=0.5, ldg_tau=0.0,
+           gamma=1.4, prandtl=0.72, S_gas=120.0, T_gas=291.15, R_gas=286.9, mu_gas=1.827e-05,
+           Mach_free_stream=0.1, rho_free_stream=0.0008421095852102401, L_free_stream=1.0, T_free_stream=300.0,
+           rho_c_ic=0.0008421095852102401, Mach_c_ic=0.1, T_c_ic=300.0)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        hfx.lib()  # dependency, loaded first so that the rpath-less case also resolves
+        if not os.path.exists(LIB_PATH):
+            raise hfx.HfxError("libhfx_host.so is not built")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.hfxh_last_error.restype = C.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise hfx.HfxError(lib().hfxh_last_error().decode())
+
+
+class Case:
+    def __init__(self, n, xv=None, loc_1d_upts=None, **kw):
+        d = CaseDesc()
+        cfg = dict(TGV)
+        cfg.update(kw)
+        for k, v in cfg.items():
+            setattr(d, k, v)
+        if isinstance(n, int):
+            n = [n] * 3
+        for i in range(3):
+            d.n[i] = n[i] if i < len(n) else 1
+        self._xv = None
+        if xv is not None:
+            self._xv = np.asfortranarray(np.array(xv, dtype=np.float64))
+            d.xv = self._xv.ctypes.data_as(dp)
+        self._x1 = None
+        if loc_1d_upts is not None:
+            self._x1 = np.ascontiguousarray(np.array(loc_1d_upts, dtype=np.float64))
+            d.loc_1d_upts = self._x1.ctypes.data_as(dp)
+        self.h = C.c_void_p()
+        check(lib().hfxh_case_create(C.byref(d), C.byref(self.h)))
+        sz = (C.c_int * 8)()
+        check(lib().hfxh_case_sizes(self.h, sz))
+        self.sizes = list(sz)
+        self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims, self.order, self.ele_type, self.n_stages = self.sizes
+        self.on_device = False
+
+    def array(self, name):
+        """Copy of a host array, Fortran-ordered with the reference's dims (trailing 1s dropped)."""
+        p = dp()
+        dims = (C.c_int * 4)()
+        check(lib().hfxh_case_get_array(self.h, name.encode(), C.byref(p), dims))
+        dims = list(dims)
+        while len(dims) > 1 and dims[-1] == 1:
+            dims.pop()
+        n = int(np.prod(dims))
+        a = np.ctypeslib.as_array(p, shape=(n,)).copy()
+        return a.reshape(dims, order="F")
+
+    def faces(self):
+        L, R = ip(), ip()
+        nf, ni = C.c_int(), C.c_int()
+        check(lib().hfxh_case_get_faces(self.h, C.byref(L), C.byref(R), C.byref(nf), C.byref(ni)))
+        n = nf.value * ni.value
+        l = np.ctypeslib.as_array(L, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
+        r = np.ctypeslib.as_array(R, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
+        return l, r
+
+    def params(self):
+        p = hfx.Params()
+        check(lib().hfxh_case_params(self.h, C.byref(p)))
+        return p
+
+    def registration(self):
+        """dict with the fixture key names (operators, metrics, faces, params) for the oracle / raw C ABI."""
+        d = {"sizes": np.array(self.sizes, dtype=np.int32)}
+        names = ["opp_0", "opp_3", "detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts"]
+        p = self.params()
+        if p.viscous:
+            names.append("opp_6")
+        for i in range(self.n_dims):
+            names += ["opp_1_%d" % i, "opp_2_%d" % i] + (["opp_4_%d" % i, "opp_5_%d" % i] if p.viscous else [])
+        for k in names:
+            d[k] = self.array(k)
+        L, R = self.faces()
+        t = 2 if self.n_dims == 3 else 0
+        d["int%d_L" % t], d["int%d_R" % t] = L, R
+        for k in ("gamma", "prandtl", "rt_inf", "mu_inf", "c_sth", "fix_vis", "ldg_beta", "ldg_tau", "dt",
+                  "viscous", "riemann_solve_type", "vis_riemann_solve_type", "adv_type", "dt_type"):
+            d[k] = np.array([getattr(p, k)], dtype=np.float64)
+        d["RK_a"] = np.array(list(p.RK_a)[:p.n_rk])
+        d["RK_b"] = np.array(list(p.RK_b)[:p.n_rk])
+        d["u_init"] = self.array("disu_upts0")
+        return d
+
+    def to_device(self, device=0):
+        check(lib().hfxh_case_to_device(self.h, C.c_int(device)))
+        self.on_device = True
+
+    def handles(self):
+        ctx, e, f = C.c_void_p(), C.c_void_p(), C.POINTER(C.c_void_p)()
+        nb = C.c_int()
+        check(lib().hfxh_case_handles(self.h, C.byref(ctx), C.byref(e), C.byref(f), C.byref(nb)))
+        return ctx, e, f, nb.value
+
+    def CalcResidual(self):
+        check(lib().hfxh_case_CalcResidual(self.h))
+
+    def run(self, n_steps):
+        check(lib().hfxh_case_run(self.h, C.c_int(n_steps)))
+
+    def run_steps_lib(self, n_steps, fused=False):
+        """hfx_run_steps on this case's device blocks (the whole RK loop inside libhfx)."""
+        ctx, e, f, nb = self.handles()
+        hfx.check(hfx.lib().hfx_run_steps(e, f, C.c_int(nb), C.c_int(n_steps), C.c_int(1 if fused else 0)))
+
+    def synchronize(self):
+        ctx, e, f, nb = self.handles()
+        hfx.check(hfx.lib().hfx_ctx_synchronize(ctx))
+
+    def stream(self):
+        ctx, e, f, nb = self.handles()
+        return hfx.lib().hfx_ctx_stream(ctx)
+
+    def sync_host(self):
+        check(lib().hfxh_case_sync_host(self.h))
+
+    def close(self):
+        if self.h:
+            lib().hfxh_case_destroy(self.h)
+            self.h = C.c_void_p()

@@ -153,6 +153,16 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
  * fused per-stage kernels (same results to rounding), 0 the per-method path. */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
 
+/* ---- measurement ------------------------------------------------------- */
+/* Average duration (ms, HIP events on the context's stream) of every per-method entry
+ * point over `reps` repetitions of one RK stage, in CalcResidual order:
+ *  0 extrapolate_solution  1 calculate_gradient  2 evaluate_invFlux  3 common_invFlux (all face blocks)
+ *  4 correct_gradient      5 evaluate_viscFlux   6 extrapolate_totalFlux  7 calculate_divergence
+ *  8 common_viscFlux       9 calculate_corrected_divergence  10 AdvanceSolution
+ * The state advances by reps stages (stage index cycles through the scheme). */
+#define HFX_N_TIMED_METHODS 11
+int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int reps, double ms[HFX_N_TIMED_METHODS]);
+
 #ifdef __cplusplus
 }
 #endif

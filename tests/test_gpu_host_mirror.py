@@ -1,0 +1,153 @@
+"""The whole chain -- host-side mirror (setup in C++, mirrored CalcResidual / RK loop) driving
+libhfx -- against the genuine reference's fixtures, against the oracle at a mid size, and through
+size-independent properties at BASELINE.json's full size (32^3 hexa, P4).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hfx
+import hfx_host as H
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def fixture_case(name, ref_nodes=False):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    k = json.loads(bytes(d["meta_json"]).decode())
+    kk = k["keys"]
+    x1 = d["loc_upts"][0, :kk["order"] + 1] if ref_nodes else None
+    c = H.Case(k["n"], xv=d["xv"], loc_1d_upts=x1, order=kk["order"], adv_type=kk["adv_type"],
+               riemann_solve_type=kk["riemann_solve_type"], upts_type=kk["upts_type_hexa"],
+               vcjh_scheme=kk["vcjh_scheme_hexa"], fix_vis=kk["fix_vis"], T_c_ic=kk["T_c_ic"])
+    return c, d
+
+
+@pytest.mark.parametrize("name,ref_nodes", [("hex_p4_n3_deformed", False), ("hex_p2_lobatto", False), ("hex_p2_sd", False),
+                                            ("hex_p2_n3_uniform", True)])
+def test_mirrored_rk_loop_vs_reference(name, ref_nodes):
+    """On the axis-aligned mesh the face normals carry ~4e-17 rounding noise in the components that are
+    geometrically zero, and the reference's LDG switch (exact sign tests on the left normal,
+    src/inters.cpp:568-581) is decided by that noise; it is only reproducible with bit-identical metrics,
+    i.e. with the reference's own (not bit-symmetric) quadrature-table abscissae -- passed in here.
+    With the computed, symmetric nodes the result differs by ~6e-9 (a different but equally valid
+    one-sided LDG choice on those faces); test_uniform_mesh_vs_oracle covers that configuration."""
+    c, d = fixture_case(name, ref_nodes)
+    c.to_device(0)
+    c.run(1)  # mirrored classes: CalcResidual + AdvanceSolution per stage
+    c.sync_host()
+    last = int(d["sizes"][7]) - 1
+    assert rel(c.array("disu_upts0"), d["u_step0_stage%d" % last]) < 1e-11
+    c.close()
+
+
+def test_uniform_mesh_vs_oracle(oracle):
+    """Computed nodes on the axis-aligned fixture mesh: GPU and oracle see the same registration data."""
+    c, d = fixture_case("hex_p2_n3_uniform")
+    reg = c.registration()
+    c.to_device(0)
+    c.run(2)
+    c.sync_host()
+    oc = O.Case(reg)
+    e = oc.c_eles()
+    f, nb = oc.c_faces()
+    for _ in range(2):
+        assert oracle.orc_rk_step(C.byref(e), f, nb, C.byref(oc.params)) == -1
+    assert rel(c.array("disu_upts0"), oc.arr["u0"]) < 1e-11
+    # and the reference itself is within the switch-noise distance
+    assert rel(c.array("disu_upts0"), d["u_step1_stage4"]) < 1e-7
+    c.close()
+
+
+def test_mirrored_residual_vs_reference():
+    c, d = fixture_case("hex_p4_n3_deformed")
+    c.to_device(0)
+    c.CalcResidual()
+    c.sync_host()
+    assert rel(c.array("div_tconf_upts"), d["s0_div_tconf_upts"]) < 5e-11
+    c.close()
+
+
+def test_mid_size_vs_oracle(oracle):
+    c = H.Case(6, order=4, amp=0.1)
+    reg = c.registration()
+    c.to_device(0)
+    c.run_steps_lib(1)
+    c.sync_host()
+    oc = O.Case(reg)
+    e = oc.c_eles()
+    f, nb = oc.c_faces()
+    oracle.orc_set_threads(8)
+    assert oracle.orc_rk_step(C.byref(e), f, nb, C.byref(oc.params)) == -1
+    oracle.orc_set_threads(1)
+    assert rel(c.array("disu_upts0"), oc.arr["u0"]) < 1e-11
+    c.close()
+
+
+def gauss_weights(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return w
+
+
+def integrals(c, u):
+    """sum over elements of the Gauss quadrature of each conserved field: int u dV."""
+    N = c.order + 1
+    w1 = gauss_weights(N)
+    w = (w1[:, None, None] * w1[None, :, None] * w1[None, None, :]).ravel()  # upt = k + N j + N^2 i
+    dj = c.array("detjac_upts")
+    return np.einsum("p,pe,pef->f", w, dj, u)
+
+
+@pytest.mark.parametrize("fused", [False])
+def test_full_size_conservation_and_symmetry(fused):
+    """BASELINE.json configs[1]: TGV 32^3 hexa P4.  Flux reconstruction is conservative: on a periodic
+    box the integral of every conserved variable is constant in time (up to rounding); and the common
+    flux seen from the two sides of a face cancels exactly, so this exercises every face table entry."""
+    c = H.Case(32, order=4)
+    u0 = c.array("disu_upts0")
+    i0 = integrals(c, u0)
+    c.to_device(0)
+    c.run_steps_lib(2, fused=fused)
+    c.sync_host()
+    u = c.array("disu_upts0")
+    assert np.isfinite(u).all()
+    i1 = integrals(c, u)
+    vol = (2 * np.pi) ** 3
+    # mass, momentum, energy: drift relative to (volume * typical magnitude of the field)
+    scale = np.array([1.0, 1.0, 1.0, 1.0, u0[:, :, 4].max()]) * vol
+    assert np.all(np.abs(i1 - i0) / scale < 1e-12), (i1 - i0) / scale
+    # the state did move
+    assert rel(u, u0) > 1e-6
+    # z-momentum of the TGV stays antisymmetric about the mid-plane: its integral stays ~0
+    assert abs(i1[3]) / vol < 1e-12
+    c.close()
+
+
+def test_full_size_residual_norms_vs_reference_stdout():
+    """BASELINE.json configs[1] at FULL size against the genuine reference's own output: BASELINE.md
+    section 2 records the iteration-1 row the reference printed for the generated periodic 32^3 P4 TGV
+    case (L1 residual per field, 8 digits): 0.00070019 0.05031596 0.05031596 0.06433493 0.11799063.
+    The monitor (src/output.cpp:2166-2248) evaluates sum|div_tconf/detjac| / n_upts on the divergence
+    left by the LAST stage of the step, so: one full time step, then the norms."""
+    c = H.Case(32, order=4)
+    c.to_device(0)
+    c.run_steps_lib(1)
+    ctx, e, f, nb = c.handles()
+    v = C.c_double()
+    r = []
+    for fld in range(5):
+        hfx.check(hfx.lib().hfx_eles_compute_res_upts(e, 1, fld, C.byref(v)))
+        r.append(v.value / (c.n_eles * c.n_upts))
+    c.close()
+    want = np.array([0.00070019, 0.05031596, 0.05031596, 0.06433493, 0.11799063])
+    assert np.all(np.abs(np.array(r) - want) < 6e-9), r

@@ -1,0 +1,102 @@
+"""The host-side mirror's setup (operators, metrics, faces, TGV state) against the genuine
+reference's fixtures.  CPU only: nothing here touches the GPU.
+
+The 1-D nodes are computed (Newton) instead of read from the reference's data/*.bin, so the
+operators agree to a few ulps of their scale rather than bitwise; the reference's structural
+zeros, which the sparse contraction path relies on, must be exact zeros here too.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hfx_host as H
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["hex_p2_n3_deformed", "hex_p2_n3_uniform", "hex_p4_n3_deformed", "hex_p3_n3_deformed", "hex_p2_sd",
+         "hex_p2_lobatto", "hex_p1_sutherland"]
+
+
+def case_from_fixture(d):
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    k = meta["keys"]
+    kw = dict(order=k["order"], viscous=k["viscous"], riemann_solve_type=k["riemann_solve_type"], adv_type=k["adv_type"],
+              upts_type=k["upts_type_hexa"], vcjh_scheme=k["vcjh_scheme_hexa"], fix_vis=k["fix_vis"], dt=k["dt"],
+              ldg_beta=k.get("ldg_beta", 0.5), ldg_tau=k.get("ldg_tau", 0.0), T_c_ic=k["T_c_ic"])
+    return H.Case(meta["n"], xv=d["xv"], **kw), meta
+
+
+def rel(a, b):
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_setup_matches_reference(name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c, meta = case_from_fixture(d)
+    assert c.sizes[:7] == [int(v) for v in d["sizes"][:7]]
+    ops = ["opp_0", "opp_3", "opp_6"] + ["opp_%d_%d" % (w, i) for w in (1, 2, 4, 5) for i in range(3)]
+    for k in ops:
+        got, want = c.array(k), d[k]
+        assert rel(got, want) < 5e-14, k
+        # every structural zero of the reference is an exact zero here; the reference's table nodes
+        # are not bit-symmetric (P2 mid node -4.5e-17), which leaves it a few ~1e-16 entries where the
+        # symmetric nodes computed here give exact zeros
+        assert np.all(got[want == 0.0] == 0.0), "zero pattern of %s" % k
+        assert np.all(np.abs(want[got == 0.0]) < 1e-15), "zero pattern of %s" % k
+    for k in ("loc_upts", "tloc_fpts", "tnorm_fpts", "shape"):
+        assert rel(c.array(k), d[k]) < 1e-15, k
+    for k in ("detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts"):
+        assert rel(c.array(k), d[k]) < 1e-14, k
+    # exact zeros of the unit normals decide the LDG switch (inters.cpp:568-581)
+    assert np.array_equal(c.array("norm_fpts") == 0.0, d["norm_fpts"] == 0.0)
+    assert rel(c.array("disu_upts0"), d["u_init"]) < 1e-14
+    p = c.params()
+    for k in ("gamma", "prandtl", "rt_inf", "mu_inf", "c_sth", "fix_vis", "dt", "ldg_beta", "ldg_tau"):
+        assert abs(getattr(p, k) - float(d[k][0])) <= 1e-15 * max(1.0, abs(float(d[k][0]))), k
+    assert np.allclose(list(p.RK_a)[:p.n_rk], np.ravel(d["RK_a"]), rtol=0, atol=0)
+    assert np.allclose(list(p.RK_b)[:p.n_rk], np.ravel(d["RK_b"]), rtol=0, atol=0)
+    # face tables: identical, including face order and left/right orientation (the LDG switch reads
+    # the LEFT normal only, so the orientation is part of the contract)
+    L, R = c.faces()
+    assert np.array_equal(L, d["int2_L"])
+    assert np.array_equal(R, d["int2_R"])
+    c.close()
+
+
+def test_rk414_tableau():
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p1_rk414.npz")))
+    c = H.Case(3, order=1, adv_type=4, amp=0.1)
+    p = c.params()
+    assert p.n_rk == 14
+    assert np.array_equal(np.array(list(p.RK_a)[:14]), np.ravel(d["RK_a"]))
+    assert np.array_equal(np.array(list(p.RK_b)[:14]), np.ravel(d["RK_b"]))
+    c.close()
+
+
+def test_generated_vertices_match_mesh_writer():
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p2_n3_deformed.npz")))
+    c = H.Case(3, order=2, amp=0.15)
+    assert rel(c.array("shape"), d["shape"]) < 1e-15
+    c.close()
+
+
+def test_quad_case_builds():
+    c = H.Case([4, 4, 1], dims=2, order=3, amp=0.1)
+    assert c.sizes[:7] == [16, 16, 16, 4, 2, 3, 1]
+    L, R = c.faces()
+    assert L.shape == (4, 32)
+    assert len(set(L.ravel()) | set(R.ravel())) == 16 * 16  # every flux point on exactly one face side
+    assert (c.array("opp_0") != 0).sum(1).max() == 4
+    c.close()
+
+
+def test_error_convention_host():
+    import hfx
+    with pytest.raises(hfx.HfxError):
+        H.Case(2, order=2)  # fewer than 3 cells per direction
+    with pytest.raises(hfx.HfxError):
+        H.Case(3, order=2, riemann_solve_type=1)  # Lax-Friedrich with NS (input.cpp:546)
