@@ -9,4 +9,8 @@ void fused_invalidate(hfx_eles *e);
 void fused_destroy(hfx_eles *e);
 // n_steps time steps with the fused kernels; fails loudly when the block does not qualify
 int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps);
+// average duration (ms, HIP events on the context stream) of each fused kernel over `reps` stages
+int fused_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len);
+// algorithmic HBM bytes per launch of each fused kernel, same order as fused_time_kernels
+void fused_kernel_bytes(const hfx_eles *e, double *bytes);
 } // namespace hfx

@@ -842,4 +842,18 @@ int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, d
   return 0;
 }
 
+int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double ms[8], char names[256])
+{
+  HFX_CHECK(e && ms && names && reps > 0, "hfx_time_fused_kernels: bad argument");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  return fused_time_kernels(e, faces, nfb, reps, ms, names, 256);
+}
+
+int hfx_fused_kernel_bytes(hfx_eles *e, double bytes[8])
+{
+  HFX_CHECK(e && bytes, "hfx_fused_kernel_bytes: bad argument");
+  fused_kernel_bytes(e, bytes);
+  return 0;
+}
+
 } // extern "C"

@@ -14,6 +14,7 @@ namespace hfx
 {
 
 void set_error(const char *fmt, ...);
+struct FusedData;
 
 #define HFX_HIP(call)                                                                          \
   do                                                                                           \
@@ -55,6 +56,7 @@ struct Operator
 
 } // namespace hfx
 
+struct hfx_inters;
 struct hfx_ctx
 {
   int device = 0;
@@ -97,8 +99,8 @@ struct hfx_eles
   double *red_buf = nullptr;              // device partial sums for reductions
   int red_blocks = 0;
   // fused-path private data (built lazily)
-  struct FusedData *fused = nullptr;
-  std::vector<struct hfx_inters *> faces_attached;
+  hfx::FusedData *fused = nullptr;
+  std::vector<hfx_inters *> faces_attached;
 };
 
 struct hfx_inters

@@ -162,6 +162,11 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int 
  * The state advances by reps stages (stage index cycles through the scheme). */
 #define HFX_N_TIMED_METHODS 11
 int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int reps, double ms[HFX_N_TIMED_METHODS]);
+/* The same for the kernels of the fused path: ms[8] (unused entries 0), names = comma-separated
+ * kernel names (buffer of 256 chars); the state advances by reps stages. */
+int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int reps, double ms[8], char names[256]);
+/* ALGORITHMIC HBM bytes per launch of each fused kernel (same order), see DESIGN.md */
+int hfx_fused_kernel_bytes(hfx_eles *e, double bytes[8]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,135 @@
+"""The fused per-stage path (hfx_run_steps(..., fused=1)) against the genuine reference's fixtures,
+against the per-method path, and through the full-size properties."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import hfx
+import hfx_host as H
+from test_gpu_methods_vs_golden import build, relerr, ALL, GOLDEN
+from test_gpu_host_mirror import integrals
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hfx.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_fused_vs_reference(ctx, name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e, faces = build(ctx, d)
+    nstage = int(d["sizes"][7])
+    steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
+    for st in steps:
+        hfx.run_steps(e, faces, 1, fused=True)
+        assert relerr(e.download(hfx.DISU_UPTS0), d["u_step%d_stage%d" % (st, nstage - 1)]) < 1e-11, st
+    assert e.check_nan() == -1
+    for f in faces:
+        f.close()
+    e.close()
+
+
+def test_fused_public_arrays_after_a_step(ctx):
+    """What the fused path leaves in the public arrays: state, RK register, flux-point solution of the
+    NEW state, corrected gradients and the divergence of the step's last stage (for the monitors)."""
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p3_n3_deformed.npz")))
+    ef, ff = build(ctx, d)
+    em, fm = build(ctx, d)
+    hfx.run_steps(ef, ff, 1, fused=True)
+    hfx.run_steps(em, fm, 1, fused=False)
+    assert relerr(ef.download(hfx.DISU_UPTS0), em.download(hfx.DISU_UPTS0)) < 1e-12
+    assert relerr(ef.download(hfx.DISU_UPTS1), em.download(hfx.DISU_UPTS1)) < 1e-9
+    assert relerr(ef.download(hfx.DIV_TCONF_UPTS), em.download(hfx.DIV_TCONF_UPTS)) < 5e-11
+    assert relerr(ef.download(hfx.GRAD_DISU_UPTS), em.download(hfx.GRAD_DISU_UPTS)) < 1e-11
+    assert relerr(ef.download(hfx.GRAD_DISU_FPTS), em.download(hfx.GRAD_DISU_FPTS)) < 1e-11
+    em.extrapolate_solution()
+    assert relerr(ef.download(hfx.DISU_FPTS), em.download(hfx.DISU_FPTS)) < 1e-13
+    # mixing the paths: a per-method stage after fused steps sees a consistent state
+    hfx.run_steps(ef, ff, 1, fused=False)
+    hfx.run_steps(em, fm, 1, fused=True)
+    assert relerr(ef.download(hfx.DISU_UPTS0), em.download(hfx.DISU_UPTS0)) < 1e-12
+    for f in ff + fm:
+        f.close()
+    ef.close(); em.close()
+
+
+def test_fused_nan_flag(ctx):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p1_rusanov.npz")))
+    e, faces = build(ctx, d)
+    u = np.array(d["u_init"], order="F")
+    u[3, 5, 0] = np.nan
+    e.upload(hfx.DISU_UPTS0, u)
+    hfx.run_steps(e, faces, 1, fused=True)
+    assert e.check_nan() >= 0
+    for f in faces:
+        f.close()
+    e.close()
+
+
+def test_fused_quads_vs_methods():
+    """2-D tensor-product elements (BASELINE.json configs[0]'s element type) through both paths."""
+    a = H.Case([6, 5, 1], dims=2, order=3, amp=0.1)
+    b = H.Case([6, 5, 1], dims=2, order=3, amp=0.1)
+    a.to_device(0); b.to_device(0)
+    a.run_steps_lib(2, fused=True)
+    b.run_steps_lib(2, fused=False)
+    a.sync_host(); b.sync_host()
+    assert relerr(a.array("disu_upts0"), b.array("disu_upts0")) < 1e-12
+    assert relerr(a.array("disu_upts0"), H.Case([6, 5, 1], dims=2, order=3, amp=0.1).array("disu_upts0")) > 1e-8
+    a.close(); b.close()
+
+
+def test_fused_full_size_conservation():
+    c = H.Case(32, order=4)
+    u0 = c.array("disu_upts0")
+    i0 = integrals(c, u0)
+    c.to_device(0)
+    c.run_steps_lib(2, fused=True)
+    c.sync_host()
+    u = c.array("disu_upts0")
+    assert np.isfinite(u).all()
+    i1 = integrals(c, u)
+    vol = (2 * np.pi) ** 3
+    scale = np.array([1.0, 1.0, 1.0, 1.0, u0[:, :, 4].max()]) * vol
+    assert np.all(np.abs(i1 - i0) / scale < 1e-12), (i1 - i0) / scale
+    # and the two paths agree at full size
+    m = H.Case(32, order=4)
+    m.to_device(0)
+    m.run_steps_lib(2, fused=False)
+    m.sync_host()
+    assert relerr(u, m.array("disu_upts0")) < 1e-12
+    c.close(); m.close()
+
+
+def test_fused_full_size_residual_norms_vs_reference_stdout():
+    """the reference's own iteration-1 row for the 32^3 P4 TGV case."""
+    c = H.Case(32, order=4)
+    c.to_device(0)
+    c.run_steps_lib(1, fused=True)
+    ctx_, e, f, nb = c.handles()
+    v = C.c_double()
+    r = []
+    for fld in range(5):
+        hfx.check(hfx.lib().hfx_eles_compute_res_upts(e, 1, fld, C.byref(v)))
+        r.append(v.value / (c.n_eles * c.n_upts))
+    c.close()
+    want = np.array([0.00070019, 0.05031596, 0.05031596, 0.06433493, 0.11799063])
+    assert np.all(np.abs(np.array(r) - want) < 6e-9), r
+
+
+def test_fused_refuses_what_it_cannot_do(ctx):
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p1_rusanov.npz")))
+    e, faces = build(ctx, d)
+    with pytest.raises(hfx.HfxError):
+        hfx.run_steps(e, [], 1, fused=True)  # flux points without partner
+    for f in faces:
+        f.close()
+    e.close()
