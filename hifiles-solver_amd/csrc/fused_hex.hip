@@ -19,9 +19,18 @@
 // left/right argument order with the LEFT normal, so both sides compute bit-identical
 // numbers and nothing is scattered (no atomics, no norm_tconf / delta round trip).
 //
-// The operators are applied in their registered sparse (ELL) form, every thread owning one
-// operator row whose non-zeros live in registers for the whole persistent loop; summation
-// orders are the reference's (column ascending, dimension slabs in order).
+// Work decomposition (64-wide wavefronts): a workgroup is WU "solution-point" waves
+// (one thread per upt) plus WF "flux-point" waves (one thread per fpt).  The two roles
+// overlap: while the upt waves evaluate fluxes, the fpt waves have their partner gathers
+// in flight.  The element state is double-buffered in LDS so that the next element's
+// loads are issued a full iteration ahead.
+//
+// Operator rows are held in DICTIONARY-COMPRESSED sparse form: a tensor-product operator
+// has only a handful of distinct values (entries of the 1-D matrices), so a row entry is
+// 16 bits (value id, column), two per 32-bit register, and the values sit in a 2 kB LDS
+// table.  A thread keeps the rows of its role in ~12 registers for the whole persistent
+// loop instead of ~100.  The arithmetic is unchanged: the same non-zeros, multiplied in
+// the same ascending-column order as the reference dgemm (src/funcs.cpp:110-117).
 #include "fused_hex.hpp"
 
 #include <algorithm>
@@ -32,12 +41,23 @@
 namespace hfx
 {
 
+constexpr int MAX_TAB = 256;
+
+// minimum waves per SIMD the fused kernels are compiled for (second __launch_bounds__ argument):
+// bounds the register allocation; the kernels are latency-bound at low occupancy
+#ifndef HFX_FUSED_WAVES
+#define HFX_FUSED_WAVES 2
+#endif
+
 struct FusedData
 {
-  int *nbr = nullptr;           // (n_fpts, n_eles) partner offset in the (fpt,ele) plane, -1: none
+  int *nbr = nullptr;            // (n_fpts, n_eles) partner offset in the (fpt,ele) plane
   unsigned char *meta = nullptr; // bit0: this point is the RIGHT side, bit1: beta sign flipped
-  double *fnorm = nullptr;      // (n_fpts, n_eles, n_dims) the LEFT element's unit normal of the pair
-  double *disu_alt = nullptr;   // second disu_fpts buffer
+  double *fnorm = nullptr;       // (n_fpts, n_eles, n_dims) the LEFT element's unit normal of the pair
+  double *disu_alt = nullptr;    // second disu_fpts buffer
+  unsigned *pk_g = nullptr, *pk_r = nullptr; // packed operator rows of the gradient / residual kernel
+  double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)
+  int *o1m_dim = nullptr;                    // (n_fpts) dimension slab of the merged opp_1 row
   bool built = false;
   int grid = 0;
 };
@@ -51,25 +71,19 @@ void fused_destroy(hfx_eles *e)
 {
   if (!e || !e->fused) return;
   FusedData *f = e->fused;
-  if (f->nbr) (void)hipFree(f->nbr);
-  if (f->meta) (void)hipFree(f->meta);
-  if (f->fnorm) (void)hipFree(f->fnorm);
-  if (f->disu_alt) (void)hipFree(f->disu_alt);
+  void *p[] = {f->nbr, f->meta, f->fnorm, f->disu_alt, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
+  for (void *q : p)
+    if (q) (void)hipFree(q);
   delete f;
   e->fused = nullptr;
 }
 
-struct EllRef
-{
-  const double *val;
-  const int *idx;
-  int w; // stored width (nnz_max, >= 1)
-};
-
 struct FusedArgs
 {
   int n_eles;
-  EllRef o0, o1[3], o2[3], o3, o4[3], o5[3], o6;
+  const unsigned *pk; // packed operator rows of this kernel
+  const double *tab;  // value table (MAX_TAB)
+  const int *o1m_dim;
   const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts, *tdA_fpts, *fnorm;
   const int *nbr;
   const unsigned char *meta;
@@ -81,21 +95,83 @@ struct FusedArgs
   unsigned long long *nan_flag;
   Phys P;
   // time stepping
-  int adv_type, in_step, dt_local_on, write_div;
+  int adv_type, in_step, dt_local_on, write_div, need_u1;
   double dt, rk_a, rk_b;
 };
 
 constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+constexpr int words_of(int w) { return (w + 1) / 2; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int W>
-__device__ __forceinline__ void load_row(const EllRef &o, int m, int r, double (&v)[W], int (&ix)[W])
+template <int ND, int N>
+struct Geo
+{
+  static constexpr int NF = ND + 2;
+  static constexpr int NU = ipow(N, ND);
+  static constexpr int NFP = 2 * ND * ipow(N, ND - 1);
+  static constexpr int WU = (NU + 63) / 64;  // solution-point waves
+  static constexpr int WF = (NFP + 63) / 64; // flux-point waves
+  static constexpr int TU = 64 * WU;
+  static constexpr int TB = 64 * (WU + WF);
+  static constexpr int UNP = (NF * NU + TU - 1) / TU; // doubles of the next element's state per upt thread
+  static constexpr int WN = words_of(N);
+  // packed-row layout, gradient kernel: opp_4[d] | opp_5[d] (rows = upts) | opp_0 | opp_6 (rows = fpts)
+  static constexpr int G_O4 = 0;
+  static constexpr int G_O5 = G_O4 + ND * WN * NU;
+  static constexpr int G_O0 = G_O5 + ND * words_of(2) * NU;
+  static constexpr int G_O6 = G_O0 + WN * NFP;
+  static constexpr int G_END = G_O6 + WN * NFP;
+  static constexpr int G_WU = ND * WN + ND * words_of(2); // words per upt thread
+  static constexpr int G_WF = 2 * WN;                     // words per fpt thread
+  // residual kernel: opp_2[d] | opp_3 (upts) | opp_0 | merged opp_1 (fpts)
+  static constexpr int R_O2 = 0;
+  static constexpr int R_O3 = R_O2 + ND * WN * NU;
+  static constexpr int R_O0 = R_O3 + words_of(2 * ND) * NU;
+  static constexpr int R_O1 = R_O0 + WN * NFP;
+  static constexpr int R_END = R_O1 + WN * NFP;
+  static constexpr int R_WU = ND * WN + words_of(2 * ND);
+  static constexpr int R_WF = 2 * WN;
+};
+
+// acc += sum_q tab[vid_q] * data[col_q], ascending q (= ascending column).  `w` is a
+// register array subscripted with compile-time constants only.
+template <int W, int OFF, int PW>
+__device__ __forceinline__ double row_dot(const unsigned (&w)[PW], const double *tab, const double *data, double acc)
 {
 #pragma unroll
-  for (int q = 0; q < W; q++)
+  for (int i = 0; i < words_of(W); i++)
   {
-    const bool in = q < o.w;
-    v[q] = in ? o.val[r + m * q] : 0.0;
-    ix[q] = in ? o.idx[r + m * q] : o.idx[r];
+    // The unpacked (value id, column) pairs are loop invariant; left alone the compiler hoists
+    // all of them out of the persistent loop and the ~12 packed registers turn back into ~100
+    // address registers.  The empty asm makes the word opaque so that it is unpacked at the use.
+    unsigned word = w[OFF + i];
+    asm volatile("" : "+v"(word));
+    {
+      const unsigned ent = word & 0xffffu;
+      acc += tab[ent >> 8] * data[ent & 0xffu];
+    }
+    if (2 * i + 1 < W)
+    {
+      const unsigned ent = word >> 16;
+      acc += tab[ent >> 8] * data[ent & 0xffu];
+    }
+  }
+  return acc;
+}
+
+// g_phys(d) = sum_l (inv_detjac * g_ref(l)) * JGinv(l,d)   (BLAS=NO branch of src/eles.cpp:1975-1979)
+template <int ND>
+__device__ __forceinline__ void to_physical(const double inv_detjac, const double (&JG)[ND * ND], const double (&tg)[ND],
+                                            double (&cg)[ND])
+{
+#pragma unroll
+  for (int d = 0; d < ND; d++) cg[d] = 0.0;
+#pragma unroll
+  for (int l = 0; l < ND; l++)
+  {
+    const double temp = inv_detjac * tg[l];
+#pragma unroll
+    for (int d = 0; d < ND; d++) cg[d] += temp * JG[l + ND * d];
   }
 }
 
@@ -103,270 +179,369 @@ __device__ __forceinline__ void load_row(const EllRef &o, int m, int r, double (
 // gradient kernel
 // ---------------------------------------------------------------------------------------
 template <int ND, int N>
-__global__ __launch_bounds__(((ipow(N, ND) > 2 * ND * ipow(N, ND - 1) ? ipow(N, ND) : 2 * ND * ipow(N, ND - 1)) + 63) / 64 * 64)
-void fused_gradient_kernel(const FusedArgs a)
+__global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_gradient_kernel(const FusedArgs a)
 {
-  constexpr int NF = ND + 2;
-  constexpr int NU = ipow(N, ND);
-  constexpr int NFP = 2 * ND * ipow(N, ND - 1);
-  constexpr int TB = ((NU > NFP ? NU : NFP) + 63) / 64 * 64;
-  __shared__ double su[NF][NU];
+  using G = Geo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TU = G::TU, UNP = G::UNP, WN = G::WN;
+  constexpr int PW = cmax(G::G_WU, G::G_WF);
+  __shared__ double tab[MAX_TAB];
+  __shared__ double su[2][NF][NU];
   __shared__ double sd[NF][NFP];
   __shared__ double sg[NF * ND][NU];
-  const int t = threadIdx.x;
-  const bool is_u = t < NU, is_f = t < NFP;
+  const int tid = threadIdx.x;
+  const bool role_u = tid < TU;
+  const int tu = tid, tf = tid - TU;
+  const bool act = role_u ? (tu < NU) : (tf < NFP);
   const long ne = a.n_eles;
   const long plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
+  const long stride = gridDim.x;
 
-  double v0[N], v6[N], v4[ND][N], v5[ND][2];
-  int i0[N], i6[N], i4[ND][N], i5[ND][2];
-  if (is_f)
-  {
-    load_row<N>(a.o0, NFP, t, v0, i0);
-    load_row<N>(a.o6, NFP, t, v6, i6);
-  }
-  if (is_u)
-  {
+  for (int q = tid; q < MAX_TAB; q += G::TB) tab[q] = a.tab[q];
+
+  // the operator rows of this thread's role: upt [opp_4[0..ND) | opp_5[0..ND)], fpt [opp_0 | opp_6]
+  unsigned pw[PW];
 #pragma unroll
-    for (int d = 0; d < ND; d++)
+  for (int i = 0; i < PW; i++) pw[i] = 0;
+  if (act)
+  {
+    if (role_u)
     {
-      load_row<N>(a.o4[d], NU, t, v4[d], i4[d]);
-      load_row<2>(a.o5[d], NU, t, v5[d], i5[d]);
+#pragma unroll
+      for (int d = 0; d < ND; d++)
+      {
+#pragma unroll
+        for (int i = 0; i < WN; i++) pw[d * WN + i] = a.pk[G::G_O4 + (d * WN + i) * NU + tu];
+        pw[ND * WN + d] = a.pk[G::G_O5 + d * NU + tu];
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < WN; i++)
+      {
+        pw[i] = a.pk[G::G_O0 + i * NFP + tf];
+        pw[WN + i] = a.pk[G::G_O6 + i * NFP + tf];
+      }
     }
   }
 
-  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  long e = blockIdx.x;
+  long nb = 0;
+  unsigned mt = 0;
+  if (e < ne)
   {
-    // ---- stage u of this element through LDS (5 contiguous runs of NU doubles)
-    for (int q = t; q < NF * NU; q += TB)
+    if (role_u)
     {
-      const int f = q / NU, p = q - f * NU;
-      su[f][p] = a.u0[p + NU * e + f * plane_u];
+      for (int q = tu; q < NF * NU; q += TU)
+      {
+        const int f = q / NU, p = q - f * NU;
+        su[0][f][p] = a.u0[p + NU * e + f * plane_u];
+      }
     }
-    __syncthreads();
-
-    // ---- flux points: own value (opp_0 row), partner value, LDG common solution -> delta
-    if (is_f)
+    else if (act)
     {
-      const long o = t + NFP * e;
-      const long nb = a.nbr[o];
-      const unsigned char mt = a.meta[o];
+      nb = a.nbr[tf + NFP * e];
+      mt = a.meta[tf + NFP * e];
+    }
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (; e < ne; e += stride, buf ^= 1)
+  {
+    const long en = e + stride;
+    const bool has_next = en < ne;
+    double un[UNP];
+    double g[NF][ND];
+    double JG[ND * ND], inv_detjac = 0.0;
+    // ---------------- P1
+    if (role_u)
+    {
+      if (has_next)
+      {
+#pragma unroll
+        for (int r = 0; r < UNP; r++)
+        {
+          const int q = tu + r * TU;
+          if (q < NF * NU)
+          {
+            const int f = q / NU, p = q - f * NU;
+            un[r] = a.u0[p + NU * en + f * plane_u];
+          }
+        }
+      }
+      if (act)
+      {
+        const long p = tu + NU * e;
+#pragma unroll
+        for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
+        inv_detjac = 1.0 / a.detjac_upts[p];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          g[k][0] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+          g[k][1] = row_dot<N, WN, PW>(pw, tab, &su[buf][k][0], 0.0);
+          if (ND == 3) g[k][ND - 1] = row_dot<N, (ND - 1) * WN, PW>(pw, tab, &su[buf][k][0], 0.0);
+        }
+      }
+    }
+    else if (act)
+    {
+      const long o = tf + NFP * e;
+      double oth[NF];
+#pragma unroll
+      for (int k = 0; k < NF; k++) oth[k] = a.disu_cur[nb + k * plane_f];
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_fpts[o * (ND * ND) + q];
+      inv_detjac = 1.0 / a.detjac_fpts[o];
       const bool right = mt & 1;
       const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
-        double own = 0.0;
-#pragma unroll
-        for (int q = 0; q < N; q++) own += v0[q] * su[k][i0[q]];
-        const double oth = a.disu_cur[nb + k * plane_f];
-        const double ul = right ? oth : own, ur = right ? own : oth;
+        const double own = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+        const double ul = right ? oth[k] : own, ur = right ? own : oth[k];
         // u_c = 1/2 (u_l + u_r) - beta (u_l - u_r)   (src/inters.cpp:637)
         const double uc = 0.5 * (ul + ur) - beta * (ul - ur);
-        sd[k][t] = uc - own;
+        sd[k][tf] = uc - own;
       }
     }
-    __syncthreads();
+    __syncthreads(); // B: sd ready
 
-    // ---- solution points: grad_ref = opp_4 u + opp_5 delta ; physical transform ; store
-    if (is_u)
+    // ---------------- P2
+    long nb_next = 0;
+    unsigned mt_next = 0;
+    if (role_u)
     {
-      const long p = t + NU * e;
-      double JG[ND * ND];
+      if (act)
+      {
+        const long p = tu + NU * e;
 #pragma unroll
-      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
-      const double inv_detjac = 1.0 / a.detjac_upts[p];
+        for (int k = 0; k < NF; k++)
+        {
+          double tg[ND], cg[ND];
+          tg[0] = row_dot<2, ND * WN + 0, PW>(pw, tab, &sd[k][0], g[k][0]);
+          tg[1] = row_dot<2, ND * WN + 1, PW>(pw, tab, &sd[k][0], g[k][1]);
+          if (ND == 3) tg[ND - 1] = row_dot<2, ND * WN + ND - 1, PW>(pw, tab, &sd[k][0], g[k][ND - 1]);
+#pragma unroll
+          for (int d = 0; d < ND; d++) sg[k + NF * d][tu] = tg[d]; // opp_6 acts on the reference-space gradient
+          to_physical<ND>(inv_detjac, JG, tg, cg);
+#pragma unroll
+          for (int d = 0; d < ND; d++) a.grad_upts[p + (k + NF * d) * plane_u] = cg[d];
+        }
+      }
+      if (has_next)
+      {
+#pragma unroll
+        for (int r = 0; r < UNP; r++)
+        {
+          const int q = tu + r * TU;
+          if (q < NF * NU)
+          {
+            const int f = q / NU, p = q - f * NU;
+            su[buf ^ 1][f][p] = un[r];
+          }
+        }
+      }
+    }
+    else if (act && has_next)
+    {
+      nb_next = a.nbr[tf + NFP * en];
+      mt_next = a.meta[tf + NFP * en];
+    }
+    __syncthreads(); // C: sg ready, su[buf^1] ready
+
+    // ---------------- P3
+    if (!role_u && act)
+    {
+      const long o = tf + NFP * e;
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
         double tg[ND], cg[ND];
 #pragma unroll
-        for (int d = 0; d < ND; d++)
-        {
-          double g = 0.0;
-#pragma unroll
-          for (int q = 0; q < N; q++) g += v4[d][q] * su[k][i4[d][q]];
-#pragma unroll
-          for (int q = 0; q < 2; q++) g += v5[d][q] * sd[k][i5[d][q]];
-          tg[d] = g;
-          sg[k + NF * d][t] = g; // opp_6 acts on the reference-space corrected gradient
-        }
-#pragma unroll
-        for (int d = 0; d < ND; d++) cg[d] = 0.0;
-#pragma unroll
-        for (int l = 0; l < ND; l++)
-        {
-          const double temp = inv_detjac * tg[l];
-#pragma unroll
-          for (int d = 0; d < ND; d++) cg[d] += temp * JG[l + ND * d];
-        }
-#pragma unroll
-        for (int d = 0; d < ND; d++) a.grad_upts[p + (k + NF * d) * plane_u] = cg[d];
-      }
-    }
-    __syncthreads();
-
-    // ---- flux points: grad_fpts = opp_6 grad_ref ; physical transform ; store for the neighbours
-    if (is_f)
-    {
-      const long o = t + NFP * e;
-      double JG[ND * ND];
-#pragma unroll
-      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_fpts[o * (ND * ND) + q];
-      const double inv_detjac = 1.0 / a.detjac_fpts[o];
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        double tg[ND], cg[ND];
-#pragma unroll
-        for (int d = 0; d < ND; d++)
-        {
-          double g = 0.0;
-#pragma unroll
-          for (int q = 0; q < N; q++) g += v6[q] * sg[k + NF * d][i6[q]];
-          tg[d] = g;
-        }
-#pragma unroll
-        for (int d = 0; d < ND; d++) cg[d] = 0.0;
-#pragma unroll
-        for (int l = 0; l < ND; l++)
-        {
-          const double temp = inv_detjac * tg[l];
-#pragma unroll
-          for (int d = 0; d < ND; d++) cg[d] += temp * JG[l + ND * d];
-        }
+        for (int d = 0; d < ND; d++) tg[d] = row_dot<N, WN, PW>(pw, tab, &sg[k + NF * d][0], 0.0);
+        to_physical<ND>(inv_detjac, JG, tg, cg);
 #pragma unroll
         for (int d = 0; d < ND; d++) a.grad_fpts[o + (k + NF * d) * plane_f] = cg[d];
       }
+      nb = nb_next;
+      mt = mt_next;
     }
-    // no barrier needed here: the next iteration's writes to su / sd / sg are each separated from
-    // this iteration's last reads of them by the barriers above
+    // no barrier: the next iteration's first LDS writes (sd by the fpt waves, sg by the upt waves
+    // after its barrier B) are ordered behind this iteration's last reads by barriers B' / C
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // residual kernel
 // ---------------------------------------------------------------------------------------
-template <int ND, int N>
-__global__ __launch_bounds__(((ipow(N, ND) > 2 * ND * ipow(N, ND - 1) ? ipow(N, ND) : 2 * ND * ipow(N, ND - 1)) + 63) / 64 * 64)
-void fused_residual_kernel(const FusedArgs a)
+template <int ND, int N, int RS>
+__global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_residual_kernel(const FusedArgs a)
 {
-  constexpr int NF = ND + 2;
-  constexpr int NU = ipow(N, ND);
-  constexpr int NFP = 2 * ND * ipow(N, ND - 1);
-  constexpr int TB = ((NU > NFP ? NU : NFP) + 63) / 64 * 64;
+  using G = Geo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TU = G::TU, UNP = G::UNP, WN = G::WN;
   constexpr int N3 = 2 * ND;
-  __shared__ double su[NF][NU];
+  constexpr int PW = cmax(G::R_WU, G::R_WF);
+  __shared__ double tab[MAX_TAB];
+  __shared__ double su[2][NF][NU];
   __shared__ double st[NF * ND][NU];
   __shared__ double sc[NF][NFP];
-  const int t = threadIdx.x;
-  const bool is_u = t < NU, is_f = t < NFP;
+  const int tid = threadIdx.x;
+  const bool role_u = tid < TU;
+  const int tu = tid, tf = tid - TU;
+  const bool act = role_u ? (tu < NU) : (tf < NFP);
   const long ne = a.n_eles;
   const long plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
+  const long stride = gridDim.x;
   const bool viscous = a.P.viscous;
 
-  double v0[N], v1[ND][N], v2[ND][N], v3[N3];
-  int i0[N], i1[ND][N], i2[ND][N], i3[N3];
-  if (is_f)
-  {
-    load_row<N>(a.o0, NFP, t, v0, i0);
-#pragma unroll
-    for (int d = 0; d < ND; d++) load_row<N>(a.o1[d], NFP, t, v1[d], i1[d]);
-  }
-  if (is_u)
-  {
-#pragma unroll
-    for (int d = 0; d < ND; d++) load_row<N>(a.o2[d], NU, t, v2[d], i2[d]);
-    load_row<N3>(a.o3, NU, t, v3, i3);
-  }
+  for (int q = tid; q < MAX_TAB; q += G::TB) tab[q] = a.tab[q];
 
-  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  // upt [opp_2[0..ND) | opp_3], fpt [opp_0 | merged opp_1]
+  unsigned pw[PW];
+#pragma unroll
+  for (int i = 0; i < PW; i++) pw[i] = 0;
+  int d1 = 0;
+  if (act)
   {
-    for (int q = t; q < NF * NU; q += TB)
+    if (role_u)
     {
-      const int f = q / NU, p = q - f * NU;
-      su[f][p] = a.u0[p + NU * e + f * plane_u];
+#pragma unroll
+      for (int i = 0; i < ND * WN; i++) pw[i] = a.pk[G::R_O2 + i * NU + tu];
+#pragma unroll
+      for (int i = 0; i < words_of(N3); i++) pw[ND * WN + i] = a.pk[G::R_O3 + i * NU + tu];
     }
-    __syncthreads();
-
-    // ---- solution points: total transformed flux, discontinuous divergence
-    double div[NF];
-    if (is_u)
+    else
     {
-      const long p = t + NU * e;
-      double u[NF], f[NF * ND], JG[ND * ND], td[NF * ND];
 #pragma unroll
-      for (int k = 0; k < NF; k++) u[k] = su[k][t];
+      for (int i = 0; i < WN; i++)
+      {
+        pw[i] = a.pk[G::R_O0 + i * NFP + tf];
+        pw[WN + i] = a.pk[G::R_O1 + i * NFP + tf];
+      }
+      d1 = a.o1m_dim[tf];
+    }
+  }
+
+  long e = blockIdx.x;
+  long nb = 0;
+  unsigned mt = 0;
+  if (e < ne)
+  {
+    if (role_u)
+    {
+      for (int q = tu; q < NF * NU; q += TU)
+      {
+        const int f = q / NU, p = q - f * NU;
+        su[0][f][p] = a.u0[p + NU * e + f * plane_u];
+      }
+    }
+    else if (act)
+    {
+      nb = a.nbr[tf + NFP * e];
+      mt = a.meta[tf + NFP * e];
+    }
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (; e < ne; e += stride, buf ^= 1)
+  {
+    const long en = e + stride;
+    const bool has_next = en < ne;
+    double un[UNP];
+    double div[NF], u1v[NF], dj = 1.0;
+    double tconf[NF];
+    // ---------------- P1
+    if (role_u)
+    {
+      if (has_next)
+      {
 #pragma unroll
-      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
-      calc_invf<ND>(a.P.gamma, u, f);
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-#pragma unroll
-        for (int l = 0; l < ND; l++)
+        for (int r = 0; r < UNP; r++)
         {
-          double s = 0.0;
-#pragma unroll
-          for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-          td[k + NF * l] = s;
-        }
-      if (viscous)
-      {
-        double g[NF * ND];
-#pragma unroll
-        for (int q = 0; q < NF * ND; q++) g[q] = a.grad_upts[p + q * plane_u];
-        calc_visf<ND>(a.P, u, g, f);
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-#pragma unroll
-          for (int l = 0; l < ND; l++)
+          const int q = tu + r * TU;
+          if (q < NF * NU)
           {
-            double s = td[k + NF * l];
-#pragma unroll
-            for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-            td[k + NF * l] = s;
+            const int f = q / NU, p = q - f * NU;
+            un[r] = a.u0[p + NU * en + f * plane_u];
           }
+        }
       }
-#pragma unroll
-      for (int q = 0; q < NF * ND; q++) st[q][t] = td[q];
-    }
-    __syncthreads();
-
-    if (is_u)
-    {
-#pragma unroll
-      for (int k = 0; k < NF; k++)
+      if (act)
       {
-        double s = 0.0;
+        const long p = tu + NU * e;
+        double u[NF], f[NF * ND], JG[ND * ND];
 #pragma unroll
-        for (int d = 0; d < ND; d++)
+        for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
+        dj = a.detjac_upts[p];
+        if (a.need_u1)
+        {
 #pragma unroll
-          for (int q = 0; q < N; q++) s += v2[d][q] * st[k + NF * d][i2[d][q]];
-        div[k] = s;
+          for (int k = 0; k < NF; k++) u1v[k] = a.u1[p + k * plane_u];
+        }
+#pragma unroll
+        for (int k = 0; k < NF; k++) u[k] = su[buf][k][tu];
+        calc_invf<ND, true>(a.P.gamma, u, f);
+        if (!viscous)
+        {
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+#pragma unroll
+            for (int l = 0; l < ND; l++)
+            {
+              double s = 0.0;
+#pragma unroll
+              for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+              st[k + NF * l][tu] = s;
+            }
+        }
+        else
+        {
+          double td[NF * ND];
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+#pragma unroll
+            for (int l = 0; l < ND; l++)
+            {
+              double s = 0.0;
+#pragma unroll
+              for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+              td[k + NF * l] = s;
+            }
+          {
+            double gr[NF * ND];
+#pragma unroll
+            for (int q = 0; q < NF * ND; q++) gr[q] = a.grad_upts[p + q * plane_u];
+            calc_visf<ND, true>(a.P, u, gr, f);
+          }
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+#pragma unroll
+            for (int l = 0; l < ND; l++)
+            {
+              double s = td[k + NF * l];
+#pragma unroll
+              for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+              st[k + NF * l][tu] = s;
+            }
+        }
       }
     }
-
-    // ---- flux points: normal discontinuous flux, common fluxes from own + partner data
-    if (is_f)
+    else if (act)
     {
-      const long o = t + NFP * e;
-      const long nb = a.nbr[o];
-      const unsigned char mt = a.meta[o];
+      const long o = tf + NFP * e;
       const bool right = mt & 1;
       const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
       double own[NF], oth[NF], n[ND], fn[NF];
 #pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < N; q++) s += v0[q] * su[k][i0[q]];
-        own[k] = s;
-        oth[k] = a.disu_cur[nb + k * plane_f];
-      }
+      for (int k = 0; k < NF; k++) oth[k] = a.disu_cur[nb + k * plane_f];
 #pragma unroll
       for (int m = 0; m < ND; m++) n[m] = a.fnorm[o + m * plane_f];
       const double tdA = a.tdA_fpts[o];
+#pragma unroll
+      for (int k = 0; k < NF; k++) own[k] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
       const double sgn_tdA = right ? -tdA : tdA;
       double ul[NF], ur[NF];
 #pragma unroll
@@ -375,134 +550,169 @@ void fused_residual_kernel(const FusedArgs a)
         ul[k] = right ? oth[k] : own[k];
         ur[k] = right ? own[k] : oth[k];
       }
-      riemann_flux<ND>(a.P, ul, ur, n, fn);
-      double tconf[NF];
+      riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
 #pragma unroll
       for (int k = 0; k < NF; k++) tconf[k] = fn[k] * sgn_tdA;
       if (viscous)
       {
-        double gl[NF * ND], gr[NF * ND], fl[NF * ND], fr[NF * ND];
-#pragma unroll
-        for (int s = 0; s < NF * ND; s++)
+        // the left state's gradient lives on this point when it is the LEFT side, on the partner otherwise
+        const long ol = right ? nb : o, orr = right ? o : nb;
+        // fn_v = sum_l [(1/2+beta) F_l + (1/2-beta) F_r](k,l) n_l - tau (u_r - u_l)   (src/inters.cpp:583-611).
+        // The left contribution is projected on the normal before the right flux is evaluated, so
+        // that only NF (not NF*ND) values stay live across the second flux evaluation; this
+        // re-associates the sum over the two sides (a rounding-level change).
+        double pl[NF];
         {
-          const double go = a.grad_fpts[o + s * plane_f];
-          const double gn = a.grad_fpts[nb + s * plane_f];
-          gl[s] = right ? gn : go;
-          gr[s] = right ? go : gn;
+          double gq[NF * ND], fq[NF * ND];
+#pragma unroll
+          for (int s = 0; s < NF * ND; s++) gq[s] = a.grad_fpts[ol + s * plane_f];
+          calc_visf<ND, true>(a.P, ul, gq, fq);
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+          {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < ND; l++) s += ((0.5 + beta) * fq[k + NF * l]) * n[l];
+            pl[k] = s;
+          }
         }
-        calc_visf<ND>(a.P, ul, gl, fl);
-        calc_visf<ND>(a.P, ur, gr, fr);
+        {
+          double gq[NF * ND], fq[NF * ND];
+#pragma unroll
+          for (int s = 0; s < NF * ND; s++) gq[s] = a.grad_fpts[orr + s * plane_f];
+          calc_visf<ND, true>(a.P, ur, gq, fq);
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+          {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < ND; l++) s += ((0.5 - beta) * fq[k + NF * l]) * n[l];
+            double fv = pl[k] + s;
+            fv -= a.P.ldg_tau * (ur[k] - ul[k]);
+            tconf[k] += fv * sgn_tdA;
+          }
+        }
+      }
+    }
+    __syncthreads(); // B: st ready
+
+    // ---------------- P2
+    if (role_u)
+    {
+      if (act)
+      {
 #pragma unroll
         for (int k = 0; k < NF; k++)
         {
-          double fv = 0.0;
-#pragma unroll
-          for (int l = 0; l < ND; l++)
-          {
-            const double fc = (0.5 + beta) * fl[k + NF * l] + (0.5 - beta) * fr[k + NF * l];
-            fv += fc * n[l];
-          }
-          fv -= a.P.ldg_tau * (ur[k] - ul[k]);
-          tconf[k] += fv * sgn_tdA;
+          double s = row_dot<N, 0, PW>(pw, tab, &st[k][0], 0.0);
+          s = row_dot<N, WN, PW>(pw, tab, &st[k + NF][0], s);
+          if (ND == 3) s = row_dot<N, (ND - 1) * WN, PW>(pw, tab, &st[k + NF * (ND - 1)][0], s);
+          div[k] = s;
         }
       }
-#pragma unroll
-      for (int k = 0; k < NF; k++)
+      if (has_next)
       {
-        double ntd = 0.0;
 #pragma unroll
-        for (int d = 0; d < ND; d++)
-#pragma unroll
-          for (int q = 0; q < N; q++) ntd += v1[d][q] * st[k + NF * d][i1[d][q]];
-        sc[k][t] = tconf[k] + -1.0 * ntd; // norm_tconf -= norm_tdisf (src/eles.cpp:1746)
+        for (int r = 0; r < UNP; r++)
+        {
+          const int q = tu + r * TU;
+          if (q < NF * NU)
+          {
+            const int f = q / NU, p = q - f * NU;
+            su[buf ^ 1][f][p] = un[r];
+          }
+        }
       }
     }
-    __syncthreads();
-
-    // ---- solution points: correction, RK update
-    if (is_u)
+    else if (act)
     {
-      const long p = t + NU * e;
-      const double dj = a.detjac_upts[p];
-      const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
-        double dv = div[k];
+        const double ntd = row_dot<N, WN, PW>(pw, tab, &st[k + NF * d1][0], 0.0);
+        sc[k][tf] = tconf[k] + -1.0 * ntd; // norm_tconf -= norm_tdisf (src/eles.cpp:1746)
+      }
+    }
+    __syncthreads(); // C: sc ready, su[buf^1] ready
+
+    // ---------------- P3
+    long nb_next = 0;
+    unsigned mt_next = 0;
+    if (role_u)
+    {
+      if (act)
+      {
+        const long p = tu + NU * e;
+        const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
 #pragma unroll
-        for (int q = 0; q < N3; q++) dv += v3[q] * sc[k][i3[q]];
-        const long q = p + k * plane_u;
-        if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)q);
-        if (a.write_div) a.div_out[q] = dv;
-        const double s = a.src ? a.src[q] : 0.0;
-        const double dd = dv / dj;
-        double u = su[k][t];
-        if (a.adv_type == 0)
-          u -= dt * (dd - s);
-        else if (a.adv_type == 1)
+        for (int k = 0; k < NF; k++)
         {
-          if (a.in_step == 0) a.u1[q] = u;
-          if (a.in_step < 3)
-            u -= dt / 3.0 * (dd - s);
+          const double dv = row_dot<N3, ND * WN, PW>(pw, tab, &sc[k][0], div[k]);
+          const long q = p + k * plane_u;
+          if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)q);
+          if (a.write_div) a.div_out[q] = dv;
+          const double s = a.src ? a.src[q] : 0.0;
+          const double dd = dv / dj;
+          double u = su[buf][k][tu];
+          if (a.adv_type == 0)
+            u -= dt * (dd - s);
+          else if (a.adv_type == 1)
+          {
+            if (a.in_step == 0) a.u1[q] = u;
+            if (a.in_step < 3)
+              u -= dt / 3.0 * (dd - s);
+            else
+            {
+              const double rhs = -dd + s;
+              u = 3.0 / 4.0 * u + 1.0 / 4.0 * u1v[k] + dt / 4.0 * rhs;
+            }
+          }
+          else if (a.adv_type == 2)
+          {
+            if (a.in_step == 0) a.u1[q] = u;
+            if (a.in_step < 2 || a.in_step == 3)
+              u -= dt / 2.0 * (dd - s);
+            else if (a.in_step == 2)
+            {
+              const double rhs = -dd + s;
+              u = 1.0 / 3.0 * u + 2.0 / 3.0 * u1v[k] + dt / 6.0 * rhs;
+            }
+          }
           else
           {
             const double rhs = -dd + s;
-            u = 3.0 / 4.0 * u + 1.0 / 4.0 * a.u1[q] + dt / 4.0 * rhs;
+            const double r1 = a.rk_a * u1v[k] + dt * rhs;
+            a.u1[q] = r1;
+            u += a.rk_b * r1;
           }
+          a.u0[q] = u;
+          su[buf][k][tu] = u; // own point only; the fpt waves read it after barrier D
         }
-        else if (a.adv_type == 2)
-        {
-          if (a.in_step == 0) a.u1[q] = u;
-          if (a.in_step < 2 || a.in_step == 3)
-            u -= dt / 2.0 * (dd - s);
-          else if (a.in_step == 2)
-          {
-            const double rhs = -dd + s;
-            u = 1.0 / 3.0 * u + 2.0 / 3.0 * a.u1[q] + dt / 6.0 * rhs;
-          }
-        }
-        else
-        {
-          const double rhs = -dd + s;
-          const double r1 = a.rk_a * a.u1[q] + dt * rhs;
-          a.u1[q] = r1;
-          u += a.rk_b * r1;
-        }
-        a.u0[q] = u;
-        su[k][t] = u; // each thread overwrites only its own point, read again after the barrier
       }
     }
-    __syncthreads();
-
-    // ---- disu_fpts of the NEW state into the other buffer (the partners still read the old one)
-    if (is_f)
+    else if (act && has_next)
     {
-      const long o = t + NFP * e;
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < N; q++) s += v0[q] * su[k][i0[q]];
-        a.disu_next[o + k * plane_f] = s;
-      }
+      nb_next = a.nbr[tf + NFP * en];
+      mt_next = a.meta[tf + NFP * en];
     }
-    __syncthreads(); // su is rewritten at the top of the loop
+    __syncthreads(); // D: su[buf] holds the new state
+
+    // ---------------- P4: disu_fpts of the NEW state into the other buffer (partners still read the old one)
+    if (!role_u && act)
+    {
+      const long o = tf + NFP * e;
+#pragma unroll
+      for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+      nb = nb_next;
+      mt = mt_next;
+    }
+    // no barrier: su[buf] is next written in P2 of the following iteration, behind its barrier B
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-static EllRef ellref(const Operator &op)
-{
-  EllRef r;
-  r.val = op.ell_val;
-  r.idx = op.ell_idx;
-  r.w = std::max(op.nnz_max, 1);
-  return r;
-}
-
 static int tensor_n(const hfx_eles *e)
 {
   // N with N^ND = n_upts and 2 ND N^(ND-1) = n_fpts, or 0
@@ -511,12 +721,111 @@ static int tensor_n(const hfx_eles *e)
   return 0;
 }
 
+struct Dict
+{
+  std::vector<double> vals;
+  Dict() { vals.push_back(0.0); } // id 0 = +0.0: padding entries multiply by it
+  int id(double v)
+  {
+    for (size_t i = 0; i < vals.size(); i++)
+      if (std::memcmp(&vals[i], &v, sizeof v) == 0) return (int)i;
+    vals.push_back(v);
+    return (int)vals.size() - 1;
+  }
+};
+
+// pack `w` entries per row of an operator given in host ELL form (width hw) at word offset `off`
+static void pack_rows(std::vector<unsigned> &pk, size_t off, int m, int w, const double *hv, const int *hi, int hw, Dict &dict)
+{
+  for (int r = 0; r < m; r++)
+    for (int q = 0; q < w; q++)
+    {
+      const double v = (q < hw) ? hv[r + (size_t)m * q] : 0.0;
+      const int c = (q < hw) ? hi[r + (size_t)m * q] : hi[r];
+      const unsigned ent = ((unsigned)dict.id(v) << 8) | (unsigned)c;
+      pk[off + (size_t)(q >> 1) * m + r] |= ent << (16 * (q & 1));
+    }
+}
+
+static int upload(void **dst, const void *src, size_t bytes)
+{
+  if (!*dst) HFX_HIP(hipMalloc(dst, std::max<size_t>(bytes, 8)));
+  HFX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+template <int ND, int N>
+static int build_packed(hfx_eles *e, FusedData *F, const std::vector<double> &o1v, const std::vector<int> &o1i)
+{
+  using G = Geo<ND, N>;
+  constexpr int NU = G::NU, NFP = G::NFP, WN = G::WN;
+  auto hw = [](const Operator &op) { return std::max(op.nnz_max, 1); };
+  {
+    Dict dict;
+    std::vector<unsigned> pk(G::R_END, 0u);
+    for (int d = 0; d < ND; d++)
+      pack_rows(pk, G::R_O2 + (size_t)d * WN * NU, NU, N, e->opp_2[d].h_val.data(), e->opp_2[d].h_idx.data(), hw(e->opp_2[d]), dict);
+    pack_rows(pk, G::R_O3, NU, 2 * ND, e->opp_3.h_val.data(), e->opp_3.h_idx.data(), hw(e->opp_3), dict);
+    pack_rows(pk, G::R_O0, NFP, N, e->opp_0.h_val.data(), e->opp_0.h_idx.data(), hw(e->opp_0), dict);
+    pack_rows(pk, G::R_O1, NFP, N, o1v.data(), o1i.data(), N, dict);
+    HFX_CHECK(dict.vals.size() <= MAX_TAB, "fused path: operators hold %zu distinct values (> %d)", dict.vals.size(), MAX_TAB);
+    dict.vals.resize(MAX_TAB, 0.0);
+    if (upload((void **)&F->pk_r, pk.data(), sizeof(unsigned) * pk.size())) return 1;
+    if (upload((void **)&F->tab_r, dict.vals.data(), sizeof(double) * MAX_TAB)) return 1;
+  }
+  if (e->viscous_ops)
+  {
+    Dict dict;
+    std::vector<unsigned> pk(G::G_END, 0u);
+    for (int d = 0; d < ND; d++)
+    {
+      pack_rows(pk, G::G_O4 + (size_t)d * WN * NU, NU, N, e->opp_4[d].h_val.data(), e->opp_4[d].h_idx.data(), hw(e->opp_4[d]), dict);
+      pack_rows(pk, G::G_O5 + (size_t)d * NU, NU, 2, e->opp_5[d].h_val.data(), e->opp_5[d].h_idx.data(), hw(e->opp_5[d]), dict);
+    }
+    pack_rows(pk, G::G_O0, NFP, N, e->opp_0.h_val.data(), e->opp_0.h_idx.data(), hw(e->opp_0), dict);
+    pack_rows(pk, G::G_O6, NFP, N, e->opp_6.h_val.data(), e->opp_6.h_idx.data(), hw(e->opp_6), dict);
+    HFX_CHECK(dict.vals.size() <= MAX_TAB, "fused path: operators hold %zu distinct values (> %d)", dict.vals.size(), MAX_TAB);
+    dict.vals.resize(MAX_TAB, 0.0);
+    if (upload((void **)&F->pk_g, pk.data(), sizeof(unsigned) * pk.size())) return 1;
+    if (upload((void **)&F->tab_g, dict.vals.data(), sizeof(double) * MAX_TAB)) return 1;
+  }
+  return 0;
+}
+
+static int dispatch_build_packed(hfx_eles *e, FusedData *F, int N, const std::vector<double> &o1v, const std::vector<int> &o1i)
+{
+  if (e->n_dims == 3)
+  {
+    switch (N)
+    {
+    case 2: return build_packed<3, 2>(e, F, o1v, o1i);
+    case 3: return build_packed<3, 3>(e, F, o1v, o1i);
+    case 4: return build_packed<3, 4>(e, F, o1v, o1i);
+    case 5: return build_packed<3, 5>(e, F, o1v, o1i);
+    case 6: return build_packed<3, 6>(e, F, o1v, o1i);
+    }
+  }
+  else
+  {
+    switch (N)
+    {
+    case 2: return build_packed<2, 2>(e, F, o1v, o1i);
+    case 3: return build_packed<2, 3>(e, F, o1v, o1i);
+    case 4: return build_packed<2, 4>(e, F, o1v, o1i);
+    case 5: return build_packed<2, 5>(e, F, o1v, o1i);
+    case 6: return build_packed<2, 6>(e, F, o1v, o1i);
+    }
+  }
+  set_error("fused path: no kernel for N = %d, n_dims = %d", N, e->n_dims);
+  return 1;
+}
+
 static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
 {
   HFX_CHECK(e->ele_type == 4 || e->ele_type == 1, "fused path: tensor-product elements only (hexes, quads)");
   const int N = tensor_n(e);
   HFX_CHECK(N >= 2 && N <= 6, "fused path: built for orders 1..5 (n_upts %d, n_fpts %d)", e->n_upts, e->n_fpts);
-  const int nd = e->n_dims;
+  const int nd = e->n_dims, nfp = e->n_fpts;
   // the registered operators must have the collocated tensor-product sparsity the kernels are sized for
   HFX_CHECK(e->opp_0.nnz_max <= N && e->opp_3.nnz_max <= 2 * nd, "fused path: opp_0 / opp_3 are not tensor-product sparse");
   for (int d = 0; d < nd; d++)
@@ -527,16 +836,50 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
   }
   if (e->viscous_ops) HFX_CHECK(e->opp_6.nnz_max <= N, "fused path: opp_6 is not tensor-product sparse");
   HFX_CHECK(!e->ctx->params.viscous || e->viscous_ops, "fused path: viscous run but the block has no opp_4/5/6");
+  HFX_CHECK(e->n_upts <= 256 && e->n_fpts <= 256, "fused path: column indices must fit 8 bits");
 
   if (!e->fused) e->fused = new FusedData();
   FusedData *F = e->fused;
+
+  // opp_1 merged over the dimension slabs (row k of opp_1[d] is l_j(fpt_k) * tnorm(d,k): one d per row)
+  {
+    std::vector<double> mv((size_t)nfp * N, 0.0);
+    std::vector<int> mi((size_t)nfp * N, 0), md(nfp, 0);
+    for (int r = 0; r < nfp; r++)
+    {
+      int dsel = -1;
+      for (int d = 0; d < nd; d++)
+      {
+        const Operator &op = e->opp_1[d];
+        const int w = std::max(op.nnz_max, 1);
+        bool any = false;
+        for (int q = 0; q < w; q++) any = any || (op.h_val[r + (size_t)nfp * q] != 0.0);
+        if (any)
+        {
+          HFX_CHECK(dsel < 0, "fused path: row %d of opp_1 has entries in two dimension slabs", r);
+          dsel = d;
+        }
+      }
+      if (dsel < 0) dsel = 0;
+      const Operator &op = e->opp_1[dsel];
+      const int w = std::max(op.nnz_max, 1);
+      md[r] = dsel;
+      for (int q = 0; q < N; q++)
+      {
+        mv[r + (size_t)nfp * q] = (q < w) ? op.h_val[r + (size_t)nfp * q] : 0.0;
+        mi[r + (size_t)nfp * q] = (q < w) ? op.h_idx[r + (size_t)nfp * q] : op.h_idx[r];
+      }
+    }
+    if (upload((void **)&F->o1m_dim, md.data(), sizeof(int) * md.size())) return 1;
+    if (dispatch_build_packed(e, F, N, mv, mi)) return 1;
+  }
+
   const long plane_f = (long)e->n_fpts * e->n_eles;
   std::vector<int> nbr(plane_f, -1);
   std::vector<unsigned char> meta(plane_f, 0);
-  std::vector<double> norm((size_t)plane_f * nd), fnorm((size_t)plane_f * nd);
+  std::vector<double> norm((size_t)plane_f * nd), fnorm;
   HFX_HIP(hipMemcpy(norm.data(), e->norm_fpts, sizeof(double) * norm.size(), hipMemcpyDeviceToHost));
   fnorm = norm;
-  const double beta0 = 1.0; // only the sign decision is stored
   for (int b = 0; b < nfb; b++)
   {
     hfx_inters *f = faces[b];
@@ -547,9 +890,10 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
       const int il = f->hL[q], ir = f->hR[q];
       nbr[il] = ir;
       nbr[ir] = il;
-      // the consistent switch of src/inters.cpp:568-581 on the LEFT normal (exact zero tests)
-      double n[3] = {norm[il], norm[il + plane_f], nd == 3 ? norm[il + 2 * plane_f] : 0.0};
-      double bt = beta0;
+      // the consistent switch of src/inters.cpp:568-581 on the LEFT normal (exact zero tests);
+      // only the sign decision is stored
+      const double n[3] = {norm[il], norm[il + plane_f], nd == 3 ? norm[il + 2 * plane_f] : 0.0};
+      double bt = 1.0;
       if (n[0] < 0.)
         bt = -bt;
       else if (n[0] == 0.)
@@ -569,14 +913,13 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
   }
   for (long o = 0; o < plane_f; o++)
     HFX_CHECK(nbr[o] >= 0, "fused path: flux point %ld has no partner (boundary / partition faces are not fused yet)", o);
-  if (!F->nbr) HFX_HIP(hipMalloc((void **)&F->nbr, sizeof(int) * plane_f));
-  if (!F->meta) HFX_HIP(hipMalloc((void **)&F->meta, plane_f));
-  if (!F->fnorm) HFX_HIP(hipMalloc((void **)&F->fnorm, sizeof(double) * plane_f * nd));
+  if (upload((void **)&F->nbr, nbr.data(), sizeof(int) * plane_f)) return 1;
+  if (upload((void **)&F->meta, meta.data(), plane_f)) return 1;
+  if (upload((void **)&F->fnorm, fnorm.data(), sizeof(double) * plane_f * nd)) return 1;
   if (!F->disu_alt) HFX_HIP(hipMalloc((void **)&F->disu_alt, sizeof(double) * plane_f * e->n_fields));
-  HFX_HIP(hipMemcpy(F->nbr, nbr.data(), sizeof(int) * plane_f, hipMemcpyHostToDevice));
-  HFX_HIP(hipMemcpy(F->meta, meta.data(), plane_f, hipMemcpyHostToDevice));
-  HFX_HIP(hipMemcpy(F->fnorm, fnorm.data(), sizeof(double) * plane_f * nd, hipMemcpyHostToDevice));
-  F->grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * 6);
+  F->grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * 4);
+  if (const char *g = getenv("HFX_FUSED_GRID_PER_CU"))
+    F->grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * std::max(1, atoi(g)));
   F->built = true;
   return 0;
 }
@@ -586,19 +929,7 @@ static FusedArgs fused_args(hfx_eles *e)
   FusedArgs a{};
   FusedData *F = e->fused;
   a.n_eles = e->n_eles;
-  a.o0 = ellref(e->opp_0);
-  a.o3 = ellref(e->opp_3);
-  for (int d = 0; d < e->n_dims; d++)
-  {
-    a.o1[d] = ellref(e->opp_1[d]);
-    a.o2[d] = ellref(e->opp_2[d]);
-    if (e->viscous_ops)
-    {
-      a.o4[d] = ellref(e->opp_4[d]);
-      a.o5[d] = ellref(e->opp_5[d]);
-    }
-  }
-  if (e->viscous_ops) a.o6 = ellref(e->opp_6);
+  a.o1m_dim = F->o1m_dim;
   a.detjac_upts = e->detjac_upts; a.JGinv_upts = e->JGinv_upts;
   a.detjac_fpts = e->detjac_fpts; a.JGinv_fpts = e->JGinv_fpts;
   a.tdA_fpts = e->tdA_fpts; a.fnorm = F->fnorm; a.nbr = F->nbr; a.meta = F->meta;
@@ -619,11 +950,26 @@ static FusedArgs fused_args(hfx_eles *e)
 template <int ND, int N>
 static int launch_stage(hfx_eles *e, FusedArgs &a, bool do_grad, bool do_res)
 {
-  constexpr int NU = ipow(N, ND), NFP = 2 * ND * ipow(N, ND - 1);
-  constexpr int TB = ((NU > NFP ? NU : NFP) + 63) / 64 * 64;
   const int grid = e->fused->grid;
-  if (do_grad) hipLaunchKernelGGL((fused_gradient_kernel<ND, N>), dim3(grid), dim3(TB), 0, e->ctx->stream, a);
-  if (do_res) hipLaunchKernelGGL((fused_residual_kernel<ND, N>), dim3(grid), dim3(TB), 0, e->ctx->stream, a);
+  FusedData *F = e->fused;
+  if (do_grad)
+  {
+    a.pk = F->pk_g;
+    a.tab = F->tab_g;
+    hipLaunchKernelGGL((fused_gradient_kernel<ND, N>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
+  }
+  if (do_res)
+  {
+    a.pk = F->pk_r;
+    a.tab = F->tab_r;
+    const int rs = a.P.riemann;
+    if (rs == 0)
+      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 0>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
+    else if (rs == 2)
+      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 2>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
+    else
+      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 3>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
+  }
   HFX_HIP(hipGetLastError());
   return 0;
 }
@@ -665,6 +1011,7 @@ static int fused_stage(hfx_eles *e, int in_step, bool last_stage, int which = 0)
   a.in_step = in_step;
   a.rk_a = (p.adv_type >= 3) ? p.RK_a[in_step] : 0.0;
   a.rk_b = (p.adv_type >= 3) ? p.RK_b[in_step] : 0.0;
+  a.need_u1 = (p.adv_type >= 3) || (p.adv_type == 1 && in_step == 3) || (p.adv_type == 2 && in_step == 2);
   a.write_div = last_stage ? 1 : 0; // the monitors read the divergence of a step's last stage
   const bool do_grad = p.viscous && which != 2, do_res = which != 1;
   if (dispatch_stage(e, a, do_grad, do_res)) return 1;

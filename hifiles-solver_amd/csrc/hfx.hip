@@ -74,6 +74,8 @@ static int make_operator(Operator &op, const double *host, int m, int k)
   HFX_HIP(hipMalloc((void **)&op.ell_idx, sizeof(int) * idx.size()));
   HFX_HIP(hipMemcpy(op.ell_val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
   HFX_HIP(hipMemcpy(op.ell_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+  op.h_val = val;
+  op.h_idx = idx;
   return 0;
 }
 

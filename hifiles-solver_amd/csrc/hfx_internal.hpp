@@ -51,6 +51,8 @@ struct Operator
   double *ell_val = nullptr;
   int *ell_idx = nullptr;
   long nnz_total = 0;
+  std::vector<double> h_val; // host copy of the ELL arrays (width max(nnz_max,1), row-interleaved)
+  std::vector<int> h_idx;
   bool present() const { return dense != nullptr; }
 };
 

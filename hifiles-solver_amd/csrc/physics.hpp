@@ -21,17 +21,25 @@ struct Phys
 };
 
 // f(k,m) = f[k + NF*m]
-template <int ND>
+// FAST (fused path only): divisions by the density become multiplications by its reciprocal
+// (one v_rcp + Newton step instead of ND full IEEE divisions) -- a <= 1 ulp change per quotient.
+template <int ND, bool FAST = false>
 __device__ __forceinline__ void calc_invf(const double gamma, const double (&u)[ND + 2], double (&f)[(ND + 2) * ND])
 {
   constexpr int NF = ND + 2;
-  const double rrho = u[0];
+  const double rho = u[0];
   double v[ND];
   double vsq = 0.0;
-#pragma unroll
-  for (int d = 0; d < ND; d++)
+  if (FAST)
   {
-    v[d] = u[d + 1] / rrho;
+    const double ir = 1.0 / rho;
+#pragma unroll
+    for (int d = 0; d < ND; d++) v[d] = u[d + 1] * ir;
+  }
+  else
+  {
+#pragma unroll
+    for (int d = 0; d < ND; d++) v[d] = u[d + 1] / rho;
   }
   // ((vx*vx)+(vy*vy))+(vz*vz), the reference's association (flux.cpp:43,87)
   vsq = v[0] * v[0] + v[1] * v[1];
@@ -52,36 +60,47 @@ __device__ __forceinline__ void calc_invf(const double gamma, const double (&u)[
 }
 
 // viscosity law shared by flux and time-step code (flux.cpp:319-321)
+template <bool FAST = false>
 __device__ __forceinline__ double viscosity(const Phys &P, const double inte)
 {
+  // fix_vis == 1: mu + 1*(mu_inf - mu) is mu_inf up to one rounding; the fused path skips the
+  // Sutherland evaluation (sqrt + 2 divisions) altogether in that case
+  if (FAST && P.fix_vis == 1.0) return P.mu_inf;
   const double rt_ratio = (P.gamma - 1.0) * inte / P.rt_inf;
-  double mu = P.mu_inf * pow(rt_ratio, 1.5) * (1.0 + P.c_sth) / (rt_ratio + P.c_sth);
+  // rt_ratio^1.5 as x*sqrt(x): within 1 ulp of the reference's pow(x,1.5) at a fraction of its
+  // instruction and register cost (the library pow expands to ~100 instructions per call)
+  double mu = P.mu_inf * (rt_ratio * sqrt(rt_ratio)) * (1.0 + P.c_sth) / (rt_ratio + P.c_sth);
   mu = mu + P.fix_vis * (P.mu_inf - mu);
   return mu;
 }
 
 // grad_u(k,m) = g[k + NF*m]; RANS off (mu_t = 0)
-template <int ND>
+template <int ND, bool FAST = false>
 __device__ __forceinline__ void calc_visf(const Phys &P, const double (&u)[ND + 2], const double (&g)[(ND + 2) * ND],
                                           double (&f)[(ND + 2) * ND])
 {
   constexpr int NF = ND + 2;
   const double rho = u[0];
+  const double ir = FAST ? 1.0 / rho : 0.0;
   double v[ND];
   double ke2 = 0.0; // u*u+v*v+w*w
 #pragma unroll
-  for (int d = 0; d < ND; d++) v[d] = u[d + 1] / rho;
+  for (int d = 0; d < ND; d++) v[d] = FAST ? u[d + 1] * ir : u[d + 1] / rho;
   ke2 = v[0] * v[0] + v[1] * v[1];
   if (ND == 3) ke2 = ke2 + v[ND - 1] * v[ND - 1];
-  const double inte = u[ND + 1] / rho - 0.5 * ke2;
-  const double mu = viscosity(P, inte);
+  const double inte = (FAST ? u[ND + 1] * ir : u[ND + 1] / rho) - 0.5 * ke2;
+  const double mu = viscosity<FAST>(P, inte);
 
   // velocity gradients dv[d][m] = d v_d / d x_m
   double dv[ND][ND];
 #pragma unroll
   for (int d = 0; d < ND; d++)
 #pragma unroll
-    for (int m = 0; m < ND; m++) dv[d][m] = (g[(d + 1) + NF * m] - g[0 + NF * m] * v[d]) / rho;
+    for (int m = 0; m < ND; m++)
+    {
+      const double num = g[(d + 1) + NF * m] - g[0 + NF * m] * v[d];
+      dv[d][m] = FAST ? num * ir : num / rho;
+    }
 
   double de[ND];
 #pragma unroll
@@ -90,12 +109,13 @@ __device__ __forceinline__ void calc_visf(const Phys &P, const double (&u)[ND + 
     double conv = v[0] * dv[0][m] + v[1] * dv[1][m];
     if (ND == 3) conv = conv + v[ND - 1] * dv[ND - 1][m];
     const double dke = 0.5 * ke2 * g[0 + NF * m] + rho * conv;
-    de[m] = (g[(ND + 1) + NF * m] - dke - g[0 + NF * m] * inte) / rho;
+    const double num = g[(ND + 1) + NF * m] - dke - g[0 + NF * m] * inte;
+    de[m] = FAST ? num * ir : num / rho;
   }
 
   double divv = dv[0][0] + dv[1][1];
   if (ND == 3) divv = divv + dv[ND - 1][ND - 1];
-  const double diag = divv / 3.0;
+  const double diag = FAST ? divv * (1.0 / 3.0) : divv / 3.0;
 
   double tau[ND][ND];
 #pragma unroll
@@ -138,44 +158,45 @@ struct Side
   double v[ND], vn, vsq, p, h;
 };
 
-template <int ND>
+template <int ND, bool FAST = false>
 __device__ __forceinline__ Side<ND> side_state(const double gamma, const double (&u)[ND + 2], const double (&n)[ND])
 {
   Side<ND> s;
   s.vn = 0.0;
   s.vsq = 0.0;
+  const double ir = FAST ? 1.0 / u[0] : 0.0;
 #pragma unroll
   for (int i = 0; i < ND; i++)
   {
-    s.v[i] = u[i + 1] / u[0];
+    s.v[i] = FAST ? u[i + 1] * ir : u[i + 1] / u[0];
     s.vn += s.v[i] * n[i];
     s.vsq += s.v[i] * s.v[i];
   }
   s.p = (gamma - 1.0) * (u[ND + 1] - 0.5 * u[0] * s.vsq);
-  s.h = (u[ND + 1] + s.p) / u[0];
+  s.h = FAST ? (u[ND + 1] + s.p) * ir : (u[ND + 1] + s.p) / u[0];
   return s;
 }
 
 // inters.cpp:277-324
-template <int ND>
+template <int ND, bool FAST = false>
 __device__ __forceinline__ void rusanov_flux(const double gamma, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
                                              const double (&fnl)[ND + 2], const double (&fnr)[ND + 2],
                                              const double (&n)[ND], double (&fn)[ND + 2])
 {
-  const Side<ND> L = side_state<ND>(gamma, ul, n), R = side_state<ND>(gamma, ur, n);
+  const Side<ND> L = side_state<ND, FAST>(gamma, ul, n), R = side_state<ND, FAST>(gamma, ur, n);
   const double eig = sqrt(gamma * (L.p + R.p) / (ul[0] + ur[0])) + 0.5 * fabs(L.vn + R.vn);
 #pragma unroll
   for (int k = 0; k < ND + 2; k++) fn[k] = 0.5 * ((fnl[k] + fnr[k]) - eig * (ur[k] - ul[k]));
 }
 
 // inters.cpp:327-437
-template <int ND>
+template <int ND, bool FAST = false>
 __device__ __forceinline__ void roeM_flux(const double gamma, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
                                           const double (&fnl)[ND + 2], const double (&fnr)[ND + 2],
                                           const double (&n)[ND], double (&fn)[ND + 2])
 {
   constexpr int NF = ND + 2;
-  const Side<ND> L = side_state<ND>(gamma, ul, n), R = side_state<ND>(gamma, ur, n);
+  const Side<ND> L = side_state<ND, FAST>(gamma, ul, n), R = side_state<ND, FAST>(gamma, ur, n);
   const double drho = ur[0] - ul[0], dp = R.p - L.p, dh = R.h - L.h, dvn = R.vn - L.vn;
   const double sq_rho = sqrt(ur[0] / ul[0]);
   const double rrho = 1.0 / (1.0 + sq_rho);
@@ -216,12 +237,12 @@ __device__ __forceinline__ void roeM_flux(const double gamma, const double (&ul)
 }
 
 // inters.cpp:439-532.  NOTE a_m uses the NORMAL Roe velocity only (inters.cpp:497) -- kept as is.
-template <int ND>
+template <int ND, bool FAST = false>
 __device__ __forceinline__ void hllc_flux(const double gamma, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
                                           const double (&fnl)[ND + 2], const double (&fnr)[ND + 2],
                                           const double (&n)[ND], double (&fn)[ND + 2])
 {
-  const Side<ND> L = side_state<ND>(gamma, ul, n), R = side_state<ND>(gamma, ur, n);
+  const Side<ND> L = side_state<ND, FAST>(gamma, ul, n), R = side_state<ND, FAST>(gamma, ur, n);
   const double sq_rho = sqrt(ur[0] / ul[0]);
   const double rrho = 1.0 / (sq_rho + 1.0);
   const double vn_m = rrho * (L.vn + sq_rho * R.vn);
@@ -240,19 +261,41 @@ __device__ __forceinline__ void hllc_flux(const double gamma, const double (&ul)
   {
     const double rcp_star = S_L - S_star;
     const double pst = S_L * (L.p + ul[0] * (S_L - L.vn) * (S_star - L.vn));
-    fn[0] = S_star * (S_L * ul[0] - fnl[0]) / rcp_star;
+    if (FAST)
+    {
+      const double is = 1.0 / rcp_star;
+      fn[0] = S_star * (S_L * ul[0] - fnl[0]) * is;
 #pragma unroll
-    for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_L * ul[i + 1] - fnl[i + 1]) + pst * n[i]) / rcp_star;
-    fn[ND + 1] = (S_star * (S_L * ul[ND + 1] - fnl[ND + 1]) + pst * S_star) / rcp_star;
+      for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_L * ul[i + 1] - fnl[i + 1]) + pst * n[i]) * is;
+      fn[ND + 1] = (S_star * (S_L * ul[ND + 1] - fnl[ND + 1]) + pst * S_star) * is;
+    }
+    else
+    {
+      fn[0] = S_star * (S_L * ul[0] - fnl[0]) / rcp_star;
+#pragma unroll
+      for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_L * ul[i + 1] - fnl[i + 1]) + pst * n[i]) / rcp_star;
+      fn[ND + 1] = (S_star * (S_L * ul[ND + 1] - fnl[ND + 1]) + pst * S_star) / rcp_star;
+    }
   }
   else if (S_R >= 0)
   {
     const double rcp_star = S_R - S_star;
     const double pst = S_R * (R.p + ur[0] * (S_R - R.vn) * (S_star - R.vn));
-    fn[0] = S_star * (S_R * ur[0] - fnr[0]) / rcp_star;
+    if (FAST)
+    {
+      const double is = 1.0 / rcp_star;
+      fn[0] = S_star * (S_R * ur[0] - fnr[0]) * is;
 #pragma unroll
-    for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_R * ur[i + 1] - fnr[i + 1]) + pst * n[i]) / rcp_star;
-    fn[ND + 1] = (S_star * (S_R * ur[ND + 1] - fnr[ND + 1]) + pst * S_star) / rcp_star;
+      for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_R * ur[i + 1] - fnr[i + 1]) + pst * n[i]) * is;
+      fn[ND + 1] = (S_star * (S_R * ur[ND + 1] - fnr[ND + 1]) + pst * S_star) * is;
+    }
+    else
+    {
+      fn[0] = S_star * (S_R * ur[0] - fnr[0]) / rcp_star;
+#pragma unroll
+      for (int i = 0; i < ND; i++) fn[i + 1] = (S_star * (S_R * ur[i + 1] - fnr[i + 1]) + pst * n[i]) / rcp_star;
+      fn[ND + 1] = (S_star * (S_R * ur[ND + 1] - fnr[ND + 1]) + pst * S_star) / rcp_star;
+    }
   }
   else
   {
@@ -278,6 +321,32 @@ __device__ __forceinline__ void riemann_flux(const Phys &P, const double (&ul)[N
     roeM_flux<ND>(P.gamma, ul, ur, fnl, fnr, n, fn);
   else
     hllc_flux<ND>(P.gamma, ul, ur, fnl, fnr, n, fn);
+}
+
+// the same with the solver fixed at compile time (RS = riemann_solve_type): only one solver's
+// code and registers end up in the kernel
+template <int ND, int RS, bool FAST = false>
+__device__ __forceinline__ void riemann_flux_t(const Phys &P, const double (&ul)[ND + 2], const double (&ur)[ND + 2],
+                                               const double (&n)[ND], double (&fn)[ND + 2])
+{
+  constexpr int NF = ND + 2;
+  double fnl[NF], fnr[NF];
+  {
+    double fq[NF * ND];
+    calc_invf<ND, FAST>(P.gamma, ul, fq);
+    normal_flux<ND>(fq, n, fnl);
+  }
+  {
+    double fq[NF * ND];
+    calc_invf<ND, FAST>(P.gamma, ur, fq);
+    normal_flux<ND>(fq, n, fnr);
+  }
+  if (RS == 0)
+    rusanov_flux<ND, FAST>(P.gamma, ul, ur, fnl, fnr, n, fn);
+  else if (RS == 2)
+    roeM_flux<ND, FAST>(P.gamma, ul, ur, fnl, fnr, n, fn);
+  else
+    hllc_flux<ND, FAST>(P.gamma, ul, ur, fnl, fnr, n, fn);
 }
 
 // the "consistent switch" (inters.cpp:568-581, :620-633): exact floating-point

@@ -1,0 +1,11 @@
+#!/bin/bash
+# occupancy sweep of the fused kernels (rebuilds libhfx.so on the GPU box)
+cd $GRAFT_REPO_ROOT/hifiles-solver_amd
+for W in 2 3 4; do
+  rm -f libhfx.so
+  make HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DHFX_FUSED_WAVES=$W" libhfx.so > /dev/null 2>&1
+  for G in 2 4 8; do
+    echo "== waves/SIMD $W grid/CU $G"
+    HFX_FUSED_GRID_PER_CU=$G python ../bench.py --steps 6 --warmup 1 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_rk_stage'], d['roofline']['kernels_ms'])"
+  done
+done
