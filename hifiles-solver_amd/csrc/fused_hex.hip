@@ -48,6 +48,15 @@ constexpr int MAX_TAB = 256;
 #ifndef HFX_FUSED_WAVES
 #define HFX_FUSED_WAVES 2
 #endif
+// Diagnostic ablation mask (0 in the product build): bit0 A-role Riemann, bit1 B-role viscous
+// fluxes, bit2 U-role fluxes, bit3 operator dot products, bit4 partner gathers are replaced by
+// trivial stand-ins so that their share of a kernel's time can be measured (results are wrong).
+#ifndef HFX_ABLATE
+#define HFX_ABLATE 0
+#endif
+#ifndef HFX_FUSED_WAVES_RES
+#define HFX_FUSED_WAVES_RES 2
+#endif
 
 struct FusedData
 {
@@ -112,7 +121,8 @@ struct Geo
   static constexpr int WU = (NU + 63) / 64;  // solution-point waves
   static constexpr int WF = (NFP + 63) / 64; // flux-point waves
   static constexpr int TU = 64 * WU;
-  static constexpr int TB = 64 * (WU + WF);
+  static constexpr int TB = 64 * (WU + WF);       // gradient kernel: roles U, F
+  static constexpr int TBR = 64 * (WU + 2 * WF);  // residual kernel: roles U, A, B
   static constexpr int UNP = (NF * NU + TU - 1) / TU; // doubles of the next element's state per upt thread
   static constexpr int WN = words_of(N);
   // packed-row layout, gradient kernel: opp_4[d] | opp_5[d] (rows = upts) | opp_0 | opp_6 (rows = fpts)
@@ -138,6 +148,7 @@ struct Geo
 template <int W, int OFF, int PW>
 __device__ __forceinline__ double row_dot(const unsigned (&w)[PW], const double *tab, const double *data, double acc)
 {
+  if (HFX_ABLATE & 8) return acc + tab[w[OFF] & 0xffu] * data[0];
 #pragma unroll
   for (int i = 0; i < words_of(W); i++)
   {
@@ -157,6 +168,14 @@ __device__ __forceinline__ double row_dot(const unsigned (&w)[PW], const double 
     }
   }
   return acc;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// GLOBAL load and store of the wave (s_waitcnt vmcnt(0)); the roles exchange data through LDS
+// only, so waiting for the LDS counter is sufficient and result stores / prefetches stay in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // g_phys(d) = sum_l (inv_detjac * g_ref(l)) * JGinv(l,d)   (BLAS=NO branch of src/eles.cpp:1975-1979)
@@ -306,7 +325,7 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_gradi
         sd[k][tf] = uc - own;
       }
     }
-    __syncthreads(); // B: sd ready
+    lds_barrier(); // B: sd ready
 
     // ---------------- P2
     long nb_next = 0;
@@ -349,7 +368,7 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_gradi
       nb_next = a.nbr[tf + NFP * en];
       mt_next = a.meta[tf + NFP * en];
     }
-    __syncthreads(); // C: sg ready, su[buf^1] ready
+    lds_barrier(); // C: sg ready, su[buf^1] ready
 
     // ---------------- P3
     if (!role_u && act)
@@ -375,37 +394,45 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_gradi
 
 // ---------------------------------------------------------------------------------------
 // residual kernel
+//
+// Three roles: U (one thread per solution point), A and B (one thread per flux point each).
+// The flux-point physics is the long pole of a stage (Riemann flux + two viscous fluxes per
+// point), so it is split: A evaluates the inviscid common flux, B the LDG viscous common flux,
+// and U the volume fluxes -- three instruction streams of similar length that run concurrently
+// on the CU's four SIMDs.
 // ---------------------------------------------------------------------------------------
 template <int ND, int N, int RS>
-__global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_residual_kernel(const FusedArgs a)
+__global__ __launch_bounds__((Geo<ND, N>::TBR), HFX_FUSED_WAVES_RES) void fused_residual_kernel(const FusedArgs a)
 {
   using G = Geo<ND, N>;
   constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TU = G::TU, UNP = G::UNP, WN = G::WN;
+  constexpr int TF = 64 * G::WF;
   constexpr int N3 = 2 * ND;
   constexpr int PW = cmax(G::R_WU, G::R_WF);
   __shared__ double tab[MAX_TAB];
   __shared__ double su[2][NF][NU];
   __shared__ double st[NF * ND][NU];
   __shared__ double sc[NF][NFP];
+  __shared__ double sv[NF][NFP];
   const int tid = threadIdx.x;
-  const bool role_u = tid < TU;
-  const int tu = tid, tf = tid - TU;
-  const bool act = role_u ? (tu < NU) : (tf < NFP);
+  const int role = tid < TU ? 0 : (tid < TU + TF ? 1 : 2); // 0 U, 1 A, 2 B
+  const int tu = tid, tf = (role == 1) ? tid - TU : tid - TU - TF;
+  const bool act = (role == 0) ? (tu < NU) : (tf < NFP);
   const long ne = a.n_eles;
   const long plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
   const long stride = gridDim.x;
   const bool viscous = a.P.viscous;
 
-  for (int q = tid; q < MAX_TAB; q += G::TB) tab[q] = a.tab[q];
+  for (int q = tid; q < MAX_TAB; q += G::TBR) tab[q] = a.tab[q];
 
-  // upt [opp_2[0..ND) | opp_3], fpt [opp_0 | merged opp_1]
+  // U [opp_2[0..ND) | opp_3], A [opp_0 | merged opp_1], B [opp_0]
   unsigned pw[PW];
 #pragma unroll
   for (int i = 0; i < PW; i++) pw[i] = 0;
   int d1 = 0;
   if (act)
   {
-    if (role_u)
+    if (role == 0)
     {
 #pragma unroll
       for (int i = 0; i < ND * WN; i++) pw[i] = a.pk[G::R_O2 + i * NU + tu];
@@ -429,7 +456,7 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
   unsigned mt = 0;
   if (e < ne)
   {
-    if (role_u)
+    if (role == 0)
     {
       for (int q = tu; q < NF * NU; q += TU)
       {
@@ -452,9 +479,9 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
     const bool has_next = en < ne;
     double un[UNP];
     double div[NF], u1v[NF], dj = 1.0;
-    double tconf[NF];
+    double finv[NF], sgn_tdA = 0.0;
     // ---------------- P1
-    if (role_u)
+    if (role == 0)
     {
       if (has_next)
       {
@@ -483,7 +510,13 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
         }
 #pragma unroll
         for (int k = 0; k < NF; k++) u[k] = su[buf][k][tu];
-        calc_invf<ND, true>(a.P.gamma, u, f);
+        if (HFX_ABLATE & 4)
+        {
+#pragma unroll
+          for (int s = 0; s < NF * ND; s++) f[s] = u[s % NF] * a.P.gamma;
+        }
+        else
+          calc_invf<ND, true>(a.P.gamma, u, f);
         if (!viscous)
         {
 #pragma unroll
@@ -514,7 +547,13 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
             double gr[NF * ND];
 #pragma unroll
             for (int q = 0; q < NF * ND; q++) gr[q] = a.grad_upts[p + q * plane_u];
-            calc_visf<ND, true>(a.P, u, gr, f);
+            if (HFX_ABLATE & 4)
+            {
+#pragma unroll
+              for (int s = 0; s < NF * ND; s++) f[s] = gr[s] * u[0];
+            }
+            else
+              calc_visf<ND, true>(a.P, u, gr, f);
           }
 #pragma unroll
           for (int k = 0; k < NF; k++)
@@ -533,40 +572,64 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
     {
       const long o = tf + NFP * e;
       const bool right = mt & 1;
-      const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
-      double own[NF], oth[NF], n[ND], fn[NF];
+      double oth[NF], n[ND];
 #pragma unroll
-      for (int k = 0; k < NF; k++) oth[k] = a.disu_cur[nb + k * plane_f];
+      for (int k = 0; k < NF; k++) oth[k] = (HFX_ABLATE & 16) ? su[buf][k][tf % NU] : a.disu_cur[nb + k * plane_f];
 #pragma unroll
       for (int m = 0; m < ND; m++) n[m] = a.fnorm[o + m * plane_f];
-      const double tdA = a.tdA_fpts[o];
-#pragma unroll
-      for (int k = 0; k < NF; k++) own[k] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
-      const double sgn_tdA = right ? -tdA : tdA;
-      double ul[NF], ur[NF];
-#pragma unroll
-      for (int k = 0; k < NF; k++)
+      if (role == 1)
       {
-        ul[k] = right ? oth[k] : own[k];
-        ur[k] = right ? own[k] : oth[k];
+        // ---- A: inviscid common flux (src/int_inters.cpp:160-249)
+        const double tdA = a.tdA_fpts[o];
+        sgn_tdA = right ? -tdA : tdA;
+        double ul[NF], ur[NF];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          const double own = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+          ul[k] = right ? oth[k] : own;
+          ur[k] = right ? own : oth[k];
+        }
+        if (HFX_ABLATE & 1)
+        {
+#pragma unroll
+          for (int k = 0; k < NF; k++) finv[k] = (ul[k] - ur[k]) * n[0];
+        }
+        else
+          riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, finv);
       }
-      riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
-#pragma unroll
-      for (int k = 0; k < NF; k++) tconf[k] = fn[k] * sgn_tdA;
-      if (viscous)
+      else if (viscous)
       {
+        // ---- B: LDG viscous common flux (src/int_inters.cpp:254-343, src/inters.cpp:561-611)
         // the left state's gradient lives on this point when it is the LEFT side, on the partner otherwise
         const long ol = right ? nb : o, orr = right ? o : nb;
-        // fn_v = sum_l [(1/2+beta) F_l + (1/2-beta) F_r](k,l) n_l - tau (u_r - u_l)   (src/inters.cpp:583-611).
-        // The left contribution is projected on the normal before the right flux is evaluated, so
-        // that only NF (not NF*ND) values stay live across the second flux evaluation; this
-        // re-associates the sum over the two sides (a rounding-level change).
+        const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+        double gq[NF * ND];
+#pragma unroll
+        for (int s = 0; s < NF * ND; s++) gq[s] = (HFX_ABLATE & 16) ? su[buf][s % NF][tf % NU] : a.grad_fpts[ol + s * plane_f];
+        double ul[NF], ur[NF];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          const double own = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+          ul[k] = right ? oth[k] : own;
+          ur[k] = right ? own : oth[k];
+        }
+        // fn_v = sum_l [(1/2+beta) F_l + (1/2-beta) F_r](k,l) n_l - tau (u_r - u_l).  The left
+        // contribution is projected on the normal before the right flux is evaluated, so that only
+        // NF values stay live across the second evaluation (re-associates the two-side sum).
         double pl[NF];
         {
-          double gq[NF * ND], fq[NF * ND];
+          double fq[NF * ND];
+          if (HFX_ABLATE & 2)
+          {
 #pragma unroll
-          for (int s = 0; s < NF * ND; s++) gq[s] = a.grad_fpts[ol + s * plane_f];
-          calc_visf<ND, true>(a.P, ul, gq, fq);
+            for (int s = 0; s < NF * ND; s++) fq[s] = gq[s] * ul[0];
+          }
+          else
+            calc_visf<ND, true>(a.P, ul, gq, fq);
+#pragma unroll
+          for (int s = 0; s < NF * ND; s++) gq[s] = (HFX_ABLATE & 16) ? st[s][tf % NU] : a.grad_fpts[orr + s * plane_f];
 #pragma unroll
           for (int k = 0; k < NF; k++)
           {
@@ -577,10 +640,14 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
           }
         }
         {
-          double gq[NF * ND], fq[NF * ND];
+          double fq[NF * ND];
+          if (HFX_ABLATE & 2)
+          {
 #pragma unroll
-          for (int s = 0; s < NF * ND; s++) gq[s] = a.grad_fpts[orr + s * plane_f];
-          calc_visf<ND, true>(a.P, ur, gq, fq);
+            for (int s = 0; s < NF * ND; s++) fq[s] = gq[s] * ur[0];
+          }
+          else
+            calc_visf<ND, true>(a.P, ur, gq, fq);
 #pragma unroll
           for (int k = 0; k < NF; k++)
           {
@@ -589,15 +656,17 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
             for (int l = 0; l < ND; l++) s += ((0.5 - beta) * fq[k + NF * l]) * n[l];
             double fv = pl[k] + s;
             fv -= a.P.ldg_tau * (ur[k] - ul[k]);
-            tconf[k] += fv * sgn_tdA;
+            sv[k][tf] = fv;
           }
         }
       }
     }
-    __syncthreads(); // B: st ready
+    lds_barrier(); // B: st, sv ready
 
     // ---------------- P2
-    if (role_u)
+    long nb_next = 0;
+    unsigned mt_next = 0;
+    if (role == 0)
     {
       if (act)
       {
@@ -624,21 +693,29 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
         }
       }
     }
-    else if (act)
+    else if (role == 1)
     {
-#pragma unroll
-      for (int k = 0; k < NF; k++)
+      if (act)
       {
-        const double ntd = row_dot<N, WN, PW>(pw, tab, &st[k + NF * d1][0], 0.0);
-        sc[k][tf] = tconf[k] + -1.0 * ntd; // norm_tconf -= norm_tdisf (src/eles.cpp:1746)
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          const double ntd = row_dot<N, WN, PW>(pw, tab, &st[k + NF * d1][0], 0.0);
+          double tconf = finv[k] * sgn_tdA;                // norm_tconf  = fn * tdA      (int_inters.cpp:217)
+          if (viscous) tconf += sv[k][tf] * sgn_tdA;       // norm_tconf += fn_v * tdA    (int_inters.cpp:329)
+          sc[k][tf] = tconf + -1.0 * ntd;                  // norm_tconf -= norm_tdisf    (eles.cpp:1746)
+        }
       }
     }
-    __syncthreads(); // C: sc ready, su[buf^1] ready
+    else if (act && has_next)
+    {
+      nb_next = a.nbr[tf + NFP * en];
+      mt_next = a.meta[tf + NFP * en];
+    }
+    lds_barrier(); // C: sc ready, su[buf^1] ready
 
     // ---------------- P3
-    long nb_next = 0;
-    unsigned mt_next = 0;
-    if (role_u)
+    if (role == 0)
     {
       if (act)
       {
@@ -686,23 +763,33 @@ __global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_resid
             u += a.rk_b * r1;
           }
           a.u0[q] = u;
-          su[buf][k][tu] = u; // own point only; the fpt waves read it after barrier D
+          su[buf][k][tu] = u; // own point only; the flux-point waves read it after barrier D
         }
       }
     }
-    else if (act && has_next)
+    else if (role == 1 && act && has_next)
     {
       nb_next = a.nbr[tf + NFP * en];
       mt_next = a.meta[tf + NFP * en];
     }
-    __syncthreads(); // D: su[buf] holds the new state
+    lds_barrier(); // D: su[buf] holds the new state
 
-    // ---------------- P4: disu_fpts of the NEW state into the other buffer (partners still read the old one)
-    if (!role_u && act)
+    // ---------------- P4: disu_fpts of the NEW state into the other buffer (partners still read the
+    // old one); A and B share the fields
+    if (role != 0 && act)
     {
       const long o = tf + NFP * e;
+      constexpr int KH = (NF + 1) / 2;
+      if (role == 1)
+      {
 #pragma unroll
-      for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+        for (int k = 0; k < KH; k++) a.disu_next[o + k * plane_f] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+      }
+      else
+      {
+#pragma unroll
+        for (int k = KH; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
+      }
       nb = nb_next;
       mt = mt_next;
     }
@@ -964,11 +1051,11 @@ static int launch_stage(hfx_eles *e, FusedArgs &a, bool do_grad, bool do_res)
     a.tab = F->tab_r;
     const int rs = a.P.riemann;
     if (rs == 0)
-      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 0>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
+      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 0>), dim3(grid), dim3(Geo<ND, N>::TBR), 0, e->ctx->stream, a);
     else if (rs == 2)
-      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 2>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
+      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 2>), dim3(grid), dim3(Geo<ND, N>::TBR), 0, e->ctx->stream, a);
     else
-      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 3>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
+      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 3>), dim3(grid), dim3(Geo<ND, N>::TBR), 0, e->ctx->stream, a);
   }
   HFX_HIP(hipGetLastError());
   return 0;
