@@ -187,8 +187,16 @@ def main():
             hfx.check(lib.hfx_fused_kernel_bytes(e, share))
             bytes_launch = share[kn.index(dom)]
             achieved = bytes_launch / (times[dom] * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in separate
+            # rocprofv3 runs by tools/profile_round.sh and committed under profiles/); only valid for the
+            # workload it was measured on
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_fused_traffic.json")
+            if os.path.exists(tfile) and args.n == 32 and args.order == 4:
+                traffic = json.load(open(tfile)).get(dom, {}).get("traffic_bytes_corrected")
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, kernel_ms=times[dom],
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, algorithmic_bytes=bytes_launch,
+                        kernel_ms=times[dom],
                         kernels_ms=times, stage_algorithmic_bytes_per_element=per_ele,
                         stage_hbm_frac=per_ele * case.n_eles / (ms_per_stage * 1e-3) / 1e9 / HBM_PEAK_GBS)
         else:
