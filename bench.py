@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "hifiles-solver_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+DEFAULT_FUSED = "split"   # which fused variant `--mode auto` runs
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak
 
@@ -98,7 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=32, help="cells per direction per GPU")
     ap.add_argument("--order", type=int, default=4)
-    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "methods", "dense"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "split", "methods", "dense"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -126,15 +127,18 @@ def main():
 
     mode = args.mode
     fused_ok = False
-    if mode in ("auto", "fused"):
+    if mode in ("auto", "fused", "split"):
         rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(1))
         fused_ok = (rc == 0)
-        if mode == "fused" and not fused_ok:
+        if mode != "auto" and not fused_ok:
             raise SystemExit("fused path unavailable: " + lib.hfx_last_error().decode())
-        mode = "fused" if fused_ok else "methods"
+        if mode == "auto":
+            mode = DEFAULT_FUSED if fused_ok else "methods"
     if mode == "dense":
         hfx.check(lib.hfx_ctx_set_contract_mode(ctx, C.c_int(hfx.CONTRACT_DENSE)))
-    fused = 1 if mode == "fused" else 0
+    fused = 1 if mode == "fused" else (2 if mode == "split" else 0)
+    if fused:
+        hfx.check(lib.hfx_ctx_set_fused_mode(ctx, C.c_int(fused)))
 
     def barrier():
         if dist is not None:

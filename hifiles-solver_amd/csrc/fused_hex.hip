@@ -51,6 +51,9 @@ constexpr int MAX_TAB = 256;
 // Diagnostic ablation mask (0 in the product build): bit0 A-role Riemann, bit1 B-role viscous
 // fluxes, bit2 U-role fluxes, bit3 operator dot products, bit4 partner gathers are replaced by
 // trivial stand-ins so that their share of a kernel's time can be measured (results are wrong).
+#ifndef HFX_SPLIT_WAVES_RES
+#define HFX_SPLIT_WAVES_RES 4
+#endif
 #ifndef HFX_ABLATE
 #define HFX_ABLATE 0
 #endif
@@ -1173,6 +1176,551 @@ void fused_kernel_bytes(const hfx_eles *e, double *bytes)
   for (int i = 0; i < 8; i++) bytes[i] = 0.0;
   bytes[0] = 8.0 * grad * ne;
   bytes[1] = 8.0 * res * ne;
+}
+
+
+// =======================================================================================
+// SPLIT fused path (mode 2): four launches per stage, every one a simple high-occupancy kernel
+//
+//   face_delta_kernel    (thread per flux-point pair) LDG common solution -> delta_disu_fpts L,R
+//   split_gradient_kernel(workgroup per element)      u, delta -> grad_disu_upts, grad_disu_fpts
+//   face_flux_kernel     (thread per pair)            Riemann + LDG viscous flux -> norm_tconf_fpts L,R
+//   split_residual_kernel(workgroup per element)      u, grad, norm_tconf -> RK update, new disu_fpts
+//
+// Same HBM traffic as the gather-style pair (~21 000 doubles per P4 hex and stage) because the
+// pairwise face kernels read every flux-point datum once instead of twice, and every element
+// kernel is a thread-per-point kernel small enough to keep 3-4 workgroups resident per CU.
+// =======================================================================================
+
+struct SplitFaceArgs
+{
+  long npairs;
+  const int *L, *R;
+  const unsigned char *meta; // bit1 of the LEFT point: beta sign flipped
+  long plane_f;
+  const double *disu, *grad, *fnorm, *tdA;
+  double *delta, *tconf;
+  Phys P;
+};
+
+template <int ND>
+__global__ __launch_bounds__(256) void face_delta_kernel(const SplitFaceArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long il = a.L[q], ir = a.R[q];
+  const double beta = (a.meta[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    const double ul = a.disu[il + k * a.plane_f], ur = a.disu[ir + k * a.plane_f];
+    const double uc = 0.5 * (ul + ur) - beta * (ul - ur); // src/inters.cpp:637
+    a.delta[il + k * a.plane_f] = uc - ul;
+    a.delta[ir + k * a.plane_f] = uc - ur;
+  }
+}
+
+template <int ND, int RS>
+__global__ __launch_bounds__(256) void face_flux_kernel(const SplitFaceArgs a)
+{
+  constexpr int NF = ND + 2, NG = NF * ND;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long il = a.L[q], ir = a.R[q];
+  double ul[NF], ur[NF], n[ND], fn[NF];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu[il + k * a.plane_f];
+    ur[k] = a.disu[ir + k * a.plane_f];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.fnorm[il + m * a.plane_f];
+  const double tl = a.tdA[il], tr = a.tdA[ir];
+  riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
+  if (a.P.viscous)
+  {
+    const double beta = (a.meta[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+    double pl[NF];
+    {
+      double gq[NG], fq[NG];
+#pragma unroll
+      for (int s = 0; s < NG; s++) gq[s] = a.grad[il + s * a.plane_f];
+      calc_visf<ND, true>(a.P, ul, gq, fq);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < ND; l++) s += ((0.5 + beta) * fq[k + NF * l]) * n[l];
+        pl[k] = s;
+      }
+    }
+    {
+      double gq[NG], fq[NG];
+#pragma unroll
+      for (int s = 0; s < NG; s++) gq[s] = a.grad[ir + s * a.plane_f];
+      calc_visf<ND, true>(a.P, ur, gq, fq);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < ND; l++) s += ((0.5 - beta) * fq[k + NF * l]) * n[l];
+        double fv = pl[k] + s;
+        fv -= a.P.ldg_tau * (ur[k] - ul[k]);
+        // norm_tconf_l = fn*tdA_l + fv*tdA_l ; norm_tconf_r = -fn*tdA_r + -fv*tdA_r   (int_inters.cpp:217-220,329-332)
+        a.tconf[il + k * a.plane_f] = fn[k] * tl + fv * tl;
+        a.tconf[ir + k * a.plane_f] = -fn[k] * tr + -fv * tr;
+      }
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      a.tconf[il + k * a.plane_f] = fn[k] * tl;
+      a.tconf[ir + k * a.plane_f] = -fn[k] * tr;
+    }
+  }
+}
+
+struct SplitEleArgs
+{
+  int n_eles;
+  const unsigned *pk;
+  const double *tab;
+  const int *o1m_dim;
+  const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts;
+  double *u0, *u1;
+  const double *delta, *tconf;
+  double *disu_next;
+  double *grad_upts, *grad_fpts, *div_out;
+  const double *src, *dt_local;
+  unsigned long long *nan_flag;
+  Phys P;
+  int adv_type, in_step, dt_local_on, write_div, need_u1;
+  double dt, rk_a, rk_b;
+};
+
+template <int ND, int N>
+struct SGeo
+{
+  using G = Geo<ND, N>;
+  static constexpr int TB = 64 * (G::WU > G::WF ? G::WU : G::WF); // thread t: solution point t and flux point t
+};
+
+// ---- u, delta -> corrected gradient at solution points (physical) and flux points (physical)
+template <int ND, int N>
+__global__ __launch_bounds__((SGeo<ND, N>::TB)) void split_gradient_kernel(const SplitEleArgs a)
+{
+  using G = Geo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, WN = G::WN, TB = SGeo<ND, N>::TB;
+  constexpr int PW = G::G_WU + WN; // opp_4[d] | opp_5[d] | opp_6
+  __shared__ double tab[MAX_TAB];
+  __shared__ double su[NF][NU];
+  __shared__ double sd[NF][NFP];
+  __shared__ double sg[NF * ND][NU];
+  const int t = threadIdx.x;
+  const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
+  const bool is_u = t < NU, is_f = t < NFP;
+  const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
+  for (int q = t; q < MAX_TAB; q += TB) tab[q] = a.tab[q];
+  unsigned pw[PW];
+#pragma unroll
+  for (int d = 0; d < ND; d++)
+  {
+#pragma unroll
+    for (int i = 0; i < WN; i++) pw[d * WN + i] = a.pk[G::G_O4 + (d * WN + i) * NU + tu];
+    pw[ND * WN + d] = a.pk[G::G_O5 + d * NU + tu];
+  }
+#pragma unroll
+  for (int i = 0; i < WN; i++) pw[G::G_WU + i] = a.pk[G::G_O6 + i * NFP + tf];
+
+  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  {
+    for (int q = t; q < NF * NU; q += TB)
+    {
+      const int f = q / NU, p = q - f * NU;
+      su[f][p] = a.u0[p + NU * e + f * plane_u];
+    }
+    for (int q = t; q < NF * NFP; q += TB)
+    {
+      const int f = q / NFP, p = q - f * NFP;
+      sd[f][p] = a.delta[p + NFP * e + f * plane_f];
+    }
+    double JG[ND * ND];
+    double inv_detjac;
+    {
+      const long p = tu + NU * e;
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
+      inv_detjac = 1.0 / a.detjac_upts[p];
+    }
+    __syncthreads();
+    if (is_u)
+    {
+      const long p = tu + NU * e;
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double tg[ND], cg[ND];
+        tg[0] = row_dot<N, 0, PW>(pw, tab, &su[k][0], 0.0);
+        tg[1] = row_dot<N, WN, PW>(pw, tab, &su[k][0], 0.0);
+        if (ND == 3) tg[ND - 1] = row_dot<N, (ND - 1) * WN, PW>(pw, tab, &su[k][0], 0.0);
+        tg[0] = row_dot<2, ND * WN + 0, PW>(pw, tab, &sd[k][0], tg[0]);
+        tg[1] = row_dot<2, ND * WN + 1, PW>(pw, tab, &sd[k][0], tg[1]);
+        if (ND == 3) tg[ND - 1] = row_dot<2, ND * WN + ND - 1, PW>(pw, tab, &sd[k][0], tg[ND - 1]);
+#pragma unroll
+        for (int d = 0; d < ND; d++) sg[k + NF * d][tu] = tg[d];
+        to_physical<ND>(inv_detjac, JG, tg, cg);
+#pragma unroll
+        for (int d = 0; d < ND; d++) a.grad_upts[p + (k + NF * d) * plane_u] = cg[d];
+      }
+    }
+    {
+      const long o = tf + NFP * e;
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_fpts[o * (ND * ND) + q];
+      inv_detjac = 1.0 / a.detjac_fpts[o];
+    }
+    __syncthreads();
+    if (is_f)
+    {
+      const long o = tf + NFP * e;
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double tg[ND], cg[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) tg[d] = row_dot<N, G::G_WU, PW>(pw, tab, &sg[k + NF * d][0], 0.0);
+        to_physical<ND>(inv_detjac, JG, tg, cg);
+#pragma unroll
+        for (int d = 0; d < ND; d++) a.grad_fpts[o + (k + NF * d) * plane_f] = cg[d];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- u, grad, norm_tconf -> divergence, correction, RK update, disu_fpts of the new state.
+// Loads are placed right before their use: several workgroups are resident per CU and cover each
+// other's latency, and short live ranges keep the register count (= the occupancy) in check.
+template <int ND, int N>
+__global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT_WAVES_RES) void split_residual_kernel(const SplitEleArgs a)
+{
+  using G = Geo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, WN = G::WN, TB = SGeo<ND, N>::TB;
+  constexpr int N3 = 2 * ND, NG = NF * ND;
+  constexpr int PW = G::R_WU + G::R_WF; // opp_2[d] | opp_3 | opp_0 | merged opp_1
+  __shared__ double tab[MAX_TAB];
+  __shared__ double su[NF][NU];
+  __shared__ double st[NF * ND][NU];
+  __shared__ double sc[NF][NFP];
+  const int t = threadIdx.x;
+  const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
+  const bool is_u = t < NU, is_f = t < NFP;
+  const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
+  const bool viscous = a.P.viscous;
+  for (int q = t; q < MAX_TAB; q += TB) tab[q] = a.tab[q];
+  unsigned pw[PW];
+#pragma unroll
+  for (int i = 0; i < ND * WN; i++) pw[i] = a.pk[G::R_O2 + i * NU + tu];
+#pragma unroll
+  for (int i = 0; i < words_of(N3); i++) pw[ND * WN + i] = a.pk[G::R_O3 + i * NU + tu];
+#pragma unroll
+  for (int i = 0; i < WN; i++)
+  {
+    pw[G::R_WU + i] = a.pk[G::R_O0 + i * NFP + tf];
+    pw[G::R_WU + WN + i] = a.pk[G::R_O1 + i * NFP + tf];
+  }
+  const int d1 = a.o1m_dim[tf];
+
+  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  {
+    const long p = tu + NU * e, o = tf + NFP * e;
+    for (int q = t; q < NF * NU; q += TB)
+    {
+      const int f = q / NU, p2 = q - f * NU;
+      su[f][p2] = a.u0[p2 + NU * e + f * plane_u];
+    }
+    __syncthreads();
+    if (is_u)
+    {
+      double u[NF], f[NG], JG[ND * ND];
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
+#pragma unroll
+      for (int k = 0; k < NF; k++) u[k] = su[k][tu];
+      calc_invf<ND, true>(a.P.gamma, u, f);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+          st[k + NF * l][tu] = s;
+        }
+      if (viscous)
+      {
+        {
+          double gr[NG];
+#pragma unroll
+          for (int q = 0; q < NG; q++) gr[q] = a.grad_upts[p + q * plane_u];
+          calc_visf<ND, true>(a.P, u, gr, f);
+        }
+        // tdisf += JGinv * F_v : read-modify-write of this thread's own LDS column
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+#pragma unroll
+          for (int l = 0; l < ND; l++)
+          {
+            double s = st[k + NF * l][tu];
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+            st[k + NF * l][tu] = s;
+          }
+      }
+    }
+    __syncthreads();
+    double div[NF];
+    if (is_u)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = row_dot<N, 0, PW>(pw, tab, &st[k][0], 0.0);
+        s = row_dot<N, WN, PW>(pw, tab, &st[k + NF][0], s);
+        if (ND == 3) s = row_dot<N, (ND - 1) * WN, PW>(pw, tab, &st[k + NF * (ND - 1)][0], s);
+        div[k] = s;
+      }
+    }
+    if (is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        const double ntd = row_dot<N, G::R_WU + WN, PW>(pw, tab, &st[k + NF * d1][0], 0.0);
+        sc[k][tf] = a.tconf[o + k * plane_f] + -1.0 * ntd; // norm_tconf -= norm_tdisf (src/eles.cpp:1746)
+      }
+    }
+    __syncthreads();
+    if (is_u)
+    {
+      const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
+      const double dj = a.detjac_upts[p];
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        const double dv = row_dot<N3, ND * WN, PW>(pw, tab, &sc[k][0], div[k]);
+        const long q = p + k * plane_u;
+        if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)q);
+        if (a.write_div) a.div_out[q] = dv;
+        const double s = a.src ? a.src[q] : 0.0;
+        const double dd = dv / dj;
+        const double u1v = a.need_u1 ? a.u1[q] : 0.0;
+        double u = su[k][tu];
+        if (a.adv_type == 0)
+          u -= dt * (dd - s);
+        else if (a.adv_type == 1)
+        {
+          if (a.in_step == 0) a.u1[q] = u;
+          if (a.in_step < 3)
+            u -= dt / 3.0 * (dd - s);
+          else
+          {
+            const double rhs = -dd + s;
+            u = 3.0 / 4.0 * u + 1.0 / 4.0 * u1v + dt / 4.0 * rhs;
+          }
+        }
+        else if (a.adv_type == 2)
+        {
+          if (a.in_step == 0) a.u1[q] = u;
+          if (a.in_step < 2 || a.in_step == 3)
+            u -= dt / 2.0 * (dd - s);
+          else if (a.in_step == 2)
+          {
+            const double rhs = -dd + s;
+            u = 1.0 / 3.0 * u + 2.0 / 3.0 * u1v + dt / 6.0 * rhs;
+          }
+        }
+        else
+        {
+          const double rhs = -dd + s;
+          const double r1 = a.rk_a * u1v + dt * rhs;
+          a.u1[q] = r1;
+          u += a.rk_b * r1;
+        }
+        a.u0[q] = u;
+        su[k][tu] = u;
+      }
+    }
+    __syncthreads();
+    if (is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, G::R_WU, PW>(pw, tab, &su[k][0], 0.0);
+    }
+    __syncthreads();
+  }
+}
+
+template <int ND, int N>
+static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, SplitEleArgs &ea, int which)
+{
+  FusedData *F = e->fused;
+  hipStream_t st = e->ctx->stream;
+  const Phys P = e->ctx->phys();
+  const long plane_f = (long)e->n_fpts * e->n_eles;
+  const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * 16);
+  auto face_args = [&](hfx_inters *f) {
+    SplitFaceArgs a{};
+    a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
+    a.L = f->L; a.R = f->R; a.meta = F->meta; a.plane_f = plane_f;
+    a.disu = e->arr[HFX_DISU_FPTS]; a.grad = e->arr[HFX_GRAD_DISU_FPTS]; a.fnorm = e->norm_fpts; a.tdA = e->tdA_fpts;
+    a.delta = e->arr[HFX_DELTA_DISU_FPTS]; a.tconf = e->arr[HFX_NORM_TCONF_FPTS];
+    a.P = P;
+    return a;
+  };
+  if (P.viscous && (which == 0 || which == 1))
+  {
+    for (int b = 0; b < nfb; b++)
+    {
+      const SplitFaceArgs a = face_args(faces[b]);
+      if (a.npairs == 0) continue;
+      hipLaunchKernelGGL((face_delta_kernel<ND>), dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
+    }
+  }
+  if (P.viscous && (which == 0 || which == 2))
+  {
+    ea.pk = F->pk_g;
+    ea.tab = F->tab_g;
+    hipLaunchKernelGGL((split_gradient_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, ea);
+  }
+  if (which == 0 || which == 3)
+  {
+    for (int b = 0; b < nfb; b++)
+    {
+      const SplitFaceArgs a = face_args(faces[b]);
+      if (a.npairs == 0) continue;
+      const unsigned nb = (unsigned)((a.npairs + 255) / 256);
+      if (P.riemann == 0)
+        hipLaunchKernelGGL((face_flux_kernel<ND, 0>), dim3(nb), dim3(256), 0, st, a);
+      else if (P.riemann == 2)
+        hipLaunchKernelGGL((face_flux_kernel<ND, 2>), dim3(nb), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((face_flux_kernel<ND, 3>), dim3(nb), dim3(256), 0, st, a);
+    }
+  }
+  if (which == 0 || which == 4)
+  {
+    ea.pk = F->pk_r;
+    ea.tab = F->tab_r;
+    hipLaunchKernelGGL((split_residual_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, ea);
+  }
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_step, bool last_stage, int which = 0)
+{
+  FusedData *F = e->fused;
+  const hfx_params &p = e->ctx->params;
+  SplitEleArgs a{};
+  a.n_eles = e->n_eles;
+  a.o1m_dim = F->o1m_dim;
+  a.detjac_upts = e->detjac_upts; a.JGinv_upts = e->JGinv_upts;
+  a.detjac_fpts = e->detjac_fpts; a.JGinv_fpts = e->JGinv_fpts;
+  a.u0 = e->arr[HFX_DISU_UPTS0]; a.u1 = e->arr[HFX_DISU_UPTS1];
+  a.delta = e->arr[HFX_DELTA_DISU_FPTS]; a.tconf = e->arr[HFX_NORM_TCONF_FPTS];
+  a.disu_next = F->disu_alt;
+  a.grad_upts = e->arr[HFX_GRAD_DISU_UPTS]; a.grad_fpts = e->arr[HFX_GRAD_DISU_FPTS];
+  a.div_out = e->arr[HFX_DIV_TCONF_UPTS];
+  a.src = e->src_nonzero ? e->arr[HFX_SRC_UPTS] : nullptr;
+  a.dt_local = e->arr[HFX_DT_LOCAL];
+  a.nan_flag = e->nan_flag;
+  a.P = e->ctx->phys();
+  a.adv_type = p.adv_type; a.in_step = in_step; a.dt_local_on = p.dt_type == 2; a.dt = p.dt;
+  a.rk_a = (p.adv_type >= 3) ? p.RK_a[in_step] : 0.0;
+  a.rk_b = (p.adv_type >= 3) ? p.RK_b[in_step] : 0.0;
+  a.need_u1 = (p.adv_type >= 3) || (p.adv_type == 1 && in_step == 3) || (p.adv_type == 2 && in_step == 2);
+  a.write_div = last_stage ? 1 : 0;
+  const int N = tensor_n(e);
+  int rc = 1;
+#define HFX_SPLIT_CASE(ND_, N_) \
+  if (e->n_dims == ND_ && N == N_) rc = launch_split_stage<ND_, N_>(e, faces, nfb, a, which);
+  HFX_SPLIT_CASE(3, 2) HFX_SPLIT_CASE(3, 3) HFX_SPLIT_CASE(3, 4) HFX_SPLIT_CASE(3, 5) HFX_SPLIT_CASE(3, 6)
+  HFX_SPLIT_CASE(2, 2) HFX_SPLIT_CASE(2, 3) HFX_SPLIT_CASE(2, 4) HFX_SPLIT_CASE(2, 5) HFX_SPLIT_CASE(2, 6)
+#undef HFX_SPLIT_CASE
+  if (rc) return 1;
+  if (which == 0 || which == 4) std::swap(e->arr[HFX_DISU_FPTS], e->fused->disu_alt);
+  return 0;
+}
+
+int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
+{
+  HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
+  if (!e->fused || !e->fused->built)
+    if (fused_build(e, faces, nfb)) return 1;
+  if (n_steps <= 0) return 0;
+  const int adv = e->ctx->params.adv_type;
+  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
+  HFX_CHECK(e->ctx->params.dt_type != 2 || e->arr[HFX_DT_LOCAL], "dt_type 2 needs HFX_DT_LOCAL uploaded");
+  if (hfx_eles_extrapolate_solution(e)) return 1;
+  for (int s = 0; s < n_steps; s++)
+    for (int rk = 0; rk < nst; rk++)
+      if (split_stage(e, faces, nfb, rk, rk == nst - 1)) return 1;
+  return 0;
+}
+
+int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len)
+{
+  if (!e->fused || !e->fused->built)
+    if (fused_build(e, faces, nfb)) return 1;
+  const int adv = e->ctx->params.adv_type;
+  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
+  hipStream_t st = e->ctx->stream;
+  hipEvent_t ev[5];
+  for (auto &x : ev) HFX_HIP(hipEventCreate(&x));
+  if (hfx_eles_extrapolate_solution(e)) return 1;
+  double acc[4] = {0, 0, 0, 0};
+  for (int r = 0; r < reps; r++)
+  {
+    const int rk = r % nst;
+    for (int w = 1; w <= 4; w++)
+    {
+      HFX_HIP(hipEventRecord(ev[w - 1], st));
+      if (split_stage(e, faces, nfb, rk, rk == nst - 1, w)) return 1;
+    }
+    HFX_HIP(hipEventRecord(ev[4], st));
+    HFX_HIP(hipStreamSynchronize(st));
+    for (int w = 0; w < 4; w++)
+    {
+      float t = 0;
+      HFX_HIP(hipEventElapsedTime(&t, ev[w], ev[w + 1]));
+      acc[w] += t;
+    }
+  }
+  for (auto &x : ev) (void)hipEventDestroy(x);
+  for (int i = 0; i < 8; i++) ms[i] = 0.0;
+  for (int w = 0; w < 4; w++) ms[w] = acc[w] / reps;
+  snprintf(names, names_len, "face_delta_kernel,split_gradient_kernel,face_flux_kernel,split_residual_kernel");
+  return 0;
+}
+
+void split_kernel_bytes(const hfx_eles *e, double *bytes)
+{
+  // ALGORITHMIC HBM bytes per launch (doubles listed per element)
+  const double nu = e->n_upts, nfp = e->n_fpts, nf = e->n_fields, nd = e->n_dims, ne = e->n_eles;
+  for (int i = 0; i < 8; i++) bytes[i] = 0.0;
+  bytes[0] = ne * (8.0 * (2 * nfp * nf) + 4.0 * nfp + nfp * 0.5);                                   // disu r, delta w, index + meta
+  bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nf * nd); // + grad_fpts w
+  bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf * nd + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp);   // disu, grad, normal(left), tdA r; tconf w
+  bytes[3] = ne * 8.0 * (nu * nf + nu * (nd * nd + 1) + nfp * nf + 3 * nu * nf + nfp * nf);           // u, metrics, tconf, u1 r; u0,u1,disu w
 }
 
 } // namespace hfx

@@ -13,4 +13,8 @@ int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
 int fused_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len);
 // algorithmic HBM bytes per launch of each fused kernel, same order as fused_time_kernels
 void fused_kernel_bytes(const hfx_eles *e, double *bytes);
+// the split variant (mode 2): pairwise face kernels + per-element kernels, four launches per stage
+int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps);
+int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len);
+void split_kernel_bytes(const hfx_eles *e, double *bytes);
 } // namespace hfx

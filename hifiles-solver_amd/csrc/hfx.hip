@@ -335,6 +335,14 @@ int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode)
   return 0;
 }
 
+int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode)
+{
+  HFX_CHECK(ctx, "NULL ctx");
+  HFX_CHECK(mode == 1 || mode == 2, "hfx_ctx_set_fused_mode: mode must be 1 (gather) or 2 (split)");
+  ctx->fused_mode = mode;
+  return 0;
+}
+
 int hfx_ctx_synchronize(hfx_ctx *ctx)
 {
   HFX_CHECK(ctx, "NULL ctx");
@@ -781,6 +789,7 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, i
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   const int adv = e->ctx->params.adv_type;
   const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14; /* src/HiFiLES.cpp:143-150 */
+  if (fused == 2) return split_run_steps(e, faces, nfb, n_steps);
   if (fused) return fused_run_steps(e, faces, nfb, n_steps);
   for (int s = 0; s < n_steps; s++)
     for (int rk = 0; rk < nst; rk++)
@@ -848,13 +857,17 @@ int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int r
 {
   HFX_CHECK(e && ms && names && reps > 0, "hfx_time_fused_kernels: bad argument");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
+  if (e->ctx->fused_mode == 2) return split_time_kernels(e, faces, nfb, reps, ms, names, 256);
   return fused_time_kernels(e, faces, nfb, reps, ms, names, 256);
 }
 
 int hfx_fused_kernel_bytes(hfx_eles *e, double bytes[8])
 {
   HFX_CHECK(e && bytes, "hfx_fused_kernel_bytes: bad argument");
-  fused_kernel_bytes(e, bytes);
+  if (e->ctx->fused_mode == 2)
+    split_kernel_bytes(e, bytes);
+  else
+    fused_kernel_bytes(e, bytes);
   return 0;
 }
 

@@ -66,6 +66,7 @@ struct hfx_ctx
   hfx_params params{};
   bool have_params = false;
   int contract_mode = HFX_CONTRACT_AUTO;
+  int fused_mode = 1; // which fused variant hfx_time_fused_kernels / hfx_fused_kernel_bytes describe
   int n_cu = 256;
   hfx::Phys phys() const
   {

@@ -83,6 +83,9 @@ class Context:
         self.params = p
         check(lib().hfx_ctx_set_params(self.h, C.byref(p)))
 
+    def set_fused_mode(self, mode):
+        check(lib().hfx_ctx_set_fused_mode(self.h, C.c_int(mode)))
+
     def set_contract_mode(self, mode):
         check(lib().hfx_ctx_set_contract_mode(self.h, C.c_int(mode)))
 
@@ -208,7 +211,7 @@ def CalcResidual(eles, faces):
 
 
 def run_steps(eles, faces, n_steps, fused=False):
-    check(lib().hfx_run_steps(eles.h, _face_array(faces), C.c_int(len(faces)), C.c_int(n_steps), C.c_int(1 if fused else 0)))
+    check(lib().hfx_run_steps(eles.h, _face_array(faces), C.c_int(len(faces)), C.c_int(n_steps), C.c_int(int(fused))))
 
 
 def params_from(data):

@@ -145,7 +145,7 @@ class Case:
     def run_steps_lib(self, n_steps, fused=False):
         """hfx_run_steps on this case's device blocks (the whole RK loop inside libhfx)."""
         ctx, e, f, nb = self.handles()
-        hfx.check(hfx.lib().hfx_run_steps(e, f, C.c_int(nb), C.c_int(n_steps), C.c_int(1 if fused else 0)))
+        hfx.check(hfx.lib().hfx_run_steps(e, f, C.c_int(nb), C.c_int(n_steps), C.c_int(int(fused))))
 
     def synchronize(self):
         ctx, e, f, nb = self.handles()

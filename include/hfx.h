@@ -104,6 +104,9 @@ int hfx_ctx_create(int device, hfx_ctx **out);
 int hfx_ctx_destroy(hfx_ctx *ctx);
 int hfx_ctx_set_params(hfx_ctx *ctx, const hfx_params *p);
 int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode);
+/* which fused variant the measurement entry points describe: 1 gather-style (two kernels per stage),
+ * 2 split (pairwise face kernels + element kernels, four launches per stage) */
+int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
 int hfx_ctx_synchronize(hfx_ctx *ctx);
 /* the HIP stream (hipStream_t) all kernels of this context are launched on */
 void *hfx_ctx_stream(hfx_ctx *ctx);
@@ -149,8 +152,8 @@ int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f); /* int_inters::calc
  * face blocks, LES / RANS / forcing off; same call order as the reference. */
 int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
 /* n_steps time steps = the RK-stage loop of src/HiFiLES.cpp:194-217:
- * for each stage CalcResidual + AdvanceSolution.  `fused` != 0 selects the
- * fused per-stage kernels (same results to rounding), 0 the per-method path. */
+ * for each stage CalcResidual + AdvanceSolution.  `fused`: 0 the per-method path, 1 the gather-style
+ * fused kernels, 2 the split fused kernels (same results to rounding). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
 
 /* ---- measurement ------------------------------------------------------- */

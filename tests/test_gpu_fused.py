@@ -22,14 +22,16 @@ def ctx():
     c.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("name", ALL)
-def test_fused_vs_reference(ctx, name):
+def test_fused_vs_reference(ctx, name, mode):
+    """mode 1: gather-style fused kernels, mode 2: split fused kernels"""
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     e, faces = build(ctx, d)
     nstage = int(d["sizes"][7])
     steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
     for st in steps:
-        hfx.run_steps(e, faces, 1, fused=True)
+        hfx.run_steps(e, faces, 1, fused=mode)
         assert relerr(e.download(hfx.DISU_UPTS0), d["u_step%d_stage%d" % (st, nstage - 1)]) < 1e-11, st
     assert e.check_nan() == -1
     for f in faces:
@@ -37,13 +39,14 @@ def test_fused_vs_reference(ctx, name):
     e.close()
 
 
-def test_fused_public_arrays_after_a_step(ctx):
-    """What the fused path leaves in the public arrays: state, RK register, flux-point solution of the
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_public_arrays_after_a_step(ctx, mode):
+    """What the fused paths leave in the public arrays: state, RK register, flux-point solution of the
     NEW state, corrected gradients and the divergence of the step's last stage (for the monitors)."""
     d = dict(np.load(os.path.join(GOLDEN, "hex_p3_n3_deformed.npz")))
     ef, ff = build(ctx, d)
     em, fm = build(ctx, d)
-    hfx.run_steps(ef, ff, 1, fused=True)
+    hfx.run_steps(ef, ff, 1, fused=mode)
     hfx.run_steps(em, fm, 1, fused=False)
     assert relerr(ef.download(hfx.DISU_UPTS0), em.download(hfx.DISU_UPTS0)) < 1e-12
     assert relerr(ef.download(hfx.DISU_UPTS1), em.download(hfx.DISU_UPTS1)) < 1e-9
@@ -54,7 +57,7 @@ def test_fused_public_arrays_after_a_step(ctx):
     assert relerr(ef.download(hfx.DISU_FPTS), em.download(hfx.DISU_FPTS)) < 1e-13
     # mixing the paths: a per-method stage after fused steps sees a consistent state
     hfx.run_steps(ef, ff, 1, fused=False)
-    hfx.run_steps(em, fm, 1, fused=True)
+    hfx.run_steps(em, fm, 1, fused=mode)
     assert relerr(ef.download(hfx.DISU_UPTS0), em.download(hfx.DISU_UPTS0)) < 1e-12
     for f in ff + fm:
         f.close()
@@ -74,12 +77,13 @@ def test_fused_nan_flag(ctx):
     e.close()
 
 
-def test_fused_quads_vs_methods():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_quads_vs_methods(mode):
     """2-D tensor-product elements (BASELINE.json configs[0]'s element type) through both paths."""
     a = H.Case([6, 5, 1], dims=2, order=3, amp=0.1)
     b = H.Case([6, 5, 1], dims=2, order=3, amp=0.1)
     a.to_device(0); b.to_device(0)
-    a.run_steps_lib(2, fused=True)
+    a.run_steps_lib(2, fused=mode)
     b.run_steps_lib(2, fused=False)
     a.sync_host(); b.sync_host()
     assert relerr(a.array("disu_upts0"), b.array("disu_upts0")) < 1e-12
@@ -87,12 +91,13 @@ def test_fused_quads_vs_methods():
     a.close(); b.close()
 
 
-def test_fused_full_size_conservation():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_full_size_conservation(mode):
     c = H.Case(32, order=4)
     u0 = c.array("disu_upts0")
     i0 = integrals(c, u0)
     c.to_device(0)
-    c.run_steps_lib(2, fused=True)
+    c.run_steps_lib(2, fused=mode)
     c.sync_host()
     u = c.array("disu_upts0")
     assert np.isfinite(u).all()
@@ -109,11 +114,12 @@ def test_fused_full_size_conservation():
     c.close(); m.close()
 
 
-def test_fused_full_size_residual_norms_vs_reference_stdout():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_full_size_residual_norms_vs_reference_stdout(mode):
     """the reference's own iteration-1 row for the 32^3 P4 TGV case."""
     c = H.Case(32, order=4)
     c.to_device(0)
-    c.run_steps_lib(1, fused=True)
+    c.run_steps_lib(1, fused=mode)
     ctx_, e, f, nb = c.handles()
     v = C.c_double()
     r = []
