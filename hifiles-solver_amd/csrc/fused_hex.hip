@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "kernels_mpi.hpp"
 #include "physics.hpp"
 
 namespace hfx
@@ -910,7 +911,7 @@ static int dispatch_build_packed(hfx_eles *e, FusedData *F, int N, const std::ve
   return 1;
 }
 
-static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
+static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allow_unpaired = false)
 {
   HFX_CHECK(e->ele_type == 4 || e->ele_type == 1, "fused path: tensor-product elements only (hexes, quads)");
   const int N = tensor_n(e);
@@ -1001,8 +1002,10 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
       for (int d = 0; d < nd; d++) fnorm[ir + d * plane_f] = norm[il + d * plane_f];
     }
   }
-  for (long o = 0; o < plane_f; o++)
-    HFX_CHECK(nbr[o] >= 0, "fused path: flux point %ld has no partner (boundary / partition faces are not fused yet)", o);
+  if (!allow_unpaired)
+    for (long o = 0; o < plane_f; o++)
+      HFX_CHECK(nbr[o] >= 0, "fused path: flux point %ld has no partner (boundary faces are not fused; partition faces need "
+                             "hfx_stage_partitioned)", o);
   if (upload((void **)&F->nbr, nbr.data(), sizeof(int) * plane_f)) return 1;
   if (upload((void **)&F->meta, meta.data(), plane_f)) return 1;
   if (upload((void **)&F->fnorm, fnorm.data(), sizeof(double) * plane_f * nd)) return 1;
@@ -1721,6 +1724,75 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes)
   bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nf * nd); // + grad_fpts w
   bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf * nd + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp);   // disu, grad, normal(left), tdA r; tconf w
   bytes[3] = ne * 8.0 * (nu * nf + nu * (nd * nd + 1) + nfp * nf + 3 * nu * nf + nfp * nf);           // u, metrics, tconf, u1 r; u0,u1,disu w
+}
+
+
+// ---------------------------------------------------------------------------------------
+// split path on a partitioned block: interior pairs by the pairwise kernels, partition faces by the
+// one-sided kernels of kernels_mpi.hpp; the caller exchanges the buffers between the phases
+// ---------------------------------------------------------------------------------------
+template <int ND>
+static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
+{
+  if (f->n_inters == 0) return 0;
+  MpiArgs a{};
+  a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
+  a.nfpi = f->n_fpts_per_inter;
+  a.L = f->L; a.Rlut = f->R;
+  a.plane = (long)e->n_fpts * e->n_eles;
+  a.disu = e->arr[HFX_DISU_FPTS]; a.grad = e->arr[HFX_GRAD_DISU_FPTS];
+  a.norm = e->norm_fpts; a.tdA = e->tdA_fpts;
+  a.tconf = e->arr[HFX_NORM_TCONF_FPTS];
+  a.delta = (what == 3) ? nullptr : e->arr[HFX_DELTA_DISU_FPTS];
+  a.out_disu = f->out_disu; a.out_grad = f->out_grad; a.in_disu = f->in_disu; a.in_grad = f->in_grad;
+  a.P = e->ctx->phys();
+  const dim3 g((unsigned)((a.npairs + 255) / 256)), b(256);
+  hipStream_t st = e->ctx->stream;
+  switch (what)
+  {
+  case 0: hipLaunchKernelGGL(mpi_pack_disu_kernel<ND>, g, b, 0, st, a); break;
+  case 1: hipLaunchKernelGGL(mpi_delta_kernel<ND>, g, b, 0, st, a); break;
+  case 2: hipLaunchKernelGGL(mpi_pack_grad_kernel<ND>, g, b, 0, st, a); break;
+  case 3: hipLaunchKernelGGL((mpi_common_invflux_kernel<ND, true>), g, b, 0, st, a); break;
+  case 4: hipLaunchKernelGGL((mpi_common_viscflux_kernel<ND, true>), g, b, 0, st, a); break;
+  }
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                            int phase, int in_step, int first)
+{
+  HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
+  for (int b = 0; b < n_mpi; b++) HFX_CHECK(mpi_faces[b]->is_mpi && mpi_faces[b]->left == e, "bad partition-face block");
+  if (!e->fused || !e->fused->built)
+    if (fused_build(e, int_faces, n_int, true)) return 1;
+  const hfx_params &p = e->ctx->params;
+  const int nst = (p.adv_type == 0) ? 1 : (p.adv_type <= 2) ? 4 : (p.adv_type == 3) ? 5 : 14;
+  HFX_CHECK(in_step >= 0 && in_step < nst, "hfx_stage_partitioned: stage %d out of range", in_step);
+  auto mpi_all = [&](int what) -> int {
+    for (int b = 0; b < n_mpi; b++)
+      if ((e->n_dims == 2 ? mpi_launch<2>(e, mpi_faces[b], what) : mpi_launch<3>(e, mpi_faces[b], what))) return 1;
+    return 0;
+  };
+  if (phase == 0)
+  {
+    if (first && hfx_eles_extrapolate_solution(e)) return 1;
+    return mpi_all(0);
+  }
+  if (phase == 1)
+  {
+    if (!p.viscous) return 0;
+    if (split_stage(e, int_faces, n_int, in_step, false, 1)) return 1; // interior LDG common solution
+    if (mpi_all(1)) return 1;
+    if (split_stage(e, int_faces, n_int, in_step, false, 2)) return 1; // corrected gradients
+    return mpi_all(2);
+  }
+  if (split_stage(e, int_faces, n_int, in_step, in_step == nst - 1, 3)) return 1; // interior common fluxes
+  if (mpi_all(3)) return 1;
+  if (p.viscous && mpi_all(4)) return 1;
+  if (split_stage(e, int_faces, n_int, in_step, in_step == nst - 1, 4)) return 1; // residual, RK, new disu_fpts (swaps)
+  return mpi_all(0);
 }
 
 } // namespace hfx

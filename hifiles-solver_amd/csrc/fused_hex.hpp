@@ -17,4 +17,7 @@ void fused_kernel_bytes(const hfx_eles *e, double *bytes);
 int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps);
 int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len);
 void split_kernel_bytes(const hfx_eles *e, double *bytes);
+// one phase of a split-path stage on a partitioned block (see hfx_stage_partitioned)
+int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                            int phase, int in_step, int first);
 } // namespace hfx

@@ -9,6 +9,7 @@
 #include "fused_hex.hpp"
 #include "hfx_internal.hpp"
 #include "kernels_ops.hpp"
+#include "kernels_mpi.hpp"
 #include "kernels_point.hpp"
 
 namespace hfx
@@ -708,8 +709,107 @@ int hfx_inters_destroy(hfx_inters *f)
     }
   if (f->L) (void)hipFree(f->L);
   if (f->R) (void)hipFree(f->R);
+  for (double *b : {f->out_disu, f->in_disu, f->out_grad, f->in_grad})
+    if (b) (void)hipFree(b);
   delete f;
   return 0;
+}
+
+// ---- mpi_inters ----------------------------------------------------------------------
+int hfx_mpi_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, const int *L, const int *Rlut,
+                          hfx_inters **out)
+{
+  HFX_CHECK(ctx && left && out, "hfx_mpi_inters_create: NULL argument");
+  HFX_CHECK(n_inters >= 0 && nfpi > 0, "hfx_mpi_inters_create: bad sizes");
+  HFX_CHECK(n_inters == 0 || (L && Rlut), "hfx_mpi_inters_create: NULL table");
+  const long np = (long)n_inters * nfpi;
+  const long pl = (long)left->n_fpts * left->n_eles;
+  for (long q = 0; q < np; q++)
+  {
+    HFX_CHECK(L[q] >= 0 && L[q] < pl, "partition face table L[%ld] = %d out of range", q, L[q]);
+    HFX_CHECK(Rlut[q] >= 0 && Rlut[q] < nfpi, "partition face table Rlut[%ld] = %d out of range", q, Rlut[q]);
+  }
+  hfx_inters *f = new hfx_inters();
+  f->ctx = ctx; f->left = left; f->right = nullptr; f->n_inters = n_inters; f->n_fpts_per_inter = nfpi;
+  f->is_mpi = true;
+  f->hL.assign(L, L + np);
+  f->hR.assign(Rlut, Rlut + np);
+  const size_t ni = (size_t)std::max<long>(np, 1);
+  HFX_HIP(hipMalloc((void **)&f->L, sizeof(int) * ni));
+  HFX_HIP(hipMalloc((void **)&f->R, sizeof(int) * ni));
+  HFX_HIP(hipMemcpy(f->L, L, sizeof(int) * (size_t)np, hipMemcpyHostToDevice));
+  HFX_HIP(hipMemcpy(f->R, Rlut, sizeof(int) * (size_t)np, hipMemcpyHostToDevice));
+  const size_t nd = ni * left->n_fields, ng = nd * left->n_dims;
+  HFX_HIP(hipMalloc((void **)&f->out_disu, sizeof(double) * nd));
+  HFX_HIP(hipMalloc((void **)&f->in_disu, sizeof(double) * nd));
+  HFX_HIP(hipMalloc((void **)&f->out_grad, sizeof(double) * ng));
+  HFX_HIP(hipMalloc((void **)&f->in_grad, sizeof(double) * ng));
+  HFX_HIP(hipMemset(f->in_disu, 0, sizeof(double) * nd));
+  HFX_HIP(hipMemset(f->in_grad, 0, sizeof(double) * ng));
+  *out = f;
+  return 0;
+}
+
+static MpiArgs mpi_args(hfx_inters *f)
+{
+  MpiArgs a{};
+  hfx_eles *l = f->left;
+  a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
+  a.nfpi = f->n_fpts_per_inter;
+  a.L = f->L; a.Rlut = f->R;
+  a.plane = (long)l->n_fpts * l->n_eles;
+  a.disu = l->arr[HFX_DISU_FPTS]; a.grad = l->arr[HFX_GRAD_DISU_FPTS];
+  a.norm = l->norm_fpts; a.tdA = l->tdA_fpts;
+  a.tconf = l->arr[HFX_NORM_TCONF_FPTS]; a.delta = l->arr[HFX_DELTA_DISU_FPTS];
+  a.out_disu = f->out_disu; a.out_grad = f->out_grad; a.in_disu = f->in_disu; a.in_grad = f->in_grad;
+  a.P = f->ctx->phys();
+  return a;
+}
+
+#define HFX_MPI_LAUNCH(KERNEL2, KERNEL3)                                                                    \
+  do                                                                                                        \
+  {                                                                                                         \
+    HFX_CHECK(f && f->is_mpi, "not a partition-face block");                                                \
+    if (f->n_inters == 0) return 0;                                                                         \
+    HFX_CHECK(f->ctx->have_params, "parameters not set");                                                   \
+    const MpiArgs a = mpi_args(f);                                                                          \
+    if (f->left->n_dims == 2)                                                                               \
+      hipLaunchKernelGGL(KERNEL2, dim3(nblocks(a.npairs, 256)), dim3(256), 0, f->ctx->stream, a);           \
+    else                                                                                                    \
+      hipLaunchKernelGGL(KERNEL3, dim3(nblocks(a.npairs, 256)), dim3(256), 0, f->ctx->stream, a);           \
+    HFX_HIP(hipGetLastError());                                                                             \
+    return 0;                                                                                               \
+  } while (0)
+
+int hfx_mpi_inters_pack_solution(hfx_inters *f) { HFX_MPI_LAUNCH(mpi_pack_disu_kernel<2>, mpi_pack_disu_kernel<3>); }
+int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f) { HFX_MPI_LAUNCH(mpi_pack_grad_kernel<2>, mpi_pack_grad_kernel<3>); }
+int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f)
+{
+  HFX_MPI_LAUNCH((mpi_common_invflux_kernel<2, false>), (mpi_common_invflux_kernel<3, false>));
+}
+int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f)
+{
+  HFX_MPI_LAUNCH((mpi_common_viscflux_kernel<2, false>), (mpi_common_viscflux_kernel<3, false>));
+}
+
+int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n)
+{
+  HFX_CHECK(f && f->is_mpi && dev && n, "hfx_mpi_inters_buffer: bad argument");
+  HFX_CHECK(which >= 0 && which <= 3, "hfx_mpi_inters_buffer: which must be 0..3");
+  const long nd = (long)f->n_inters * f->n_fpts_per_inter * f->left->n_fields;
+  double *b[4] = {f->out_disu, f->in_disu, f->out_grad, f->in_grad};
+  *dev = b[which];
+  *n = (which < 2) ? nd : nd * f->left->n_dims;
+  return 0;
+}
+
+int hfx_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                          int phase, int in_step, int first)
+{
+  HFX_CHECK(e, "NULL eles");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  HFX_CHECK(phase >= 0 && phase <= 2, "hfx_stage_partitioned: phase must be 0..2");
+  return split_stage_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, phase, in_step, first);
 }
 
 static FaceArgs face_args(hfx_inters *f)

@@ -113,4 +113,7 @@ struct hfx_inters
   int n_inters = 0, n_fpts_per_inter = 0;
   int *L = nullptr, *R = nullptr; // device (n_fpts_per_inter, n_inters)
   std::vector<int> hL, hR;        // host copies (for building per-element tables)
+  // partition faces (is_mpi): R holds the received-record slot lut(j); buffers are owned here
+  bool is_mpi = false;
+  double *out_disu = nullptr, *in_disu = nullptr, *out_grad = nullptr, *in_grad = nullptr;
 };

@@ -51,6 +51,17 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
   if (in.setup_params(g_err)) { delete c; return 1; }
 
   c->mesh.dims = d->dims;
+  c->S.nproc = d->nproc > 0 ? d->nproc : 1;
+  c->S.rank = d->nproc > 0 ? d->rank : 0;
+  {
+    int r = c->S.rank;
+    for (int i = 0; i < 3; i++)
+    {
+      c->mesh.pgrid[i] = (d->nproc > 0 && d->pgrid[i] > 0 && i < d->dims) ? d->pgrid[i] : 1;
+      c->mesh.pcoord[i] = r % c->mesh.pgrid[i];
+      r /= c->mesh.pgrid[i];
+    }
+  }
   for (int i = 0; i < 3; i++) c->mesh.n[i] = d->n[i];
   c->mesh.length = d->length;
   c->mesh.amp = d->amp;
@@ -135,6 +146,38 @@ extern "C" int hfxh_case_get_faces(hfxh_case *c, const int **L, const int **R, i
   return 0;
 }
 
+static mpi_inters *the_mpi_faces(hfxh_case *c) { return &c->S.mesh_mpi_inters(c->S.n_dims == 3 ? 2 : 0); }
+
+extern "C" int hfxh_case_get_mpi_faces(hfxh_case *c, const int **L, const int **Rlut, int *n_fpts_per_inter, int *n_inters,
+                                       const int **nout_proc)
+{
+  mpi_inters *M = the_mpi_faces(c);
+  *L = M->disu_fpts_l.get_ptr_cpu();
+  *Rlut = M->disu_fpts_r.get_ptr_cpu();
+  *n_fpts_per_inter = M->n_fpts_per_inter;
+  *n_inters = M->n_inters;
+  *nout_proc = M->Nout_proc.get_ptr_cpu();
+  return 0;
+}
+
+extern "C" int hfxh_case_set_exchange(hfxh_case *c, hfxh_exchange_cb fn, void *user)
+{
+  SetExchange(&c->S, fn, user);
+  return 0;
+}
+
+extern "C" int hfxh_case_mpi_handle(hfxh_case *c, hfx_inters **f)
+{
+  *f = the_mpi_faces(c)->device();
+  return 0;
+}
+
+extern "C" int hfxh_case_run_partitioned(hfxh_case *c, int n_steps)
+{
+  if (RunStepsPartitionedFused(&c->S, n_steps)) { g_err = c->S.err; return 1; }
+  return 0;
+}
+
 extern "C" int hfxh_case_to_device(hfxh_case *c, int device)
 {
   if (MoveToDevice(&c->S, device)) { g_err = c->S.err; return 1; }
@@ -160,6 +203,7 @@ extern "C" int hfxh_case_CalcResidual(hfxh_case *c)
   eles *E = the_eles(c);
   if (E->failed()) { g_err = E->last_error(); return 1; }
   if (the_faces(c)->failed()) { g_err = the_faces(c)->last_error(); return 1; }
+  if (the_mpi_faces(c)->failed()) { g_err = the_mpi_faces(c)->last_error(); return 1; }
   return 0;
 }
 

@@ -106,3 +106,98 @@ void int_inters::calculate_common_viscFlux()
 {
   if (n_inters != 0 && hfx_int_inters_calculate_common_viscFlux(dev) && err.empty()) err = hfx_last_error();
 }
+
+// ---- mpi_inters -----------------------------------------------------------------------------
+mpi_inters::~mpi_inters()
+{
+  if (dev) hfx_inters_destroy(dev);
+}
+
+void mpi_inters::setup(int in_n_inters, int in_inter_type, input *in)
+{
+  n_inters = in_n_inters;
+  inters_type = in_inter_type;
+  order = in->order;
+  viscous = in->viscous;
+  if (inters_type == 0) { n_fpts_per_inter = order + 1; n_dims = 2; }
+  else if (inters_type == 1) { n_fpts_per_inter = (order + 2) * (order + 1) / 2; n_dims = 3; }
+  else { n_fpts_per_inter = (order + 1) * (order + 1); n_dims = 3; }
+  n_fields = n_dims + 2;
+  disu_fpts_l.setup(n_fpts_per_inter, n_inters);
+  disu_fpts_r.setup(n_fpts_per_inter, n_inters);
+  lut.setup(n_fpts_per_inter);
+}
+
+void mpi_inters::set_nproc(int in_nproc, int in_rank)
+{
+  nproc = in_nproc;
+  rank = in_rank;
+  Nout_proc.setup(nproc);
+  Nout_proc.initialize_to_zero();
+}
+
+void mpi_inters::set_nout_proc(int in_nout, int in_p) { Nout_proc(in_p) = in_nout; }
+
+void mpi_inters::set_mpi(int in_inter, int in_ele_type_l, int in_ele_l, int in_local_inter_l, int rot_tag,
+                         struct solution *FlowSol)
+{
+  if (ele_type_l < 0) ele_type_l = in_ele_type_l;
+  if (ele_type_l != in_ele_type_l)
+  {
+    if (err.empty()) err = "mpi_inters: one partition-face block must belong to one element class";
+    return;
+  }
+  // the same look-up table as interior faces (src/inters.cpp:153-262)
+  int_inters tmp;
+  tmp.inters_type = inters_type;
+  tmp.order = order;
+  tmp.n_fpts_per_inter = n_fpts_per_inter;
+  tmp.lut.setup(n_fpts_per_inter);
+  tmp.get_lut(rot_tag);
+  eles *el = FlowSol->mesh_eles(in_ele_type_l);
+  for (int j = 0; j < n_fpts_per_inter; j++)
+  {
+    disu_fpts_l(j, in_inter) = el->get_fpt_offset(in_ele_l, in_local_inter_l, j);
+    disu_fpts_r(j, in_inter) = tmp.lut(j); // in_buffer_disu.get_ptr(j_rhs, field, in_inter)
+  }
+}
+
+int mpi_inters::mv_all_cpu_gpu(hfx_ctx *ctx, struct solution *FlowSol)
+{
+  if (n_inters == 0) return 0;
+  eles *el = FlowSol->mesh_eles(ele_type_l);
+  if (hfx_mpi_inters_create(ctx, el->device(), n_inters, n_fpts_per_inter, disu_fpts_l.get_ptr_cpu(),
+                            disu_fpts_r.get_ptr_cpu(), &dev))
+  {
+    err = hfx_last_error();
+    return 1;
+  }
+  return 0;
+}
+
+#define HFX_MPI_CALL(expr)                                            \
+  do                                                                  \
+  {                                                                   \
+    if (n_inters != 0 && (expr) != 0 && err.empty()) err = hfx_last_error(); \
+  } while (0)
+
+void mpi_inters::send_solution()
+{
+  HFX_MPI_CALL(hfx_mpi_inters_pack_solution(dev));
+  if (n_inters != 0 && exchange) exchange(exchange_user, 0, 0);
+}
+void mpi_inters::receive_solution()
+{
+  if (n_inters != 0 && exchange) exchange(exchange_user, 0, 1);
+}
+void mpi_inters::send_corrected_gradient()
+{
+  HFX_MPI_CALL(hfx_mpi_inters_pack_corrected_gradient(dev));
+  if (n_inters != 0 && exchange) exchange(exchange_user, 1, 0);
+}
+void mpi_inters::receive_corrected_gradient()
+{
+  if (n_inters != 0 && exchange) exchange(exchange_user, 1, 1);
+}
+void mpi_inters::calculate_common_invFlux() { HFX_MPI_CALL(hfx_mpi_inters_calculate_common_invFlux(dev)); }
+void mpi_inters::calculate_common_viscFlux() { HFX_MPI_CALL(hfx_mpi_inters_calculate_common_viscFlux(dev)); }

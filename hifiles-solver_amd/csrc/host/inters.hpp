@@ -42,3 +42,45 @@ private:
   hfx_inters *dev = nullptr;
   std::string err;
 };
+
+// exchange hook: the reference calls MPI_Isend/Irecv + MPI_Waitall inside send_* / receive_*
+// (src/mpi_inters.cpp:244-270); here the transport is pluggable (RCCL through torch.distributed in
+// the bench, gloo in the CPU tests).  kind: 0 solution, 1 corrected gradient; phase: 0 start, 1 wait.
+typedef void (*hfxh_exchange_fn)(void *user, int kind, int phase);
+
+// Host-side mirror of the reference's partition-face class (include/mpi_inters.h:40-105).
+class mpi_inters
+{
+public:
+  ~mpi_inters();
+  void setup(int in_n_inters, int in_inter_type, input *in_run_input); // src/mpi_inters.cpp:50
+  void set_nproc(int in_nproc, int in_rank);                           // :91
+  void set_nout_proc(int in_nout, int in_p);                           // :101
+  // mpi_inters::set_mpi (src/mpi_inters.cpp:148-216): same arguments
+  void set_mpi(int in_inter, int in_ele_type_l, int in_ele_l, int in_local_inter_l, int rot_tag, struct solution *FlowSol);
+  int mv_all_cpu_gpu(hfx_ctx *ctx, struct solution *FlowSol);
+  void send_solution();              // :218 pack + start of the exchange
+  void receive_solution();           // :261 wait
+  void send_corrected_gradient();    // :278
+  void receive_corrected_gradient(); // :323
+  void calculate_common_invFlux();   // :400
+  void calculate_common_viscFlux();  // :485
+  void set_exchange(hfxh_exchange_fn fn, void *user) { exchange = fn; exchange_user = user; }
+
+  int get_n_inters() const { return n_inters; }
+  hfx_inters *device() { return dev; }
+  const std::string &last_error() const { return err; }
+  bool failed() const { return !err.empty(); }
+
+  int inters_type = 0, order = 0, viscous = 0, n_inters = 0, n_fpts_per_inter = 0, n_fields = 0, n_dims = 0;
+  int nproc = 1, rank = 0, ele_type_l = -1;
+  hf_array<int> Nout_proc;                // faces exchanged with each rank; a rank's faces are contiguous
+  hf_array<int> disu_fpts_l, disu_fpts_r; // left offsets ; received-record slot lut(j)
+  hf_array<int> lut;
+
+private:
+  hfx_inters *dev = nullptr;
+  hfxh_exchange_fn exchange = nullptr;
+  void *exchange_user = nullptr;
+  std::string err;
+};

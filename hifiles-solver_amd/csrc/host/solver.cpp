@@ -1,11 +1,13 @@
 #include "solver.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 solution::~solution()
 {
   // face blocks reference element blocks: release them first
   mesh_int_inters.setup(0);
+  mesh_mpi_inters.setup(0);
   mesh_eles_quads.free_device();
   mesh_eles_hexas.free_device();
   if (ctx) hfx_ctx_destroy(ctx);
@@ -18,18 +20,26 @@ void box_mesh::generate()
   const int NV = nv();
   xv.assign((size_t)NV * dims, 0.0);
   const double two_pi_over_l = 2.0 * 3.14159265358979323846 / length;
-  auto coord = [&](int i, int nn) { return (i == nn) ? length : length * ((double)i / nn); };
+  // vertex coordinates are functions of the GLOBAL index, so that a block of a partitioned box gets
+  // bit-identical vertices to the same cells of the unpartitioned one
+  auto coord = [&](int i, int d) {
+    const int gi = i + pcoord[d] * n[d], gn = n[d] * pgrid[d];
+    return (gi == gn) ? length : length * ((double)gi / gn);
+  };
   // periodic images must get bit-identical displacements: evaluate them at the wrapped coordinate
-  auto wrap = [&](int i, int nn) { return (i == nn) ? 0.0 : length * ((double)i / nn); };
+  auto wrap = [&](int i, int d) {
+    const int gi = i + pcoord[d] * n[d], gn = n[d] * pgrid[d];
+    return (gi == gn) ? 0.0 : length * ((double)gi / gn);
+  };
   for (int k = 0; k <= nz; k++)
     for (int j = 0; j <= ny; j++)
       for (int i = 0; i <= nx; i++)
       {
         const int v = i + (nx + 1) * (j + (ny + 1) * k);
-        double x = coord(i, nx), y = coord(j, ny), z = (dims == 3) ? coord(k, nz) : 0.0;
+        double x = coord(i, 0), y = coord(j, 1), z = (dims == 3) ? coord(k, 2) : 0.0;
         if (amp != 0.0)
         {
-          const double xw = wrap(i, nx), yw = wrap(j, ny), zw = (dims == 3) ? wrap(k, nz) : 0.0;
+          const double xw = wrap(i, 0), yw = wrap(j, 1), zw = (dims == 3) ? wrap(k, 2) : 0.0;
           const double kk = two_pi_over_l;
           if (dims == 3)
           {
@@ -78,7 +88,6 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
 {
   input &in = S->run_input;
   S->n_dims = mesh.dims;
-  S->num_cells_global = mesh.ne();
   S->mesh_eles.setup(S->n_ele_types);
   S->mesh_eles.initialize_to_value(nullptr);
   S->mesh_eles(1) = &S->mesh_eles_quads;
@@ -86,7 +95,20 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
   const int dims = mesh.dims, nx = mesh.n[0], ny = mesh.n[1], nz = (dims == 3) ? mesh.n[2] : 1;
   const int NV = mesh.nv();
   if ((int)mesh.xv.size() != NV * dims) { S->err = "box mesh: vertex array has the wrong size"; return 1; }
-  if (nx < 3 || ny < 3 || (dims == 3 && nz < 3)) { S->err = "box mesh: need >= 3 cells per direction (periodic matching)"; return 1; }
+  {
+    const int nn[3] = {nx, ny, nz};
+    int np = 1;
+    for (int d = 0; d < dims; d++)
+    {
+      np *= mesh.pgrid[d];
+      if (mesh.pgrid[d] < 1 || mesh.pcoord[d] < 0 || mesh.pcoord[d] >= mesh.pgrid[d]) { S->err = "box mesh: bad process grid"; return 1; }
+      if (mesh.pgrid[d] == 1 && nn[d] < 3) { S->err = "box mesh: need >= 3 cells per direction (periodic matching)"; return 1; }
+      if (mesh.pgrid[d] > 1 && nn[d] < 2) { S->err = "box mesh: need >= 2 cells per partitioned direction"; return 1; }
+    }
+    if (np != S->nproc) { S->err = "box mesh: process grid does not match nproc"; return 1; }
+    if (mesh.rank_of(mesh.pcoord[0], mesh.pcoord[1], dims == 3 ? mesh.pcoord[2] : 0) != S->rank) { S->err = "box mesh: process coordinates do not match rank"; return 1; }
+    S->num_cells_global = mesh.ne() * np;
+  }
 
   eles *E = (dims == 3) ? (eles *)&S->mesh_eles_hexas : (eles *)&S->mesh_eles_quads;
   const int etype = (dims == 3) ? 4 : 1;
@@ -131,15 +153,67 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
   // (src/inters.cpp:568-581), and on meshes whose face normals carry rounding noise in n_x the
   // outcome depends on which side is left.
   S->mesh_int_inters.setup(S->n_int_inter_types);
+  S->mesh_mpi_inters.setup(S->n_mpi_inter_types);
   const int ftype = (dims == 3) ? 2 : 0;
-  const int n_faces = dims * mesh.ne();
-  for (int t = 0; t < 3; t++) S->mesh_int_inters(t).setup(t == ftype ? n_faces : 0, t, &in);
-  int_inters &I = S->mesh_int_inters(ftype);
   // local face -> (axis, direction, neighbour's local face)
   static const int hex_face[6][3] = {{2, -1, 5}, {1, -1, 3}, {0, 1, 4}, {1, 1, 1}, {0, -1, 2}, {2, 1, 0}};
   static const int quad_face[4][3] = {{1, -1, 2}, {0, 1, 3}, {1, 1, 0}, {0, -1, 1}};
   const int nfaces_loc = (dims == 3) ? 6 : 4;
+  const int nn[3] = {nx, ny, nz};
   const double tol = 1e-8 * mesh.length;
+
+  // pass 1: count.  A face whose neighbour cell lives on another rank is a partition face
+  // (src/mesh.cpp match_mpifaces / src/geometry.cpp:566-663 build the same lists from ParMETIS output).
+  struct mpi_face { int nbr, key_e, key_f, e, f; };
+  std::vector<mpi_face> mf;
+  int n_int = 0;
+  for (int k = 0; k < nz; k++)
+    for (int j = 0; j < ny; j++)
+      for (int i = 0; i < nx; i++)
+      {
+        const int e = i + nx * (j + ny * k);
+        for (int f = 0; f < nfaces_loc; f++)
+        {
+          const int *fd = (dims == 3) ? hex_face[f] : quad_face[f];
+          const int d = fd[0];
+          int c[3] = {i, j, k};
+          c[d] += fd[1];
+          const bool outside = c[d] < 0 || c[d] >= nn[d];
+          c[d] = (c[d] + nn[d]) % nn[d];
+          const int er = c[0] + nx * (c[1] + ny * c[2]);
+          if (outside && mesh.pgrid[d] > 1)
+          {
+            int pc[3] = {mesh.pcoord[0], mesh.pcoord[1], dims == 3 ? mesh.pcoord[2] : 0};
+            pc[d] = (pc[d] + fd[1] + mesh.pgrid[d]) % mesh.pgrid[d];
+            const int nbr = mesh.rank_of(pc[0], pc[1], pc[2]);
+            // both sides list the faces they share in the order of the lower rank's (cell, local face)
+            mpi_face m = {nbr, (S->rank < nbr) ? e : er, (S->rank < nbr) ? f : fd[2], e, f};
+            mf.push_back(m);
+          }
+          else if (er >= e)
+            n_int++;
+        }
+      }
+  std::sort(mf.begin(), mf.end(), [](const mpi_face &a, const mpi_face &b) {
+    if (a.nbr != b.nbr) return a.nbr < b.nbr;
+    if (a.key_e != b.key_e) return a.key_e < b.key_e;
+    return a.key_f < b.key_f;
+  });
+  S->n_mpi_inters = (int)mf.size();
+
+  for (int t = 0; t < 3; t++) S->mesh_int_inters(t).setup(t == ftype ? n_int : 0, t, &in);
+  for (int t = 0; t < 3; t++)
+  {
+    S->mesh_mpi_inters(t).setup(t == ftype ? S->n_mpi_inters : 0, t, &in);
+    S->mesh_mpi_inters(t).set_nproc(S->nproc, S->rank);
+  }
+  int_inters &I = S->mesh_int_inters(ftype);
+  // interior faces.  Same numbering and left/right orientation as the reference derives from the
+  // mesh (src/mesh.cpp set_face_connectivity + src/geometry.cpp:351-415): cells ascending, local
+  // faces ascending, a face is created by the first (= lower-numbered) cell that meets it, which
+  // becomes its LEFT side.  The orientation matters: the LDG switch reads the left normal only
+  // (src/inters.cpp:568-581), and on meshes whose face normals carry rounding noise in n_x the
+  // outcome depends on which side is left.
   int fi = 0;
   for (int k = 0; k < nz; k++)
     for (int j = 0; j < ny; j++)
@@ -149,9 +223,11 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
         for (int f = 0; f < nfaces_loc; f++)
         {
           const int *fd = (dims == 3) ? hex_face[f] : quad_face[f];
+          const int d = fd[0];
           int c[3] = {i, j, k};
-          const int nn[3] = {nx, ny, nz};
-          c[fd[0]] = (c[fd[0]] + fd[1] + nn[fd[0]]) % nn[fd[0]];
+          c[d] += fd[1];
+          if ((c[d] < 0 || c[d] >= nn[d]) && mesh.pgrid[d] > 1) continue; // partition face
+          c[d] = (c[d] + nn[d]) % nn[d];
           const int er = c[0] + nx * (c[1] + ny * c[2]);
           if (er < e) continue; // created from the other side already
           const int rot = find_rot_tag(I, E, E, e, er, f, fd[2], dims, mesh.length, tol);
@@ -159,8 +235,36 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
           I.set_interior(fi++, etype, etype, e, er, f, fd[2], rot, S);
         }
       }
-  if (fi != n_faces) { S->err = "box mesh: face count mismatch"; return 1; }
+  if (fi != n_int) { S->err = "box mesh: face count mismatch"; return 1; }
   if (I.failed()) { S->err = I.last_error(); return 1; }
+
+  // partition faces: the rotation tag of a (local face, remote face) pair is topological on the
+  // structured box; read it off an adjacent pair of local cells with the same two local faces
+  if (S->n_mpi_inters)
+  {
+    mpi_inters &M = S->mesh_mpi_inters(ftype);
+    int rot_of_face[6];
+    for (int f = 0; f < nfaces_loc; f++)
+    {
+      const int *fd = (dims == 3) ? hex_face[f] : quad_face[f];
+      const int d = fd[0];
+      int c[3] = {0, 0, 0};
+      c[d] = (fd[1] > 0) ? 0 : nn[d] - 1;
+      const int ea = c[0] + nx * (c[1] + ny * c[2]);
+      c[d] += fd[1];
+      const int eb = c[0] + nx * (c[1] + ny * c[2]);
+      rot_of_face[f] = find_rot_tag(I, E, E, ea, eb, f, fd[2], dims, mesh.length, tol);
+      if (rot_of_face[f] < 0) { S->err = "Can't find coupled cyclic interface"; return 1; }
+    }
+    std::vector<int> nout(S->nproc, 0);
+    for (size_t m = 0; m < mf.size(); m++)
+    {
+      M.set_mpi((int)m, etype, mf[m].e, mf[m].f, rot_of_face[mf[m].f], S);
+      nout[mf[m].nbr]++;
+    }
+    for (int p = 0; p < S->nproc; p++) M.set_nout_proc(nout[p], p);
+    if (M.failed()) { S->err = M.last_error(); return 1; }
+  }
   return 0;
 }
 
@@ -184,6 +288,8 @@ int MoveToDevice(solution *S, int device)
       if (S->mesh_eles(i)->mv_all_cpu_gpu(S->ctx)) { S->err = S->mesh_eles(i)->last_error(); return 1; }
   for (int i = 0; i < S->n_int_inter_types; i++)
     if (S->mesh_int_inters(i).mv_all_cpu_gpu(S->ctx, S)) { S->err = S->mesh_int_inters(i).last_error(); return 1; }
+  for (int i = 0; i < S->n_mpi_inter_types; i++)
+    if (S->mesh_mpi_inters(i).mv_all_cpu_gpu(S->ctx, S)) { S->err = S->mesh_mpi_inters(i).last_error(); return 1; }
   return 0;
 }
 
@@ -197,6 +303,9 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   };
   /*! Extrapolate the solution to the flux points. */
   each_ele(&eles::extrapolate_solution);
+  /*! Send the solution at the flux points across the MPI interfaces. */
+  if (FlowSol->nproc > 1)
+    for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_solution();
   if (FlowSol->run_input.viscous)
     /*! Compute the uncorrected transformed gradient of the solution at the solution points. */
     each_ele(&eles::calculate_gradient);
@@ -204,10 +313,18 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   each_ele(&eles::evaluate_invFlux);
   /*! Compute the transformed normal inviscid numerical fluxes, common solution and corrections. */
   for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_invFlux();
+  if (FlowSol->nproc > 1)
+  {
+    for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_solution();
+    for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).calculate_common_invFlux();
+  }
   if (FlowSol->run_input.viscous)
   {
     /*! Compute physical corrected gradient of the solution at the solution and flux points. */
     each_ele(&eles::correct_gradient);
+    /*! Send the corrected physical gradients across the MPI interface. */
+    if (FlowSol->nproc > 1)
+      for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_corrected_gradient();
     /*! Compute discontinuous transformed viscous flux at upts and add to total transformed flux. */
     each_ele(&eles::evaluate_viscFlux);
   }
@@ -216,8 +333,16 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   /*! Compute the transformed divergence of total flux at solution points. */
   each_ele(&eles::calculate_divergence);
   if (FlowSol->run_input.viscous)
+  {
     /*! Compute transformed normal interface viscous flux and add to transformed normal inviscid flux. */
     for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_viscFlux();
+    /*! Evaluate the MPI interfaces. */
+    if (FlowSol->nproc > 1)
+    {
+      for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_corrected_gradient();
+      for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).calculate_common_viscFlux();
+    }
+  }
   /*! Compute the transformed divergence of the continuous flux. */
   each_ele(&eles::calculate_corrected_divergence);
 }
@@ -248,5 +373,61 @@ int RunSteps(solution *FlowSol, int n_steps)
       FlowSol->err = FlowSol->mesh_int_inters(j).last_error();
       return 1;
     }
+  for (int j = 0; j < FlowSol->n_mpi_inter_types; j++)
+    if (FlowSol->mesh_mpi_inters(j).failed())
+    {
+      FlowSol->err = FlowSol->mesh_mpi_inters(j).last_error();
+      return 1;
+    }
+  return 0;
+}
+
+void SetExchange(solution *FlowSol, hfxh_exchange_fn fn, void *user)
+{
+  FlowSol->exchange = fn;
+  FlowSol->exchange_user = user;
+  for (int j = 0; j < FlowSol->n_mpi_inter_types; j++) FlowSol->mesh_mpi_inters(j).set_exchange(fn, user);
+}
+
+int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
+{
+  // one tensor-product class, one interior block, at most one partition block
+  eles *E = nullptr;
+  for (int j = 0; j < FlowSol->n_ele_types; j++)
+    if (FlowSol->mesh_eles(j) && FlowSol->mesh_eles(j)->get_n_eles() != 0)
+    {
+      if (E) { FlowSol->err = "RunStepsPartitionedFused: one element class only"; return 1; }
+      E = FlowSol->mesh_eles(j);
+    }
+  if (!E) { FlowSol->err = "RunStepsPartitionedFused: no elements"; return 1; }
+  std::vector<hfx_inters *> fi, fm;
+  for (int j = 0; j < FlowSol->n_int_inter_types; j++)
+    if (FlowSol->mesh_int_inters(j).get_n_inters()) fi.push_back(FlowSol->mesh_int_inters(j).device());
+  for (int j = 0; j < FlowSol->n_mpi_inter_types; j++)
+    if (FlowSol->mesh_mpi_inters(j).get_n_inters()) fm.push_back(FlowSol->mesh_mpi_inters(j).device());
+  const int RKSteps = FlowSol->run_input.n_rk_stages();
+  const bool ex = !fm.empty() && FlowSol->exchange;
+  auto phase = [&](int ph, int stage, int first) {
+    return hfx_stage_partitioned(E->device(), fi.data(), (int)fi.size(), fm.data(), (int)fm.size(), ph, stage, first);
+  };
+  bool first = true;
+  for (int i_steps = 0; i_steps < n_steps; i_steps++)
+  {
+    for (int i = 0; i < RKSteps; i++)
+    {
+      if (first)
+      {
+        if (phase(0, i, 1)) { FlowSol->err = hfx_last_error(); return 1; }
+        first = false;
+      }
+      // the packed solution of this stage (phase 0, or phase 2 of the previous stage) crosses here
+      if (ex) { FlowSol->exchange(FlowSol->exchange_user, 0, 0); FlowSol->exchange(FlowSol->exchange_user, 0, 1); }
+      if (phase(1, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
+      if (ex && FlowSol->run_input.viscous) { FlowSol->exchange(FlowSol->exchange_user, 1, 0); FlowSol->exchange(FlowSol->exchange_user, 1, 1); }
+      if (phase(2, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
+    }
+    FlowSol->time += FlowSol->run_input.dt;
+    FlowSol->run_input.time = FlowSol->time;
+  }
   return 0;
 }

@@ -22,8 +22,14 @@ struct solution
   eles_hexas mesh_eles_hexas;
   int n_int_inter_types = 3;
   hf_array<int_inters> mesh_int_inters;
+  // partition faces (include/solution.h:88-94, _MPI only in the reference)
+  int n_mpi_inter_types = 3;
+  hf_array<mpi_inters> mesh_mpi_inters;
+  int n_mpi_inters = 0;
   input run_input;
   hfx_ctx *ctx = nullptr;
+  hfxh_exchange_fn exchange = nullptr;
+  void *exchange_user = nullptr;
   std::string err;
   ~solution();
 };
@@ -33,8 +39,13 @@ struct solution
 // xv[v + nv*d], v = ix + (nx+1)*(iy + (ny+1)*iz).
 struct box_mesh
 {
-  int dims = 3, n[3] = {1, 1, 1};
-  double length = 0.0, amp = 0.0;
+  int dims = 3, n[3] = {1, 1, 1}; // cells of THIS rank's block
+  double length = 0.0, amp = 0.0; // edge of the GLOBAL periodic box
+  // block decomposition of the structured box: pgrid ranks per direction, this rank's coordinates.
+  // The reference partitions with ParMETIS (src/mesh.cpp:72-314), which is not available; the
+  // structured block split is the documented stand-in.
+  int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
+  int rank_of(int px, int py, int pz) const { return px + pgrid[0] * (py + pgrid[1] * pz); }
   std::vector<double> xv; // (nv, dims) column-major
   int nv() const { return (n[0] + 1) * (n[1] + 1) * (dims == 3 ? n[2] + 1 : 1); }
   int ne() const { return n[0] * n[1] * (dims == 3 ? n[2] : 1); }
@@ -51,3 +62,7 @@ int MoveToDevice(solution *FlowSol, int device);
 void CalcResidual(int in_file_num, int in_rk_stage, solution *FlowSol);
 // RK loop of src/HiFiLES.cpp:194-221 through the mirrored class methods
 int RunSteps(solution *FlowSol, int n_steps);
+// the same RK loop through the split fused kernels on a partitioned block, exchanging between the
+// phases of hfx_stage_partitioned
+int RunStepsPartitionedFused(solution *FlowSol, int n_steps);
+void SetExchange(solution *FlowSol, hfxh_exchange_fn fn, void *user);

@@ -1,0 +1,168 @@
+// kernels_mpi.hpp -- partition faces (reference class mpi_inters, /root/reference/src/mpi_inters.cpp).
+//
+// A partition face has only its LEFT side on this rank.  The right state is read from the
+// received buffer: record (fpt, field[, dim], inter) of the neighbour's packed face, at the
+// neighbour's flux-point slot lut(j) (mpi_inters::set_mpi, src/mpi_inters.cpp:165-172).  Both
+// ranks evaluate the common flux from their own side as "left"; the results agree to rounding.
+#pragma once
+#include "hfx_internal.hpp"
+
+namespace hfx
+{
+
+struct MpiArgs
+{
+  long npairs; // n_fpts_per_inter * n_inters
+  int nfpi;
+  const int *L, *Rlut;
+  long plane; // n_fpts*n_eles of the left block
+  const double *disu, *grad, *norm, *tdA;
+  double *tconf, *delta;
+  double *out_disu, *out_grad;
+  const double *in_disu, *in_grad;
+  Phys P;
+  int accumulate; // split path: 0 write the total common flux, per-method viscous call: 1 (+=)
+};
+
+// out_buffer_disu(fpt, field, inter) = disu_fpts_l   (src/mpi_inters.cpp:225-229)
+template <int ND>
+__global__ __launch_bounds__(256) void mpi_pack_disu_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const int j = (int)(q - i * a.nfpi);
+  const long il = a.L[q];
+#pragma unroll
+  for (int k = 0; k < NF; k++) a.out_disu[j + (long)a.nfpi * (k + NF * i)] = a.disu[il + k * a.plane];
+}
+
+// out_buffer_grad_disu(fpt, field, dim, inter) = grad_disu_fpts_l   (src/mpi_inters.cpp:284-289)
+template <int ND>
+__global__ __launch_bounds__(256) void mpi_pack_grad_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const int j = (int)(q - i * a.nfpi);
+  const long il = a.L[q];
+#pragma unroll
+  for (int s = 0; s < NF * ND; s++) a.out_grad[j + (long)a.nfpi * (s + NF * ND * i)] = a.grad[il + s * a.plane];
+}
+
+// mpi_inters::calculate_common_invFlux (src/mpi_inters.cpp:400-483): writes the LEFT side only
+template <int ND, bool FAST>
+__global__ __launch_bounds__(256) void mpi_common_invflux_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const long il = a.L[q];
+  const int jr = a.Rlut[q];
+  double ul[NF], ur[NF], n[ND], fn[NF];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu[il + k * a.plane];
+    ur[k] = a.in_disu[jr + (long)a.nfpi * (k + NF * i)];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.norm[il + m * a.plane];
+  if (FAST)
+  {
+    if (a.P.riemann == 0)
+      riemann_flux_t<ND, 0, true>(a.P, ul, ur, n, fn);
+    else if (a.P.riemann == 2)
+      riemann_flux_t<ND, 2, true>(a.P, ul, ur, n, fn);
+    else
+      riemann_flux_t<ND, 3, true>(a.P, ul, ur, n, fn);
+  }
+  else
+    riemann_flux<ND>(a.P, ul, ur, n, fn);
+  const double tl = a.tdA[il];
+#pragma unroll
+  for (int k = 0; k < NF; k++) a.tconf[il + k * a.plane] = fn[k] * tl;
+  if (a.P.viscous && a.delta != nullptr)
+  {
+    const double beta = ldg_switch<ND>(a.P.ldg_beta, n);
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      const double uc = 0.5 * (ul[k] + ur[k]) - beta * (ul[k] - ur[k]);
+      a.delta[il + k * a.plane] = uc - ul[k];
+    }
+  }
+}
+
+// LDG common solution only (split path, phase 1)
+template <int ND>
+__global__ __launch_bounds__(256) void mpi_delta_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const long il = a.L[q];
+  const int jr = a.Rlut[q];
+  double n[ND];
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.norm[il + m * a.plane];
+  const double beta = ldg_switch<ND>(a.P.ldg_beta, n);
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    const double ul = a.disu[il + k * a.plane];
+    const double ur = a.in_disu[jr + (long)a.nfpi * (k + NF * i)];
+    const double uc = 0.5 * (ul + ur) - beta * (ul - ur);
+    a.delta[il + k * a.plane] = uc - ul;
+  }
+}
+
+// mpi_inters::calculate_common_viscFlux (src/mpi_inters.cpp:485-576): norm_tconf_l += fn_v * tdA_l
+template <int ND, bool FAST>
+__global__ __launch_bounds__(256) void mpi_common_viscflux_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2, NG = NF * ND;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const long il = a.L[q];
+  const int jr = a.Rlut[q];
+  double ul[NF], ur[NF], gl[NG], gr[NG], fl[NG], fr[NG], n[ND];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu[il + k * a.plane];
+    ur[k] = a.in_disu[jr + (long)a.nfpi * (k + NF * i)];
+  }
+#pragma unroll
+  for (int s = 0; s < NG; s++)
+  {
+    gl[s] = a.grad[il + s * a.plane];
+    gr[s] = a.in_grad[jr + (long)a.nfpi * (s + NG * i)];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.norm[il + m * a.plane];
+  calc_visf<ND, FAST>(a.P, ul, gl, fl);
+  calc_visf<ND, FAST>(a.P, ur, gr, fr);
+  const double beta = ldg_switch<ND>(a.P.ldg_beta, n);
+  const double tl = a.tdA[il];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    double fn = 0.0;
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      const double fc = (0.5 + beta) * fl[k + NF * l] + (0.5 - beta) * fr[k + NF * l];
+      fn += fc * n[l];
+    }
+    fn -= a.P.ldg_tau * (ur[k] - ul[k]);
+    a.tconf[il + k * a.plane] += fn * tl;
+  }
+}
+
+} // namespace hfx

@@ -1,0 +1,125 @@
+"""Partition-face exchange: the transport the reference gets from MPI_Isend / MPI_Irecv / MPI_Waitall
+(/root/reference/src/mpi_inters.cpp:244-270, 304-332), done with torch.distributed point-to-point ops --
+RCCL over xGMI on device buffers (backend "nccl"), or gloo on host tensors (CPU tests; device buffers
+are staged through pinned host memory).  Plumbing only: packing and the one-sided flux kernels are libhfx.
+
+The faces shared with one rank are contiguous in the out/in buffers (record = one face), so each
+neighbour gets ONE message per exchange: out[start:start+count] -> its in[start':start'+count].
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevBuf:
+    """__cuda_array_interface__ view of a raw device pointer owned by libhfx."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, n, device):
+    return torch.as_tensor(_DevBuf(ptr, n), device=device)
+
+
+def segments(nout_proc, rank):
+    """[(peer, first face, faces)] in buffer order."""
+    seg, start = [], 0
+    for p, c in enumerate(np.asarray(nout_proc).tolist()):
+        if c:
+            assert p != rank
+            seg.append((p, start, c))
+            start += c
+    return seg
+
+
+class Exchange:
+    """out/in tensor pairs per kind (0 solution, 1 corrected gradient); tensors are flat float64.
+
+    CPU tensors go straight through the process group.  Device tensors go through the group directly
+    when it is RCCL, and through pinned host staging when it is gloo."""
+
+    def __init__(self, nout_proc, rank, bufs, group=None, stream=None):
+        self.seg = segments(nout_proc, rank)
+        self.n_faces = sum(c for _, _, c in self.seg)
+        self.bufs = bufs  # {kind: (out, in)}
+        self.group = group
+        self.backend = dist.get_backend(group)
+        self.stream = stream  # torch.cuda.ExternalStream of the hfx context (device buffers)
+        self.pending = []
+        self.stage = {}
+        for kind, (o, i) in bufs.items():
+            assert o.numel() == i.numel() and (self.n_faces == 0 or o.numel() % self.n_faces == 0)
+            if o.is_cuda and self.backend != "nccl":
+                self.stage[kind] = (torch.empty(o.numel(), dtype=o.dtype).pin_memory(),
+                                    torch.empty(i.numel(), dtype=i.dtype).pin_memory())
+
+    def _rec(self, kind):
+        return self.bufs[kind][0].numel() // max(1, self.n_faces)
+
+    def start(self, kind):
+        o, i = self.bufs[kind]
+        rec = self._rec(kind)
+        if not self.seg:
+            return
+        if o.is_cuda and self.backend == "nccl":
+            with torch.cuda.stream(self.stream):
+                ops = []
+                for p, s, c in self.seg:
+                    ops.append(dist.P2POp(dist.isend, o[s * rec:(s + c) * rec], p, self.group))
+                    ops.append(dist.P2POp(dist.irecv, i[s * rec:(s + c) * rec], p, self.group))
+                self.pending.append((kind, dist.batch_isend_irecv(ops)))
+            return
+        if o.is_cuda:
+            so, si = self.stage[kind]
+            with torch.cuda.stream(self.stream):
+                so.copy_(o, non_blocking=True)
+            self.stream.synchronize()
+            o, i = so, si
+        reqs = []
+        for p, s, c in self.seg:
+            reqs.append(dist.irecv(i[s * rec:(s + c) * rec], src=p, group=self.group, tag=kind))
+        for p, s, c in self.seg:
+            reqs.append(dist.isend(o[s * rec:(s + c) * rec], dst=p, group=self.group, tag=kind))
+        self.pending.append((kind, reqs))
+
+    def wait(self, kind):
+        keep = []
+        for k, reqs in self.pending:
+            if k != kind:
+                keep.append((k, reqs))
+                continue
+            o, i = self.bufs[k]
+            if o.is_cuda and self.backend == "nccl":
+                with torch.cuda.stream(self.stream):
+                    for r in reqs:
+                        r.wait()
+            else:
+                for r in reqs:
+                    r.wait()
+                if o.is_cuda:
+                    with torch.cuda.stream(self.stream):
+                        i.copy_(self.stage[k][1], non_blocking=True)
+        self.pending = keep
+
+    def __call__(self, kind, phase):
+        (self.start if phase == 0 else self.wait)(kind)
+
+
+def for_case(case, group=None, device=None):
+    """Exchange wired to the device buffers of a partitioned hfx_host.Case that is on the device."""
+    import hfx
+    L, Rlut, nout = case.mpi_faces()
+    h = case.mpi_handle()
+    if not h:
+        return None
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    t = [device_tensor(*hfx.mpi_buffer(h, w), device) for w in range(4)]
+    stream = torch.cuda.ExternalStream(case.stream(), device=device)
+    p = case.params()
+    bufs = {0: (t[0], t[1])}
+    if p.viscous:
+        bufs[1] = (t[2], t[3])
+    return Exchange(nout, case.rank, bufs, group=group, stream=stream)

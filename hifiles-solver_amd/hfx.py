@@ -199,6 +199,47 @@ class IntInters:
             self.h = C.c_void_p()
 
 
+class MpiInters:
+    """Partition-face block (mpi_inters): one-sided faces whose right state arrives in in_buffer_*."""
+
+    def __init__(self, ctx, left, L, Rlut):
+        L = np.asfortranarray(np.array(L, dtype=np.int32))
+        Rlut = np.asfortranarray(np.array(Rlut, dtype=np.int32))
+        self.n_fpts_per_inter, self.n_inters = L.shape
+        self.h = C.c_void_p()
+        check(lib().hfx_mpi_inters_create(ctx.h, left.h, C.c_int(self.n_inters), C.c_int(self.n_fpts_per_inter),
+                                          L.ctypes.data_as(ip), Rlut.ctypes.data_as(ip), C.byref(self.h)))
+
+    def pack_solution(self): check(lib().hfx_mpi_inters_pack_solution(self.h))
+    def pack_corrected_gradient(self): check(lib().hfx_mpi_inters_pack_corrected_gradient(self.h))
+    def calculate_common_invFlux(self): check(lib().hfx_mpi_inters_calculate_common_invFlux(self.h))
+    def calculate_common_viscFlux(self): check(lib().hfx_mpi_inters_calculate_common_viscFlux(self.h))
+
+    def buffer(self, which):
+        """(device pointer, doubles) of 0 out_buffer_disu, 1 in_buffer_disu, 2 out_buffer_grad_disu, 3 in_buffer_grad_disu."""
+        return mpi_buffer(self.h, which)
+
+    def close(self):
+        if self.h:
+            lib().hfx_inters_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def mpi_buffer(handle, which):
+    p = dp()
+    n = C.c_size_t(0)
+    check(lib().hfx_mpi_inters_buffer(handle, C.c_int(which), C.byref(p), C.byref(n)))
+    return C.cast(p, C.c_void_p).value, n.value
+
+
+def stage_partitioned(eles_h, int_faces, mpi_faces, phase, in_step, first):
+    """hfx_stage_partitioned on raw handles (lists of c_void_p)."""
+    fi = (C.c_void_p * max(1, len(int_faces)))(*int_faces)
+    fm = (C.c_void_p * max(1, len(mpi_faces)))(*mpi_faces)
+    check(lib().hfx_stage_partitioned(eles_h, fi, C.c_int(len(int_faces)), fm, C.c_int(len(mpi_faces)),
+                                      C.c_int(phase), C.c_int(in_step), C.c_int(first)))
+
+
 def _face_array(faces):
     arr = (C.c_void_p * max(1, len(faces)))()
     for i, f in enumerate(faces):

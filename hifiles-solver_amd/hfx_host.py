@@ -22,7 +22,10 @@ class CaseDesc(C.Structure):
                 ("dt", C.c_double), ("ldg_beta", C.c_double), ("ldg_tau", C.c_double)] + \
                [(k, C.c_double) for k in ("gamma", "prandtl", "S_gas", "T_gas", "R_gas", "mu_gas",
                                           "Mach_free_stream", "rho_free_stream", "L_free_stream", "T_free_stream",
-                                          "rho_c_ic", "Mach_c_ic", "T_c_ic", "u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic")]
+                                          "rho_c_ic", "Mach_c_ic", "T_c_ic", "u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic")] + \
+               [("rank", C.c_int), ("nproc", C.c_int), ("pgrid", C.c_int * 3)]
+
+EXCHANGE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
 
 
 # the shipped Taylor-Green case (/root/reference/testcases/navier-stokes/Taylor_Green_vortex/input_TGV_SD_hex)
@@ -52,10 +55,17 @@ def check(rc):
 
 
 class Case:
-    def __init__(self, n, xv=None, loc_1d_upts=None, **kw):
+    def __init__(self, n, xv=None, loc_1d_upts=None, rank=0, pgrid=None, **kw):
+        """n: cells per direction of THIS rank's block; pgrid: ranks per direction (None: one rank)."""
         d = CaseDesc()
         cfg = dict(TGV)
         cfg.update(kw)
+        self.rank, self.pgrid = rank, (list(pgrid) if pgrid is not None else None)
+        if pgrid is not None:
+            d.rank, d.nproc = rank, int(np.prod(pgrid))
+            for i in range(3):
+                d.pgrid[i] = pgrid[i] if i < len(pgrid) else 1
+        self.nproc = max(1, d.nproc)
         for k, v in cfg.items():
             setattr(d, k, v)
         if isinstance(n, int):
@@ -98,6 +108,32 @@ class Case:
         l = np.ctypeslib.as_array(L, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
         r = np.ctypeslib.as_array(R, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
         return l, r
+
+    def mpi_faces(self):
+        """(L, Rlut, Nout_proc) of the partition-face block."""
+        L, R, nout = ip(), ip(), ip()
+        nf, ni = C.c_int(), C.c_int()
+        check(lib().hfxh_case_get_mpi_faces(self.h, C.byref(L), C.byref(R), C.byref(nf), C.byref(ni), C.byref(nout)))
+        n = nf.value * ni.value
+        if n == 0:
+            z = np.zeros((nf.value, 0), dtype=np.int32, order="F")
+            return z, z.copy(), np.zeros(self.nproc, dtype=np.int32)
+        l = np.ctypeslib.as_array(L, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
+        r = np.ctypeslib.as_array(R, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
+        return l, r, np.ctypeslib.as_array(nout, shape=(self.nproc,)).copy()
+
+    def set_exchange(self, fn):
+        """fn(kind, phase): kind 0 solution / 1 corrected gradient, phase 0 start / 1 wait."""
+        self._cb = EXCHANGE_CB(lambda user, kind, phase: fn(kind, phase))
+        check(lib().hfxh_case_set_exchange(self.h, self._cb, None))
+
+    def mpi_handle(self):
+        f = C.c_void_p()
+        check(lib().hfxh_case_mpi_handle(self.h, C.byref(f)))
+        return f
+
+    def run_partitioned(self, n_steps):
+        check(lib().hfxh_case_run_partitioned(self.h, C.c_int(n_steps)))
 
     def params(self):
         p = hfx.Params()

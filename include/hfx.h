@@ -147,6 +147,28 @@ int hfx_inters_destroy(hfx_inters *f);
 int hfx_int_inters_calculate_common_invFlux(hfx_inters *f);  /* int_inters::calculate_common_invFlux  src/int_inters.cpp:160 */
 int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f); /* int_inters::calculate_common_viscFlux src/int_inters.cpp:254 */
 
+/* ---- partition faces (reference class mpi_inters) ------------------------ */
+/* A partition face has its LEFT side on this rank; the right state arrives through an exchange.
+ * L: (n_fpts_per_inter, n_inters) left offsets as for interior faces.
+ * Rlut: (n_fpts_per_inter, n_inters) the flux-point slot `lut(j)` of the RECEIVED face record that
+ *   meets left flux point j (mpi_inters::set_mpi wires disu_fpts_r(j,i,k) to
+ *   in_buffer_disu(lut(j), k, i), src/mpi_inters.cpp:165-172).
+ * Buffers (device, owned by the block): out/in_buffer_disu (fpt, field, inter) and
+ *   out/in_buffer_grad_disu (fpt, field, dim, inter), filled in loop order inter -> [dim ->] field -> fpt
+ *   (src/mpi_inters.cpp:56-66,225-229,284-289).  Faces of one neighbour rank are contiguous, in the
+ *   order both ranks agreed on (src/geometry.cpp:1184-1239), so a message is one contiguous slice.
+ * The exchange itself is the caller's (RCCL send/recv through torch.distributed, or MPI): it moves
+ *   out_buffer slices to the neighbours' in_buffer slices between `pack` and `calculate_common_*`. */
+int hfx_mpi_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int n_fpts_per_inter, const int *L,
+                          const int *Rlut, hfx_inters **out);
+/* the packing half of mpi_inters::send_solution / send_corrected_gradient (src/mpi_inters.cpp:218-229,278-289) */
+int hfx_mpi_inters_pack_solution(hfx_inters *f);
+int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f);
+/* device pointers and lengths (doubles) of the four buffers: which = 0 out_disu, 1 in_disu, 2 out_grad, 3 in_grad */
+int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
+int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
+int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
+
 /* ---- the caller contract ---------------------------------------------- */
 /* CalcResidual (src/solver.cpp:50-223) for one element block and its interior
  * face blocks, LES / RANS / forcing off; same call order as the reference. */
@@ -155,6 +177,19 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
  * for each stage CalcResidual + AdvanceSolution.  `fused`: 0 the per-method path, 1 the gather-style
  * fused kernels, 2 the split fused kernels (same results to rounding). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
+
+/* One RK stage of the split fused path on a PARTITIONED block, cut at the two exchange points so
+ * that the caller can move the partition-face buffers in between (the order of CalcResidual's
+ * send / receive calls, src/solver.cpp:70-72,134-138,150-154,200-209):
+ *   phase 0: flux-point solution of the current state is available (first stage: extrapolate) and
+ *            packed into out_buffer_disu                                   -> exchange solution
+ *   phase 1: LDG common solution on interior and partition faces, corrected gradients,
+ *            out_buffer_grad_disu packed                                   -> exchange gradient
+ *   phase 2: common fluxes on interior and partition faces, residual, RK update (in_step), the new
+ *            state's flux-point solution packed into out_buffer_disu       -> exchange solution
+ * `first` != 0 on the first stage after the caller changed disu_upts(0). */
+int hfx_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
+                          int n_mpi, int phase, int in_step, int first);
 
 /* ---- measurement ------------------------------------------------------- */
 /* Average duration (ms, HIP events on the context's stream) of every per-method entry

@@ -40,6 +40,10 @@ typedef struct hfxh_case_desc
   double Mach_free_stream, rho_free_stream, L_free_stream, T_free_stream;
   double rho_c_ic, Mach_c_ic, T_c_ic;     /* viscous initial condition */
   double u_c_ic, v_c_ic, w_c_ic, p_c_ic;  /* inviscid initial condition */
+  /* block decomposition (all 0: one rank).  n[] is THIS rank's block, the global box has n[d]*pgrid[d]
+   * cells per direction and edge `length`; rank = px + pgrid[0]*(py + pgrid[1]*pz).  Stands in for the
+   * reference's ParMETIS partition (src/mesh.cpp:72-314). */
+  int rank, nproc, pgrid[3];
 } hfxh_case_desc;
 
 const char *hfxh_last_error(void);
@@ -54,11 +58,24 @@ int hfxh_case_params(hfxh_case *c, hfx_params *p);
 int hfxh_case_get_array(hfxh_case *c, const char *name, const double **ptr, int dims[4]);
 int hfxh_case_get_faces(hfxh_case *c, const int **L, const int **R, int *n_fpts_per_inter, int *n_inters);
 
+/* partition faces (mpi_inters): left offsets L(j,i), received-record slots Rlut(j,i), and Nout_proc[nproc]
+ * = faces shared with each rank; a rank's faces are contiguous and ordered by rank */
+int hfxh_case_get_mpi_faces(hfxh_case *c, const int **L, const int **Rlut, int *n_fpts_per_inter, int *n_inters,
+                            const int **nout_proc);
+/* exchange hook called by mpi_inters::send_* (phase 0, after packing) and receive_* (phase 1); kind 0
+ * solution, 1 corrected gradient.  The transport (RCCL / gloo through torch.distributed) belongs to the caller. */
+typedef void (*hfxh_exchange_cb)(void *user, int kind, int phase);
+int hfxh_case_set_exchange(hfxh_case *c, hfxh_exchange_cb fn, void *user);
+
 /* device */
 int hfxh_case_to_device(hfxh_case *c, int device);
 int hfxh_case_handles(hfxh_case *c, hfx_ctx **ctx, hfx_eles **e, hfx_inters ***faces, int *n_face_blocks);
 int hfxh_case_CalcResidual(hfxh_case *c); /* the mirrored CalcResidual (src/solver.cpp:50-223) */
 int hfxh_case_run(hfxh_case *c, int n_steps); /* the mirrored RK loop (src/HiFiLES.cpp:194-221) */
+/* device handle of the partition-face block (NULL on one rank) */
+int hfxh_case_mpi_handle(hfxh_case *c, hfx_inters **f);
+/* the RK loop through hfx_stage_partitioned (split fused kernels), exchanging between its phases */
+int hfxh_case_run_partitioned(hfxh_case *c, int n_steps);
 int hfxh_case_sync_host(hfxh_case *c);        /* cp_*_gpu_cpu of state, divergence, gradient */
 
 #ifdef __cplusplus

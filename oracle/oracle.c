@@ -774,6 +774,99 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, con
 }
 
 /* ------------------------------------------------------------------------ */
+/* partition faces                                                           */
+
+/* src/mpi_inters.cpp:225-229 : counter order inter -> field -> fpt */
+void orc_mpi_pack_solution(const orc_mpi_inters *F, const orc_eles *e)
+{
+  const int nf = e->n_fields, nfi = F->n_fpts_per_inter;
+  const long plane = (long)e->n_fpts * e->n_eles;
+  long counter = 0;
+  for (int i = 0; i < F->n_inters; i++)
+    for (int k = 0; k < nf; k++)
+      for (int j = 0; j < nfi; j++) F->out_disu[counter++] = e->disu_fpts[F->L[j + (long)nfi * i] + k * plane];
+}
+
+/* src/mpi_inters.cpp:284-289 : inter -> dim -> field -> fpt */
+void orc_mpi_pack_corrected_gradient(const orc_mpi_inters *F, const orc_eles *e)
+{
+  const int nf = e->n_fields, nd = e->n_dims, nfi = F->n_fpts_per_inter;
+  const long plane = (long)e->n_fpts * e->n_eles;
+  long counter = 0;
+  for (int i = 0; i < F->n_inters; i++)
+    for (int m = 0; m < nd; m++)
+      for (int k = 0; k < nf; k++)
+        for (int j = 0; j < nfi; j++)
+          F->out_grad[counter++] = e->grad_disu_fpts[F->L[j + (long)nfi * i] + (k + (long)nf * m) * plane];
+}
+
+/* src/mpi_inters.cpp:400-483 */
+void orc_mpi_calculate_common_invFlux(const orc_mpi_inters *F, orc_eles *e, const orc_params *P)
+{
+  const int nd = e->n_dims, nf = e->n_fields, nfi = F->n_fpts_per_inter;
+  const long plane = (long)e->n_fpts * e->n_eles;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < F->n_inters; i++)
+    for (int j = 0; j < nfi; j++)
+    {
+      const long il = F->L[j + (long)nfi * i];
+      const int jr = F->Rlut[j + (long)nfi * i];
+      double ul[MAXF], ur[MAXF], fl[MAXF * MAXD], fr[MAXF * MAXD], norm[MAXD], fn[MAXF], uc[MAXF];
+      for (int k = 0; k < nf; k++)
+      {
+        ul[k] = e->disu_fpts[il + k * plane];
+        ur[k] = F->in_disu[jr + (long)nfi * (k + (long)nf * i)];
+      }
+      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      orc_calc_invf(nd, P->gamma, ul, fl);
+      orc_calc_invf(nd, P->gamma, ur, fr);
+      if (P->riemann_solve_type == 0)
+        orc_rusanov_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      else if (P->riemann_solve_type == 2)
+        orc_roeM_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      else
+        orc_hllc_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      for (int k = 0; k < nf; k++) e->norm_tconf_fpts[il + k * plane] = fn[k] * e->tdA_fpts[il];
+      if (P->viscous)
+      {
+        orc_ldg_solution(0, nd, ul, ur, uc, P->ldg_beta, norm);
+        for (int k = 0; k < nf; k++) e->delta_disu_fpts[il + k * plane] = (uc[k] - ul[k]);
+      }
+    }
+}
+
+/* src/mpi_inters.cpp:485-576 (LES off) */
+void orc_mpi_calculate_common_viscFlux(const orc_mpi_inters *F, orc_eles *e, const orc_params *P)
+{
+  const int nd = e->n_dims, nf = e->n_fields, nfi = F->n_fpts_per_inter;
+  const long plane = (long)e->n_fpts * e->n_eles;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < F->n_inters; i++)
+    for (int j = 0; j < nfi; j++)
+    {
+      const long il = F->L[j + (long)nfi * i];
+      const int jr = F->Rlut[j + (long)nfi * i];
+      double ul[MAXF], ur[MAXF], gl[MAXF * MAXD], gr[MAXF * MAXD], fl[MAXF * MAXD], fr[MAXF * MAXD], norm[MAXD], fn[MAXF];
+      for (int k = 0; k < nf; k++)
+      {
+        ul[k] = e->disu_fpts[il + k * plane];
+        ur[k] = F->in_disu[jr + (long)nfi * (k + (long)nf * i)];
+      }
+      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      for (int k = 0; k < nd; k++)
+        for (int l = 0; l < nf; l++)
+        {
+          gl[l + nf * k] = e->grad_disu_fpts[il + (l + (long)nf * k) * plane];
+          gr[l + nf * k] = F->in_grad[jr + (long)nfi * (l + (long)nf * (k + (long)nd * i))];
+        }
+      orc_calc_visf(nd, P, ul, gl, fl);
+      orc_calc_visf(nd, P, ur, gr, fr);
+      orc_ldg_flux(0, nd, ul, ur, fl, fr, norm, fn, P->ldg_tau, P->ldg_beta);
+      for (int k = 0; k < nf; k++) e->norm_tconf_fpts[il + k * plane] += fn[k] * e->tdA_fpts[il];
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* src/solver.cpp:50-223, single rank, LES / RANS / forcing / over_int off   */
 long orc_CalcResidual(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *P)
 {

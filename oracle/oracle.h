@@ -75,6 +75,20 @@ typedef struct orc_int_inters
   const int *R; /* same for the right side, permutation `lut` already applied */
 } orc_int_inters;
 
+/* partition faces (reference class mpi_inters, src/mpi_inters.cpp): left side local, right side in the
+ * received buffer at slot Rlut(j) = lut(j) of record (fpt, field[, dim], inter) (set_mpi :165-172).
+ * PARITY NOTE: the reference's MPI build cannot be compiled in the build container (no ParMETIS), so
+ * these four functions are pinned through partition invariance (N-rank run == 1-rank run of the pinned
+ * single-rank oracle, tests/test_partition_gloo.py), not against reference output. */
+typedef struct orc_mpi_inters
+{
+  int n_inters, n_fpts_per_inter;
+  const int *L;    /* (n_fpts_per_inter,n_inters) left offsets */
+  const int *Rlut; /* (n_fpts_per_inter,n_inters) flux-point slot in the received face record */
+  double *out_disu, *in_disu; /* (n_fpts_per_inter,n_fields,n_inters) */
+  double *out_grad, *in_grad; /* (n_fpts_per_inter,n_fields,n_dims,n_inters) */
+} orc_mpi_inters;
+
 void orc_set_threads(int n);
 
 /* src/funcs.cpp:49-123 */
@@ -112,6 +126,12 @@ double orc_compute_res_upts(const orc_eles *e, int norm_type, int field);
 /* face methods: src/int_inters.cpp */
 void orc_int_calculate_common_invFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p);  /* :160 */
 void orc_int_calculate_common_viscFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p); /* :254 */
+
+/* partition faces: src/mpi_inters.cpp */
+void orc_mpi_pack_solution(const orc_mpi_inters *f, const orc_eles *e);           /* :218-229 */
+void orc_mpi_pack_corrected_gradient(const orc_mpi_inters *f, const orc_eles *e); /* :278-289 */
+void orc_mpi_calculate_common_invFlux(const orc_mpi_inters *f, orc_eles *e, const orc_params *p);  /* :400 */
+void orc_mpi_calculate_common_viscFlux(const orc_mpi_inters *f, orc_eles *e, const orc_params *p); /* :485 */
 
 /* the caller contract: src/solver.cpp:50-223 (single rank, LES/RANS/forcing off) */
 long orc_CalcResidual(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *p);

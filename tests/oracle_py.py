@@ -147,3 +147,74 @@ class Case:
             arr[i].L = iptr(L); arr[i].R = iptr(R)
         self._f = arr
         return arr, len(self.faces)
+
+
+class MpiInters(C.Structure):
+    _fields_ = [("n_inters", C.c_int), ("n_fpts_per_inter", C.c_int), ("L", ip), ("Rlut", ip),
+                ("out_disu", dp), ("in_disu", dp), ("out_grad", dp), ("in_grad", dp)]
+
+
+class PartitionedCase(Case):
+    """Case + one partition-face block; CalcResidual in the reference's MPI call order
+    (/root/reference/src/solver.cpp:64-211) with the exchange supplied by the caller:
+    exchange(kind, phase), kind 0 solution / 1 corrected gradient, phase 0 start / 1 wait."""
+
+    def __init__(self, data, L, Rlut, exchange=None):
+        super().__init__(data)
+        self.mL = np.asfortranarray(np.array(L, dtype=np.int32))
+        self.mR = np.asfortranarray(np.array(Rlut, dtype=np.int32))
+        nfpi, ni = self.mL.shape
+        nf, nd = self.n_fields, self.n_dims
+        # flat buffers: the exchange slices them by face record
+        self.buf = {k: np.zeros(nfpi * nf * ni * (nd if "grad" in k else 1)) for k in
+                    ("out_disu", "in_disu", "out_grad", "in_grad")}
+        self.exchange = exchange or (lambda kind, phase: None)
+
+    def c_mpi(self):
+        m = MpiInters()
+        m.n_fpts_per_inter, m.n_inters = self.mL.shape
+        m.L, m.Rlut = iptr(self.mL), iptr(self.mR)
+        for k, v in self.buf.items():
+            setattr(m, k, v.ctypes.data_as(dp))
+        self._m = m
+        return m
+
+    def CalcResidual(self):
+        o = load()
+        e, (f, nb), m, p = self.c_eles(), self.c_faces(), self.c_mpi(), self.params
+        E, M, P = C.byref(e), C.byref(m), C.byref(p)
+        have = m.n_inters > 0
+        o.orc_extrapolate_solution(E)
+        if have:
+            o.orc_mpi_pack_solution(M, E)
+            self.exchange(0, 0)
+        if p.viscous:
+            o.orc_calculate_gradient(E)
+        o.orc_evaluate_invFlux(E, C.byref(p))
+        for b in range(nb):
+            o.orc_int_calculate_common_invFlux(C.byref(f[b]), E, P)
+        if have:
+            self.exchange(0, 1)
+            o.orc_mpi_calculate_common_invFlux(M, E, P)
+        if p.viscous:
+            o.orc_correct_gradient(E)
+            if have:
+                o.orc_mpi_pack_corrected_gradient(M, E)
+                self.exchange(1, 0)
+            o.orc_evaluate_viscFlux(E, P)
+        o.orc_extrapolate_totalFlux(E)
+        o.orc_calculate_divergence(E)
+        if p.viscous:
+            for b in range(nb):
+                o.orc_int_calculate_common_viscFlux(C.byref(f[b]), E, P)
+            if have:
+                self.exchange(1, 1)
+                o.orc_mpi_calculate_common_viscFlux(M, E, P)
+        return o.orc_calculate_corrected_divergence(E)
+
+    def rk_step(self):
+        o = load()
+        for s in range(self.params.n_rk if self.params.adv_type else 1):
+            bad = self.CalcResidual()
+            assert bad < 0, "NaN at %d" % bad
+            o.orc_AdvanceSolution(C.byref(self._e), C.byref(self.params), C.c_int(s))

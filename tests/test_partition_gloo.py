@@ -1,0 +1,77 @@
+"""N>1 path on the CPU (gloo, world_size 2 and 4): partition tables of the host mirror, the oracle's
+partition-face functions and the torch.distributed exchange, pinned by partition invariance against
+the single-rank oracle (which is pinned bit-exactly against the genuine reference)."""
+import numpy as np
+import pytest
+
+import partition_util as PU
+
+CFG = dict(order=2, amp=0.05, length=6.2831853071795862, T_c_ic=300.0, dt=1e-4)
+
+
+def rel(a, b):
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+@pytest.mark.parametrize("n_local,pgrid,kw", [
+    ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=3)),                   # both x faces of a block meet the same rank
+    ([4, 2, 4], [1, 2, 1], dict(riemann_solve_type=0)),
+    ([4, 4, 2], [1, 1, 2], dict(riemann_solve_type=2)),
+    ([2, 2, 4], [2, 2, 1], dict(riemann_solve_type=3)),                   # 4 ranks, 2 neighbours each
+    ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=0, viscous=0, ic_form=1, u_c_ic=30.0, v_c_ic=10.0, w_c_ic=5.0,
+                                p_c_ic=101325.0, rho_c_ic=1.2)),          # inviscid: solution exchange only
+])
+def test_partition_invariance_oracle(tmp_path, n_local, pgrid, kw):
+    cfg = dict(CFG)
+    cfg.update(kw)
+    world = int(np.prod(pgrid))
+    PU.spawn(PU.oracle_worker, world, (n_local, pgrid, cfg, 1, str(tmp_path)))
+    n_global = [n_local[d] * pgrid[d] for d in range(3)]
+    u1, div1 = PU.single_rank_oracle(n_global, cfg, 1)
+    u = PU.assemble(str(tmp_path), "u", n_local, pgrid, u1.shape)
+    div = PU.assemble(str(tmp_path), "div", n_local, pgrid, div1.shape)
+    # not bit-exact: a partition face is evaluated from both sides (left = self on each rank), the
+    # interior face once from its lower-numbered cell
+    if cfg.get("viscous", 1):
+        assert rel(div, div1) < 1e-11
+    else:
+        # uniform free stream: the residual is rounding noise (free-stream preservation), compare it on the
+        # scale of the state
+        assert np.abs(div - div1).max() < 1e-12 * np.abs(u1).max()
+    assert rel(u, u1) < 1e-12
+
+
+def test_partition_quads(tmp_path):
+    cfg = dict(CFG, dims=2, riemann_solve_type=0)
+    n_local, pgrid = [4, 2], [1, 2]
+    PU.spawn(PU.oracle_worker, 2, (n_local, pgrid, cfg, 1, str(tmp_path)))
+    u1, div1 = PU.single_rank_oracle([4, 4], cfg, 1)
+    u = PU.assemble(str(tmp_path), "u", n_local, pgrid, u1.shape)
+    assert rel(u, u1) < 1e-12
+
+
+def test_partition_tables_are_mutually_consistent():
+    """Both sides of a rank pair list their shared faces in the same order: flux-point positions of
+    face i on rank a coincide (through Rlut, modulo the period) with those of face i on rank b."""
+    import hfx_host as H
+    n_local, pgrid = [2, 3, 4], [2, 1, 1]
+    cs = [H.Case(n_local, rank=r, pgrid=pgrid, order=2, amp=0.07) for r in range(2)]
+    pos = [c.array("pos_fpts") for c in cs]  # (n_fpts, n_eles, dims)
+    tabs = [c.mpi_faces() for c in cs]
+    nfp = cs[0].n_fpts
+    length = 6.2831853071795862
+    for a, b in ((0, 1), (1, 0)):
+        La, Ra, _ = tabs[a]
+        Lb, _, _ = tabs[b]
+        assert La.shape == Lb.shape
+        for i in range(La.shape[1]):
+            for j in range(La.shape[0]):
+                fa, ea = La[j, i] % nfp, La[j, i] // nfp
+                ob = Lb[Ra[j, i], i]  # the record slot Rlut(j) of b's face i is b's j'-th flux point
+                fb, eb = ob % nfp, ob // nfp
+                d = pos[a][fa, ea, :] - pos[b][fb, eb, :]
+                d -= length * np.round(d / length)
+                assert np.abs(d).max() < 1e-9
+    for c in cs:
+        c.close()
