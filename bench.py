@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- DOF-updates/s and ms/RK-stage of the HiFiLES hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n CELLS] [--order P] [--mode fused|methods|dense]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cells CELLS] [--order P] [--mode fused|methods|dense]
 
 One "step" is one time step = 5 RK stages (RK45), each stage = CalcResidual + AdvanceSolution
 (/root/reference/src/HiFiLES.cpp:201-217) over the whole mesh.  Workload at N=1: BASELINE.json
 configs[1], the Taylor-Green vortex on a generated periodic 32^3 hexahedral mesh, P4, Navier-Stokes,
 HLLC + LDG, fixed dt; inputs are resident in HBM before the timed region.
-For N>1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank advances its own
-32^3-element block (weak scaling).
+For N>1 (launched by torch.distributed.run, one rank per GPU over RCCL) the periodic box is split into
+N blocks of 32^3 elements on a process grid (2: 2x1x1, 4: 2x2x1, 8: 2x2x2; weak scaling); every rank
+advances its block and exchanges partition-face solution and gradient records with its neighbours
+(point-to-point over xGMI) twice per RK stage, as the reference's mpi_inters do.
 
 Prints ONE JSON line (rank 0).  The oracle under oracle/ is used only for the `cpu_baseline` leg.
 """
@@ -97,7 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=32, help="cells per direction per GPU")
+    ap.add_argument("--cells", "--n", dest="n", type=int, default=32, help="cells per direction per GPU")
     ap.add_argument("--order", type=int, default=4)
     ap.add_argument("--mode", default="auto", choices=["auto", "fused", "split", "methods", "dense"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -112,22 +114,40 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # HFX_BENCH_BACKEND=gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (host-staged
+        # exchange, ranks share the cards); the measured configuration is RCCL, one rank per GPU
+        backend = os.environ.get("HFX_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
 
     import hfx
     import hfx_host as H
 
-    case = H.Case(args.n, order=args.order)
+    pgrid = {1: None, 2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}.get(world, [world, 1, 1])
+    case = H.Case(args.n, order=args.order, rank=rank, pgrid=pgrid)
     case.to_device(local_rank)
     ctx, e, faces, nb = case.handles()
     lib = hfx.lib()
+    ex = None
+    if world > 1:
+        import exchange
+        if args.mode not in ("auto", "split", "methods"):
+            raise SystemExit("N>1 runs the split fused path or the per-method path")
+        ex = exchange.for_case(case, device=torch.device("cuda", local_rank))
+        case.set_exchange(ex)
 
     mode = args.mode
     fused_ok = False
-    if mode in ("auto", "fused", "split"):
+    if world > 1:
+        mode = "split" if mode == "auto" else mode
+    elif mode in ("auto", "fused", "split"):
         rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(1))
         fused_ok = (rc == 0)
         if mode != "auto" and not fused_ok:
@@ -145,7 +165,12 @@ def main():
             dist.barrier()
 
     def run(nsteps):
-        hfx.check(lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(nsteps), C.c_int(fused)))
+        if world == 1:
+            hfx.check(lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(nsteps), C.c_int(fused)))
+        elif fused:
+            case.run_partitioned(nsteps)  # hfx_stage_partitioned phases + exchanges
+        elif nsteps:
+            case.run(nsteps)              # mirrored CalcResidual with the mpi_inters calls
 
     run(args.warmup)
     torch.cuda.synchronize()
@@ -158,7 +183,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -176,7 +201,7 @@ def main():
 
     roof = None
     cpu = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         # ---- roofline of the dominant kernel, timed live with HIP events on the library's stream
         if fused:
             kt = (C.c_double * 8)()
@@ -244,10 +269,14 @@ def main():
             "config": {"workload": "Taylor-Green vortex, %d^3 hexa per GPU, P%d, Navier-Stokes, HLLC+LDG, RK45, "
                                    "1 step = %d RK stages" % (args.n, args.order, n_stages),
                        "n_eles_per_gpu": case.n_eles, "dof_per_gpu": dof_per_rank, "path": mode,
-                       "multi_gpu": "none" if world == 1 else "independent periodic blocks per rank (weak)"},
+                       "multi_gpu": "none" if world == 1 else
+                       "one periodic box split into %s blocks, partition-face exchange over %s p2p" %
+                       ("x".join(map(str, pgrid)), "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if ex is not None:
+        ex.close()
     case.close()
     if dist is not None:
         dist.destroy_process_group()

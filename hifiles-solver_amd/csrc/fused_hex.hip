@@ -1775,24 +1775,31 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
       if ((e->n_dims == 2 ? mpi_launch<2>(e, mpi_faces[b], what) : mpi_launch<3>(e, mpi_faces[b], what))) return 1;
     return 0;
   };
-  if (phase == 0)
+  const bool last = in_step == nst - 1;
+  switch (phase)
   {
+  case 0:
     if (first && hfx_eles_extrapolate_solution(e)) return 1;
-    return mpi_all(0);
-  }
-  if (phase == 1)
-  {
+    return first ? mpi_all(0) : 0;
+  case 1:
     if (!p.viscous) return 0;
-    if (split_stage(e, int_faces, n_int, in_step, false, 1)) return 1; // interior LDG common solution
+    return split_stage(e, int_faces, n_int, in_step, false, 1); // interior LDG common solution
+  case 2:
+    if (!p.viscous) return 0;
     if (mpi_all(1)) return 1;
     if (split_stage(e, int_faces, n_int, in_step, false, 2)) return 1; // corrected gradients
     return mpi_all(2);
+  case 3:
+    if (split_stage(e, int_faces, n_int, in_step, last, 3)) return 1; // interior common fluxes
+    return mpi_all(3);
+  case 4:
+    if (p.viscous && mpi_all(4)) return 1;
+    if (split_stage(e, int_faces, n_int, in_step, last, 4)) return 1; // residual, RK, new disu_fpts (swaps)
+    return mpi_all(0);
+  default:
+    HFX_CHECK(false, "hfx_stage_partitioned: phase %d out of range", phase);
   }
-  if (split_stage(e, int_faces, n_int, in_step, in_step == nst - 1, 3)) return 1; // interior common fluxes
-  if (mpi_all(3)) return 1;
-  if (p.viscous && mpi_all(4)) return 1;
-  if (split_stage(e, int_faces, n_int, in_step, in_step == nst - 1, 4)) return 1; // residual, RK, new disu_fpts (swaps)
-  return mpi_all(0);
+  return 0;
 }
 
 } // namespace hfx

@@ -808,7 +808,7 @@ int hfx_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, 
 {
   HFX_CHECK(e, "NULL eles");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
-  HFX_CHECK(phase >= 0 && phase <= 2, "hfx_stage_partitioned: phase must be 0..2");
+  HFX_CHECK(phase >= 0 && phase <= 4, "hfx_stage_partitioned: phase must be 0..4");
   return split_stage_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, phase, in_step, first);
 }
 

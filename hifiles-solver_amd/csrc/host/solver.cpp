@@ -410,6 +410,10 @@ int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
   auto phase = [&](int ph, int stage, int first) {
     return hfx_stage_partitioned(E->device(), fi.data(), (int)fi.size(), fm.data(), (int)fm.size(), ph, stage, first);
   };
+  auto xch = [&](int kind, int ph) {
+    if (ex) FlowSol->exchange(FlowSol->exchange_user, kind, ph);
+  };
+  const bool visc = FlowSol->run_input.viscous != 0;
   bool first = true;
   for (int i_steps = 0; i_steps < n_steps; i_steps++)
   {
@@ -418,16 +422,23 @@ int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
       if (first)
       {
         if (phase(0, i, 1)) { FlowSol->err = hfx_last_error(); return 1; }
+        xch(0, 0); // later stages: started after phase 4 of the previous one
         first = false;
       }
-      // the packed solution of this stage (phase 0, or phase 2 of the previous stage) crosses here
-      if (ex) { FlowSol->exchange(FlowSol->exchange_user, 0, 0); FlowSol->exchange(FlowSol->exchange_user, 0, 1); }
       if (phase(1, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
-      if (ex && FlowSol->run_input.viscous) { FlowSol->exchange(FlowSol->exchange_user, 1, 0); FlowSol->exchange(FlowSol->exchange_user, 1, 1); }
+      xch(0, 1);
       if (phase(2, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
+      if (visc) xch(1, 0);
+      if (phase(3, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
+      if (visc) xch(1, 1);
+      if (phase(4, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
+      xch(0, 0);
     }
     FlowSol->time += FlowSol->run_input.dt;
     FlowSol->run_input.time = FlowSol->time;
   }
+  // the exchange started after the last stage belongs to a stage that is not run: complete it so that
+  // no request is left in flight (a following call starts over with `first`)
+  xch(0, 1);
   return 0;
 }

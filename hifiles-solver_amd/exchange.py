@@ -24,12 +24,12 @@ def device_tensor(ptr, n, device):
     return torch.as_tensor(_DevBuf(ptr, n), device=device)
 
 
-def segments(nout_proc, rank):
+def segments(nout_proc, rank, allow_self=False):
     """[(peer, first face, faces)] in buffer order."""
     seg, start = [], 0
     for p, c in enumerate(np.asarray(nout_proc).tolist()):
         if c:
-            assert p != rank
+            assert allow_self or p != rank
             seg.append((p, start, c))
             start += c
     return seg
@@ -41,8 +41,8 @@ class Exchange:
     CPU tensors go straight through the process group.  Device tensors go through the group directly
     when it is RCCL, and through pinned host staging when it is gloo."""
 
-    def __init__(self, nout_proc, rank, bufs, group=None, stream=None):
-        self.seg = segments(nout_proc, rank)
+    def __init__(self, nout_proc, rank, bufs, group=None, stream=None, allow_self=False):
+        self.seg = segments(nout_proc, rank, allow_self)
         self.n_faces = sum(c for _, _, c in self.seg)
         self.bufs = bufs  # {kind: (out, in)}
         self.group = group
@@ -103,6 +103,15 @@ class Exchange:
                     with torch.cuda.stream(self.stream):
                         i.copy_(self.stage[k][1], non_blocking=True)
         self.pending = keep
+
+    def close(self):
+        """Drop the staging / aliasing tensors while the hfx context (its stream) is still alive: the
+        pinned-memory allocator records an event on every stream a block was used on when it is freed."""
+        if self.stream is not None:
+            self.stream.synchronize()
+        self.stage.clear()
+        self.bufs = {}
+        self.pending = []
 
     def __call__(self, kind, phase):
         (self.start if phase == 0 else self.wait)(kind)

@@ -178,16 +178,19 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
  * fused kernels, 2 the split fused kernels (same results to rounding). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
 
-/* One RK stage of the split fused path on a PARTITIONED block, cut at the two exchange points so
- * that the caller can move the partition-face buffers in between (the order of CalcResidual's
+/* One RK stage of the split fused path on a PARTITIONED block, cut so that the caller can move the
+ * partition-face buffers while interior faces are being worked on (the order of CalcResidual's
  * send / receive calls, src/solver.cpp:70-72,134-138,150-154,200-209):
- *   phase 0: flux-point solution of the current state is available (first stage: extrapolate) and
- *            packed into out_buffer_disu                                   -> exchange solution
- *   phase 1: LDG common solution on interior and partition faces, corrected gradients,
- *            out_buffer_grad_disu packed                                   -> exchange gradient
- *   phase 2: common fluxes on interior and partition faces, residual, RK update (in_step), the new
- *            state's flux-point solution packed into out_buffer_disu       -> exchange solution
- * `first` != 0 on the first stage after the caller changed disu_upts(0). */
+ *   phase 0: (first stage only) extrapolate, pack out_buffer_disu          -> caller STARTS solution exchange
+ *   phase 1: LDG common solution on interior faces                         -> caller WAITS for the solution
+ *   phase 2: the same on partition faces, corrected gradients, pack out_buffer_grad_disu
+ *                                                                          -> caller STARTS gradient exchange
+ *   phase 3: common fluxes on interior faces, inviscid part on partition faces
+ *                                                                          -> caller WAITS for the gradient
+ *   phase 4: viscous common flux on partition faces, residual, RK update (in_step), the new state's
+ *            flux-point solution packed into out_buffer_disu               -> caller STARTS solution exchange
+ * Inviscid runs skip phases 1-2 (they return at once).  `first` != 0 on the first stage after the caller
+ * changed disu_upts(0). */
 int hfx_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
                           int n_mpi, int phase, int in_step, int first);
 

@@ -115,6 +115,8 @@ def assemble(outdir, name, n_local, pgrid, shape_global):
 def gpu_worker(rank, world, port, n_local, pgrid, cfg, n_steps, outdir, mode, backend="gloo"):
     """N-rank libhfx run (all ranks on cuda:0 when the box has one GPU): mode "methods" = the mirrored
     CalcResidual with mpi_inters calls, mode "fused" = hfx_stage_partitioned phases."""
+    import faulthandler
+    faulthandler.enable()
     import torch
     import hfx_host as H
     import exchange
@@ -136,6 +138,8 @@ def gpu_worker(rank, world, port, n_local, pgrid, cfg, n_steps, outdir, mode, ba
         np.save(os.path.join(outdir, "u_rank%d.npy" % rank), c.array("disu_upts0"))
         np.save(os.path.join(outdir, "div_rank%d.npy" % rank), c.array("div_tconf_upts"))
         dist.barrier()
+        if ex is not None:
+            ex.close()
         c.close()
     finally:
         dist.destroy_process_group()

@@ -42,3 +42,37 @@ def test_gpu_partition_quads(tmp_path):
     u1, div1 = PU.single_rank_oracle([4, 4], cfg, 1)
     u = PU.assemble(str(tmp_path), "u", n_local, pgrid, u1.shape)
     assert rel(u, u1) < 1e-11
+
+
+def _nccl_self_worker(rank, world, port, outdir):
+    import torch
+    import hfx
+    from exchange import Exchange
+    torch.cuda.set_device(0)
+    dist = PU.init_pg(rank, world, port, "nccl")
+    try:
+        ctx = hfx.Context(0)
+        stream = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", 0))
+        nface, rec = 6, 10
+        with torch.cuda.stream(stream):
+            out = torch.arange(nface * rec, dtype=torch.float64, device="cuda") + 1.0
+            inn = torch.zeros(nface * rec, dtype=torch.float64, device="cuda")
+            g_out = -out.repeat(3)
+            g_in = torch.zeros_like(g_out)
+        stream.synchronize()
+        ex = Exchange([nface], 0, {0: (out, inn), 1: (g_out, g_in)}, stream=stream, allow_self=True)
+        ex(0, 0); ex(1, 0); ex(0, 1); ex(1, 1)
+        stream.synchronize()
+        ok = bool(torch.equal(inn, out) and torch.equal(g_in, g_out))
+        ex.close()
+        ctx.close()
+        np.save(outdir + "/ok.npy", np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gpu_exchange_rccl_device_buffers(tmp_path):
+    """The RCCL branch of the exchange (batched isend/irecv on device buffer slices, ordered on the hfx
+    stream) with the one rank a 1-GPU box allows: every segment is sent to self."""
+    PU.spawn(_nccl_self_worker, 1, (str(tmp_path),))
+    assert np.load(str(tmp_path / "ok.npy"))[0]
