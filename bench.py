@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "hifiles-solver_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-DEFAULT_FUSED = "split"   # which fused variant `--mode auto` runs
+DEFAULT_FUSED = "split3"  # which fused variant `--mode auto` runs
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak
 
@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", "--n", dest="n", type=int, default=32, help="cells per direction per GPU")
     ap.add_argument("--order", type=int, default=4)
-    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "split", "methods", "dense"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "split", "split3", "methods", "dense"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -147,7 +147,7 @@ def main():
     fused_ok = False
     if world > 1:
         mode = "split" if mode == "auto" else mode
-    elif mode in ("auto", "fused", "split"):
+    elif mode in ("auto", "fused", "split", "split3"):
         rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(1))
         fused_ok = (rc == 0)
         if mode != "auto" and not fused_ok:
@@ -156,7 +156,7 @@ def main():
             mode = DEFAULT_FUSED if fused_ok else "methods"
     if mode == "dense":
         hfx.check(lib.hfx_ctx_set_contract_mode(ctx, C.c_int(hfx.CONTRACT_DENSE)))
-    fused = 1 if mode == "fused" else (2 if mode == "split" else 0)
+    fused = {"fused": 1, "split": 2, "split3": 3}.get(mode, 0)
     if fused:
         hfx.check(lib.hfx_ctx_set_fused_mode(ctx, C.c_int(fused)))
 
@@ -220,7 +220,7 @@ def main():
             # rocprofv3 runs by tools/profile_round.sh and committed under profiles/); only valid for the
             # workload it was measured on
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_fused_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % mode)
             if os.path.exists(tfile) and args.n == 32 and args.order == 4:
                 traffic = json.load(open(tfile)).get(dom, {}).get("traffic_bytes_corrected")
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",

@@ -68,6 +68,7 @@ struct FusedData
   unsigned char *meta = nullptr; // bit0: this point is the RIGHT side, bit1: beta sign flipped
   double *fnorm = nullptr;       // (n_fpts, n_eles, n_dims) the LEFT element's unit normal of the pair
   double *disu_alt = nullptr;    // second disu_fpts buffer
+  double *fn_fpts = nullptr;     // split variant 3: projected viscous flux per flux point (n_fpts,n_eles,n_fields)
   unsigned *pk_g = nullptr, *pk_r = nullptr; // packed operator rows of the gradient / residual kernel
   double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)
   int *o1m_dim = nullptr;                    // (n_fpts) dimension slab of the merged opp_1 row
@@ -84,7 +85,7 @@ void fused_destroy(hfx_eles *e)
 {
   if (!e || !e->fused) return;
   FusedData *f = e->fused;
-  void *p[] = {f->nbr, f->meta, f->fnorm, f->disu_alt, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
+  void *p[] = {f->nbr, f->meta, f->fnorm, f->disu_alt, f->fn_fpts, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete f;
@@ -1572,8 +1573,383 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT_WAVES_RES) void split_
   }
 }
 
+
+// =======================================================================================
+// SPLIT path, variant 3 ("flux in the gradient kernel"): the element kernel that has the corrected
+// gradient in registers goes on to the fluxes, so that neither grad_disu_upts nor grad_disu_fpts
+// crosses HBM.  What leaves it is what the face and update kernels need, 5 instead of 15 doubles
+// per point:
+//
+//   face_delta_kernel   unchanged
+//   split_flux_kernel   u, delta -> corrected gradient (upts: registers, fpts: registers) ->
+//                       tdisf = JGinv (F_inv + F_visc) in LDS -> div_tdisf (upts), norm_tdisf (fpts),
+//                       and the viscous flux of this side projected on its OWN normal, Fn = F_v(u,grad).n
+//   face_flux2_kernel   Riemann flux + LDG combination (1/2+b) Fn_L - (1/2-b) Fn_R - tau (u_R-u_L)
+//   split_update_kernel div_tdisf + opp_3 (norm_tconf - norm_tdisf), RK update, disu_fpts of the new state
+//
+// The right side's flux is projected on the right element's own normal (= -left normal up to
+// rounding on a conforming mesh) instead of on the left normal as src/inters.cpp:616-633 does:
+// a last-bit difference, inside the fused paths' documented rounding tolerance.
+// =======================================================================================
+#ifndef HFX_SPLIT2_WAVES
+#define HFX_SPLIT2_WAVES 3
+#endif
+
+struct Split2Args
+{
+  int n_eles;
+  const unsigned *pk_g, *pk_r;
+  const double *tab_g, *tab_r;
+  const int *o1m_dim;
+  const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts, *norm_fpts;
+  double *u0, *u1;
+  const double *delta, *tconf;
+  double *fn_fpts;  // (n_fpts,n_eles,n_fields) projected viscous flux of this side
+  double *ntd_fpts; // norm_tdisf_fpts
+  double *div;      // div_tdisf (flux kernel) -> read by the update kernel, which may overwrite it with div_tconf
+  double *disu_next;
+  double *grad_upts, *grad_fpts; // optional outputs (NULL: not written)
+  const double *src, *dt_local;
+  unsigned long long *nan_flag;
+  Phys P;
+  int adv_type, in_step, dt_local_on, write_div, need_u1;
+  double dt, rk_a, rk_b;
+};
+
 template <int ND, int N>
-static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, SplitEleArgs &ea, int which)
+__global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flux_kernel(const Split2Args a)
+{
+  using G = Geo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, WN = G::WN, TB = SGeo<ND, N>::TB;
+  constexpr int NG = NF * ND;
+  // packed words of this thread: opp_4[d] | opp_5[d] | opp_2[d] (upt row) | opp_0 | opp_6 | merged opp_1 (fpt row)
+  constexpr int O2 = G::G_WU, O0 = O2 + ND * WN, O6 = O0 + WN, O1 = O6 + WN, PW = O1 + WN;
+  constexpr int UNION = cmax(NF * (NU + NFP), NG * NU);
+  __shared__ double tabg[MAX_TAB];
+  __shared__ double tabr[MAX_TAB];
+  __shared__ double sA[UNION]; // su | sd, later st
+  __shared__ double sg[NG * NU];
+  double *const su = sA, *const sd = sA + NF * NU, *const st = sA;
+  const int t = threadIdx.x;
+  const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
+  const bool is_u = t < NU, is_f = t < NFP;
+  const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
+  const bool viscous = a.P.viscous;
+  for (int q = t; q < MAX_TAB; q += TB)
+  {
+    tabg[q] = a.tab_g[q];
+    tabr[q] = a.tab_r[q];
+  }
+  unsigned pw[PW];
+#pragma unroll
+  for (int d = 0; d < ND; d++)
+  {
+#pragma unroll
+    for (int i = 0; i < WN; i++)
+    {
+      pw[d * WN + i] = a.pk_g[G::G_O4 + (d * WN + i) * NU + tu];
+      pw[O2 + d * WN + i] = a.pk_r[G::R_O2 + (d * WN + i) * NU + tu];
+    }
+    pw[ND * WN + d] = a.pk_g[G::G_O5 + d * NU + tu];
+  }
+#pragma unroll
+  for (int i = 0; i < WN; i++)
+  {
+    pw[O0 + i] = a.pk_g[G::G_O0 + i * NFP + tf];
+    pw[O6 + i] = a.pk_g[G::G_O6 + i * NFP + tf];
+    pw[O1 + i] = a.pk_r[G::R_O1 + i * NFP + tf];
+  }
+  const int d1 = a.o1m_dim[tf];
+
+  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  {
+    const long p = tu + NU * e, o = tf + NFP * e;
+    for (int q = t; q < NF * NU; q += TB)
+    {
+      const int f = q / NU, p2 = q - f * NU;
+      su[q] = a.u0[p2 + NU * e + f * plane_u];
+    }
+    if (viscous)
+      for (int q = t; q < NF * NFP; q += TB)
+      {
+        const int f = q / NFP, p2 = q - f * NFP;
+        sd[q] = a.delta[p2 + NFP * e + f * plane_f];
+      }
+    double JG[ND * ND];
+#pragma unroll
+    for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
+    const double inv_detjac = viscous ? 1.0 / a.detjac_upts[p] : 0.0;
+    __syncthreads();
+    double tfl[NG]; // transformed total flux at this solution point
+    double uf[NF];  // solution at this flux point
+    if (is_u)
+    {
+      double u[NF], f[NG];
+#pragma unroll
+      for (int k = 0; k < NF; k++) u[k] = su[k * NU + tu];
+      calc_invf<ND, true>(a.P.gamma, u, f);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+          tfl[k + NF * l] = s;
+        }
+      if (viscous)
+      {
+        double gr[NG];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double tg[ND], cg[ND];
+          tg[0] = row_dot<N, 0, PW>(pw, tabg, &su[k * NU], 0.0);
+          tg[1] = row_dot<N, WN, PW>(pw, tabg, &su[k * NU], 0.0);
+          if (ND == 3) tg[ND - 1] = row_dot<N, (ND - 1) * WN, PW>(pw, tabg, &su[k * NU], 0.0);
+          tg[0] = row_dot<2, ND * WN + 0, PW>(pw, tabg, &sd[k * NFP], tg[0]);
+          tg[1] = row_dot<2, ND * WN + 1, PW>(pw, tabg, &sd[k * NFP], tg[1]);
+          if (ND == 3) tg[ND - 1] = row_dot<2, ND * WN + ND - 1, PW>(pw, tabg, &sd[k * NFP], tg[ND - 1]);
+#pragma unroll
+          for (int d = 0; d < ND; d++) sg[(k + NF * d) * NU + tu] = tg[d];
+          to_physical<ND>(inv_detjac, JG, tg, cg);
+#pragma unroll
+          for (int d = 0; d < ND; d++) gr[k + NF * d] = cg[d];
+        }
+        if (a.grad_upts)
+#pragma unroll
+          for (int q = 0; q < NG; q++) a.grad_upts[p + q * plane_u] = gr[q];
+        calc_visf<ND, true>(a.P, u, gr, f);
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+#pragma unroll
+          for (int l = 0; l < ND; l++)
+          {
+            double s = tfl[k + NF * l];
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+            tfl[k + NF * l] = s;
+          }
+      }
+    }
+    if (viscous && is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) uf[k] = row_dot<N, O0, PW>(pw, tabg, &su[k * NU], 0.0);
+    }
+    __syncthreads(); // every reader of su / sd is done: the region becomes st
+    if (is_u)
+    {
+#pragma unroll
+      for (int q = 0; q < NG; q++) st[q * NU + tu] = tfl[q];
+    }
+    __syncthreads();
+    if (is_u)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = row_dot<N, O2, PW>(pw, tabr, &st[k * NU], 0.0);
+        s = row_dot<N, O2 + WN, PW>(pw, tabr, &st[(k + NF) * NU], s);
+        if (ND == 3) s = row_dot<N, O2 + (ND - 1) * WN, PW>(pw, tabr, &st[(k + NF * (ND - 1)) * NU], s);
+        a.div[p + k * plane_u] = s;
+      }
+    }
+    if (is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+        a.ntd_fpts[o + k * plane_f] = row_dot<N, O1, PW>(pw, tabr, &st[(k + NF * d1) * NU], 0.0);
+      if (viscous)
+      {
+        double JF[ND * ND], n[ND], grf[NG], fq[NG];
+#pragma unroll
+        for (int q = 0; q < ND * ND; q++) JF[q] = a.JGinv_fpts[o * (ND * ND) + q];
+        const double inv_df = 1.0 / a.detjac_fpts[o];
+#pragma unroll
+        for (int m = 0; m < ND; m++) n[m] = a.norm_fpts[o + m * plane_f];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double tg[ND], cg[ND];
+#pragma unroll
+          for (int d = 0; d < ND; d++) tg[d] = row_dot<N, O6, PW>(pw, tabg, &sg[(k + NF * d) * NU], 0.0);
+          to_physical<ND>(inv_df, JF, tg, cg);
+#pragma unroll
+          for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
+        }
+        if (a.grad_fpts)
+#pragma unroll
+          for (int q = 0; q < NG; q++) a.grad_fpts[o + q * plane_f] = grf[q];
+        calc_visf<ND, true>(a.P, uf, grf, fq);
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < ND; l++) s += fq[k + NF * l] * n[l];
+          a.fn_fpts[o + k * plane_f] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct Split2FaceArgs
+{
+  long npairs;
+  const int *L, *R;
+  const unsigned char *meta;
+  long plane_f;
+  const double *disu, *fn, *fnorm, *tdA;
+  double *tconf;
+  Phys P;
+};
+
+template <int ND, int RS>
+__global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long il = a.L[q], ir = a.R[q];
+  double ul[NF], ur[NF], n[ND], fn[NF];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu[il + k * a.plane_f];
+    ur[k] = a.disu[ir + k * a.plane_f];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.fnorm[il + m * a.plane_f];
+  const double tl = a.tdA[il], tr = a.tdA[ir];
+  riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
+  if (a.P.viscous)
+  {
+    const double beta = (a.meta[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      // (1/2+b) F_L.n + (1/2-b) F_R.n - tau (u_R - u_L), n the left normal = -(right normal)
+      double fv = (0.5 + beta) * a.fn[il + k * a.plane_f] - (0.5 - beta) * a.fn[ir + k * a.plane_f];
+      fv -= a.P.ldg_tau * (ur[k] - ul[k]);
+      a.tconf[il + k * a.plane_f] = fn[k] * tl + fv * tl;
+      a.tconf[ir + k * a.plane_f] = -fn[k] * tr + -fv * tr;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      a.tconf[il + k * a.plane_f] = fn[k] * tl;
+      a.tconf[ir + k * a.plane_f] = -fn[k] * tr;
+    }
+  }
+}
+
+// div_tdisf + opp_3 (norm_tconf - norm_tdisf) -> RK update -> disu_fpts of the new state: a streaming kernel
+template <int ND, int N>
+__global__ __launch_bounds__((SGeo<ND, N>::TB)) void split_update_kernel(const Split2Args a)
+{
+  using G = Geo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, WN = G::WN, TB = SGeo<ND, N>::TB;
+  constexpr int N3 = 2 * ND;
+  constexpr int O3 = 0, O0 = words_of(N3), PW = O0 + WN;
+  __shared__ double tab[MAX_TAB];
+  __shared__ double su[NF][NU];
+  __shared__ double sc[NF][NFP];
+  const int t = threadIdx.x;
+  const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
+  const bool is_u = t < NU, is_f = t < NFP;
+  const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
+  for (int q = t; q < MAX_TAB; q += TB) tab[q] = a.tab_r[q];
+  unsigned pw[PW];
+#pragma unroll
+  for (int i = 0; i < words_of(N3); i++) pw[O3 + i] = a.pk_r[G::R_O3 + i * NU + tu];
+#pragma unroll
+  for (int i = 0; i < WN; i++) pw[O0 + i] = a.pk_r[G::R_O0 + i * NFP + tf];
+
+  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  {
+    const long p = tu + NU * e, o = tf + NFP * e;
+    double u[NF], dvin[NF], u1v[NF];
+    if (is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) sc[k][tf] = a.tconf[o + k * plane_f] + -1.0 * a.ntd_fpts[o + k * plane_f];
+    }
+    const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
+    const double dj = a.detjac_upts[p];
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      u[k] = a.u0[p + k * plane_u];
+      dvin[k] = a.div[p + k * plane_u];
+      u1v[k] = a.need_u1 ? a.u1[p + k * plane_u] : 0.0;
+    }
+    __syncthreads();
+    if (is_u)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        const double dv = row_dot<N3, O3, PW>(pw, tab, &sc[k][0], dvin[k]);
+        const long q = p + k * plane_u;
+        if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)q);
+        if (a.write_div) a.div[q] = dv;
+        const double s = a.src ? a.src[q] : 0.0;
+        const double dd = dv / dj;
+        double un = u[k];
+        if (a.adv_type == 0)
+          un -= dt * (dd - s);
+        else if (a.adv_type == 1)
+        {
+          if (a.in_step == 0) a.u1[q] = un;
+          if (a.in_step < 3)
+            un -= dt / 3.0 * (dd - s);
+          else
+          {
+            const double rhs = -dd + s;
+            un = 3.0 / 4.0 * un + 1.0 / 4.0 * u1v[k] + dt / 4.0 * rhs;
+          }
+        }
+        else if (a.adv_type == 2)
+        {
+          if (a.in_step == 0) a.u1[q] = un;
+          if (a.in_step < 2 || a.in_step == 3)
+            un -= dt / 2.0 * (dd - s);
+          else if (a.in_step == 2)
+          {
+            const double rhs = -dd + s;
+            un = 1.0 / 3.0 * un + 2.0 / 3.0 * u1v[k] + dt / 6.0 * rhs;
+          }
+        }
+        else
+        {
+          const double rhs = -dd + s;
+          const double r1 = a.rk_a * u1v[k] + dt * rhs;
+          a.u1[q] = r1;
+          un += a.rk_b * r1;
+        }
+        a.u0[q] = un;
+        su[k][tu] = un;
+      }
+    }
+    __syncthreads();
+    if (is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, O0, PW>(pw, tab, &su[k][0], 0.0);
+    }
+    __syncthreads();
+  }
+}
+
+template <int ND, int N>
+static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, SplitEleArgs &ea, int which, int variant)
 {
   FusedData *F = e->fused;
   hipStream_t st = e->ctx->stream;
@@ -1589,6 +1965,22 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     a.P = P;
     return a;
   };
+  Split2Args e2{};
+  if (variant == 3)
+  {
+    if (!F->fn_fpts) HFX_HIP(hipMalloc((void **)&F->fn_fpts, sizeof(double) * (size_t)plane_f * e->n_fields));
+    e2.n_eles = ea.n_eles;
+    e2.pk_g = F->pk_g; e2.pk_r = F->pk_r; e2.tab_g = F->tab_g; e2.tab_r = F->tab_r; e2.o1m_dim = F->o1m_dim;
+    e2.detjac_upts = ea.detjac_upts; e2.JGinv_upts = ea.JGinv_upts; e2.detjac_fpts = ea.detjac_fpts;
+    e2.JGinv_fpts = ea.JGinv_fpts; e2.norm_fpts = e->norm_fpts;
+    e2.u0 = ea.u0; e2.u1 = ea.u1; e2.delta = ea.delta; e2.tconf = ea.tconf;
+    e2.fn_fpts = F->fn_fpts; e2.ntd_fpts = e->arr[HFX_NORM_TDISF_FPTS]; e2.div = ea.div_out;
+    e2.disu_next = ea.disu_next;
+    e2.grad_upts = nullptr; e2.grad_fpts = nullptr;
+    e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;
+    e2.adv_type = ea.adv_type; e2.in_step = ea.in_step; e2.dt_local_on = ea.dt_local_on; e2.write_div = ea.write_div;
+    e2.need_u1 = ea.need_u1; e2.dt = ea.dt; e2.rk_a = ea.rk_a; e2.rk_b = ea.rk_b;
+  }
   if (P.viscous && (which == 0 || which == 1))
   {
     for (int b = 0; b < nfb; b++)
@@ -1598,7 +1990,12 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       hipLaunchKernelGGL((face_delta_kernel<ND>), dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
     }
   }
-  if (P.viscous && (which == 0 || which == 2))
+  if (variant == 3)
+  {
+    if (which == 0 || which == 2)
+      hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+  }
+  else if (P.viscous && (which == 0 || which == 2))
   {
     ea.pk = F->pk_g;
     ea.tab = F->tab_g;
@@ -1611,7 +2008,19 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       const SplitFaceArgs a = face_args(faces[b]);
       if (a.npairs == 0) continue;
       const unsigned nb = (unsigned)((a.npairs + 255) / 256);
-      if (P.riemann == 0)
+      if (variant == 3)
+      {
+        Split2FaceArgs a2{};
+        a2.npairs = a.npairs; a2.L = a.L; a2.R = a.R; a2.meta = a.meta; a2.plane_f = plane_f;
+        a2.disu = a.disu; a2.fn = F->fn_fpts; a2.fnorm = a.fnorm; a2.tdA = a.tdA; a2.tconf = a.tconf; a2.P = P;
+        if (P.riemann == 0)
+          hipLaunchKernelGGL((face_flux2_kernel<ND, 0>), dim3(nb), dim3(256), 0, st, a2);
+        else if (P.riemann == 2)
+          hipLaunchKernelGGL((face_flux2_kernel<ND, 2>), dim3(nb), dim3(256), 0, st, a2);
+        else
+          hipLaunchKernelGGL((face_flux2_kernel<ND, 3>), dim3(nb), dim3(256), 0, st, a2);
+      }
+      else if (P.riemann == 0)
         hipLaunchKernelGGL((face_flux_kernel<ND, 0>), dim3(nb), dim3(256), 0, st, a);
       else if (P.riemann == 2)
         hipLaunchKernelGGL((face_flux_kernel<ND, 2>), dim3(nb), dim3(256), 0, st, a);
@@ -1621,15 +2030,21 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   }
   if (which == 0 || which == 4)
   {
-    ea.pk = F->pk_r;
-    ea.tab = F->tab_r;
-    hipLaunchKernelGGL((split_residual_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, ea);
+    if (variant == 3)
+      hipLaunchKernelGGL((split_update_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+    else
+    {
+      ea.pk = F->pk_r;
+      ea.tab = F->tab_r;
+      hipLaunchKernelGGL((split_residual_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, ea);
+    }
   }
   HFX_HIP(hipGetLastError());
   return 0;
 }
 
-static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_step, bool last_stage, int which = 0)
+static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_step, bool last_stage, int which = 0,
+                       int variant = 2)
 {
   FusedData *F = e->fused;
   const hfx_params &p = e->ctx->params;
@@ -1655,7 +2070,7 @@ static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_st
   const int N = tensor_n(e);
   int rc = 1;
 #define HFX_SPLIT_CASE(ND_, N_) \
-  if (e->n_dims == ND_ && N == N_) rc = launch_split_stage<ND_, N_>(e, faces, nfb, a, which);
+  if (e->n_dims == ND_ && N == N_) rc = launch_split_stage<ND_, N_>(e, faces, nfb, a, which, variant);
   HFX_SPLIT_CASE(3, 2) HFX_SPLIT_CASE(3, 3) HFX_SPLIT_CASE(3, 4) HFX_SPLIT_CASE(3, 5) HFX_SPLIT_CASE(3, 6)
   HFX_SPLIT_CASE(2, 2) HFX_SPLIT_CASE(2, 3) HFX_SPLIT_CASE(2, 4) HFX_SPLIT_CASE(2, 5) HFX_SPLIT_CASE(2, 6)
 #undef HFX_SPLIT_CASE
@@ -1664,7 +2079,7 @@ static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_st
   return 0;
 }
 
-int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
+int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int variant)
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
   if (!e->fused || !e->fused->built)
@@ -1676,11 +2091,12 @@ int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
   if (hfx_eles_extrapolate_solution(e)) return 1;
   for (int s = 0; s < n_steps; s++)
     for (int rk = 0; rk < nst; rk++)
-      if (split_stage(e, faces, nfb, rk, rk == nst - 1)) return 1;
+      if (split_stage(e, faces, nfb, rk, rk == nst - 1, 0, variant)) return 1;
   return 0;
 }
 
-int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len)
+int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len,
+                       int variant)
 {
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
@@ -1697,7 +2113,7 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
     for (int w = 1; w <= 4; w++)
     {
       HFX_HIP(hipEventRecord(ev[w - 1], st));
-      if (split_stage(e, faces, nfb, rk, rk == nst - 1, w)) return 1;
+      if (split_stage(e, faces, nfb, rk, rk == nst - 1, w, variant)) return 1;
     }
     HFX_HIP(hipEventRecord(ev[4], st));
     HFX_HIP(hipStreamSynchronize(st));
@@ -1711,11 +2127,12 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
   for (auto &x : ev) (void)hipEventDestroy(x);
   for (int i = 0; i < 8; i++) ms[i] = 0.0;
   for (int w = 0; w < 4; w++) ms[w] = acc[w] / reps;
-  snprintf(names, names_len, "face_delta_kernel,split_gradient_kernel,face_flux_kernel,split_residual_kernel");
+  snprintf(names, names_len, "%s", variant == 3 ? "face_delta_kernel,split_flux_kernel,face_flux2_kernel,split_update_kernel"
+                                                : "face_delta_kernel,split_gradient_kernel,face_flux_kernel,split_residual_kernel");
   return 0;
 }
 
-void split_kernel_bytes(const hfx_eles *e, double *bytes)
+void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant)
 {
   // ALGORITHMIC HBM bytes per launch (doubles listed per element)
   const double nu = e->n_upts, nfp = e->n_fpts, nf = e->n_fields, nd = e->n_dims, ne = e->n_eles;
@@ -1724,6 +2141,13 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes)
   bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nf * nd); // + grad_fpts w
   bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf * nd + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp);   // disu, grad, normal(left), tdA r; tconf w
   bytes[3] = ne * 8.0 * (nu * nf + nu * (nd * nd + 1) + nfp * nf + 3 * nu * nf + nfp * nf);           // u, metrics, tconf, u1 r; u0,u1,disu w
+  if (variant == 3)
+  {
+    // u, delta, volume + flux-point metrics, own normals r ; div, norm_tdisf, Fn w
+    bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nd + nu * nf + 2 * nfp * nf);
+    bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp); // disu, Fn, normal(left), tdA r; tconf w
+    bytes[3] = ne * 8.0 * (3 * nu * nf + nu + 2 * nfp * nf + 2 * nu * nf + nfp * nf);            // u0,u1,div,detjac,tconf,ntd r; u0,u1,disu w
+  }
 }
 
 

@@ -175,7 +175,11 @@ int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calc
 int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
 /* n_steps time steps = the RK-stage loop of src/HiFiLES.cpp:194-217:
  * for each stage CalcResidual + AdvanceSolution.  `fused`: 0 the per-method path, 1 the gather-style
- * fused kernels, 2 the split fused kernels (same results to rounding). */
+ * fused kernels, 2 the split fused kernels, 3 the split kernels with the fluxes evaluated in the
+ * gradient kernel (same results to rounding).  All leave disu_upts(0), disu_upts(1), disu_fpts of the
+ * new state and, for the step's last stage, div_tconf_upts in the public arrays; modes 1 and 2 also
+ * leave grad_disu_upts / grad_disu_fpts of the last stage, mode 3 keeps them in registers (run one
+ * per-method stage when a monitor needs them). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
 
 /* One RK stage of the split fused path on a PARTITIONED block, cut so that the caller can move the

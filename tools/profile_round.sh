@@ -10,3 +10,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/p3 -o p3 --output-format csv -
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/p4 -o p4 --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/p4.log 2>&1
 python $R/bench.py --steps 20 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
+python $R/tools/pmc_traffic.py $OUT/p3/p3_counter_collection.csv $OUT/p4/p4_counter_collection.csv $OUT/traffic.json > /dev/null
+python $R/tools/prof_summary.py $OUT/stats/stats_results.db $OUT/kernel_stats.txt > /dev/null
