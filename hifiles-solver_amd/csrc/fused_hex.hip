@@ -69,6 +69,10 @@ struct FusedData
   double *fnorm = nullptr;       // (n_fpts, n_eles, n_dims) the LEFT element's unit normal of the pair
   double *disu_alt = nullptr;    // second disu_fpts buffer
   double *fn_fpts = nullptr;     // split variant 3: projected viscous flux per flux point (n_fpts,n_eles,n_fields)
+  // tensor-product tables of the sum-factorised flux kernel (valid when tensor_ok)
+  bool tensor_ok = false;
+  double *t_coef = nullptr; // Dm[N][N] | c5[ND][2][N] | Lf[ND][2][N] | L1[ND][2][N]
+  int *t_idx = nullptr;     // pf[ND][L][2] | fdq[NFP] | fbase[NFP]
   unsigned *pk_g = nullptr, *pk_r = nullptr; // packed operator rows of the gradient / residual kernel
   double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)
   int *o1m_dim = nullptr;                    // (n_fpts) dimension slab of the merged opp_1 row
@@ -85,7 +89,7 @@ void fused_destroy(hfx_eles *e)
 {
   if (!e || !e->fused) return;
   FusedData *f = e->fused;
-  void *p[] = {f->nbr, f->meta, f->fnorm, f->disu_alt, f->fn_fpts, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
+  void *p[] = {f->nbr, f->meta, f->fnorm, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete f;
@@ -912,6 +916,173 @@ static int dispatch_build_packed(hfx_eles *e, FusedData *F, int N, const std::ve
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Tensor-product structure of the registered operators (checked bit for bit; anything else keeps
+// the dictionary kernels).  With collocated solution / flux bases on a tensor-product element
+//   opp_4[d](p, .) = opp_2[d](p, .) : N entries D[i_d(p)][m] on the pencil through p along d
+//   opp_5[d](p, .)                  : the pencil's two flux points, c5[d][q][i_d(p)]
+//   opp_0(f, .) = opp_6(f, .)       : N entries Lf[d][q][m] on the pencil that ends in f
+//   opp_1 merged (f, .)             : the same pencil, L1[d][q][m]
+// (definitions: /root/reference/src/eles.cpp:3074-3596).
+// ---------------------------------------------------------------------------------------
+static int line_of(int nd, int N, int d, int p, int &i_d)
+{
+  // pencil of point p along d: its index among the N^(nd-1) lines, and the position i_d on it
+  const int S = ipow(N, d);
+  i_d = (p / S) % N;
+  const int base = p - i_d * S;
+  if (nd == 2) return d == 0 ? base / N : base;
+  if (d == 0) return base / N;                    // (j,k): base = N (j + N k)
+  if (d == 1) return (base % N) + N * (base / (N * N)); // (i,k): base = i + N^2 k
+  return base;                                    // (i,j)
+}
+static int base_of_line(int nd, int N, int d, int line)
+{
+  if (nd == 2) return d == 0 ? N * line : line;
+  if (d == 0) return N * line;
+  if (d == 1) return (line % N) + N * N * (line / N);
+  return line;
+}
+
+static bool bits_equal(double a, double b) { return std::memcmp(&a, &b, sizeof a) == 0; }
+
+static int tensor_build(hfx_eles *e, FusedData *F, int N, const std::vector<double> &o1v, const std::vector<int> &o1i,
+                        const std::vector<int> &o1d)
+{
+  F->tensor_ok = false;
+  const int nd = e->n_dims, nu = e->n_upts, nfp = e->n_fpts, L = ipow(N, nd - 1);
+  auto V = [](const Operator &op, int r, int q) { return op.h_val[r + (size_t)op.m * q]; };
+  auto I = [](const Operator &op, int r, int q) { return op.h_idx[r + (size_t)op.m * q]; };
+  for (int d = 0; d < nd; d++)
+    if (e->opp_2[d].nnz_max != N) return 0;
+  if (e->opp_0.nnz_max != N) return 0;
+  const bool visc = e->viscous_ops;
+  std::vector<double> Dm((size_t)N * N), c5((size_t)nd * 2 * N, 0.0), Lf((size_t)nd * 2 * N), L1((size_t)nd * 2 * N);
+  std::vector<int> pf((size_t)nd * L * 2, -1), fdq(nfp, -1), fbase(nfp, -1);
+  for (int i = 0; i < N; i++)
+    for (int m = 0; m < N; m++) Dm[i * N + m] = V(e->opp_2[0], i, m);
+  if (visc)
+    for (int d = 0; d < nd; d++)
+    {
+      if (e->opp_5[d].nnz_max != 2) return 0;
+      for (int p = 0; p < nu; p++)
+      {
+        int i_d;
+        if (line_of(nd, N, d, p, i_d) != 0) continue;
+        for (int q = 0; q < 2; q++) c5[((size_t)d * 2 + q) * N + i_d] = V(e->opp_5[d], p, q);
+      }
+    }
+  for (int d = 0; d < nd; d++)
+  {
+    const int S = ipow(N, d);
+    for (int p = 0; p < nu; p++)
+    {
+      int i_d;
+      const int line = line_of(nd, N, d, p, i_d), base = p - i_d * S;
+      for (int m = 0; m < N; m++)
+      {
+        if (I(e->opp_2[d], p, m) != base + m * S || !bits_equal(V(e->opp_2[d], p, m), Dm[i_d * N + m])) return 0;
+        if (visc && (e->opp_4[d].nnz_max != N || I(e->opp_4[d], p, m) != base + m * S ||
+                     !bits_equal(V(e->opp_4[d], p, m), Dm[i_d * N + m])))
+          return 0;
+      }
+      if (visc)
+      {
+        if (e->opp_5[d].nnz_max != 2) return 0;
+        for (int q = 0; q < 2; q++)
+        {
+          int &slot = pf[((size_t)d * L + line) * 2 + q];
+          const int f = I(e->opp_5[d], p, q);
+          if (slot < 0) slot = f;
+          if (slot != f) return 0;
+          if (!bits_equal(V(e->opp_5[d], p, q), c5[((size_t)d * 2 + q) * N + i_d])) return 0;
+        }
+      }
+    }
+  }
+  if (!visc)
+  {
+    // inviscid blocks have no opp_5: find the two flux points of a pencil from opp_0's columns
+    for (int f = 0; f < nfp; f++)
+    {
+      const int c0 = I(e->opp_0, f, 0), S = I(e->opp_0, f, 1) - c0;
+      int d = -1;
+      for (int dd = 0; dd < nd; dd++)
+        if (S == ipow(N, dd)) d = dd;
+      if (d < 0) return 0;
+      int i_d;
+      const int line = line_of(nd, N, d, c0, i_d);
+      if (i_d != 0) return 0;
+      int *slot = &pf[((size_t)d * L + line) * 2];
+      if (slot[0] < 0) slot[0] = f;
+      else if (slot[1] < 0) slot[1] = f;
+      else return 0;
+    }
+  }
+  // every flux point is the end of exactly one pencil
+  for (int d = 0; d < nd; d++)
+    for (int line = 0; line < L; line++)
+      for (int q = 0; q < 2; q++)
+      {
+        const int f = pf[((size_t)d * L + line) * 2 + q];
+        if (f < 0 || f >= nfp || fdq[f] >= 0) return 0;
+        fdq[f] = d * 2 + q;
+        fbase[f] = base_of_line(nd, N, d, line);
+        const int S = ipow(N, d);
+        if (o1d[f] != d) return 0;
+        for (int m = 0; m < N; m++)
+        {
+          if (I(e->opp_0, f, m) != fbase[f] + m * S || o1i[f + (size_t)nfp * m] != fbase[f] + m * S) return 0;
+          if (visc && (e->opp_6.nnz_max != N || I(e->opp_6, f, m) != fbase[f] + m * S ||
+                       !bits_equal(V(e->opp_6, f, m), V(e->opp_0, f, m))))
+            return 0;
+          double &lf = Lf[((size_t)d * 2 + q) * N + m], &l1 = L1[((size_t)d * 2 + q) * N + m];
+          if (line == 0)
+          {
+            lf = V(e->opp_0, f, m);
+            l1 = o1v[f + (size_t)nfp * m];
+          }
+          if (!bits_equal(lf, V(e->opp_0, f, m)) || !bits_equal(l1, o1v[f + (size_t)nfp * m])) return 0;
+        }
+      }
+  for (int f = 0; f < nfp; f++)
+    if (fdq[f] < 0) return 0;
+  // merged opp_1 row = tnorm * opp_0 row with tnorm = +-1 (exact): keep the sign only
+  for (int dq = 0; dq < nd * 2; dq++)
+  {
+    double sgn = 0.0;
+    for (int m = 0; m < N; m++)
+    {
+      const double lf = Lf[(size_t)dq * N + m], l1 = L1[(size_t)dq * N + m];
+      const double s_m = bits_equal(l1, lf) ? 1.0 : (bits_equal(l1, -lf) ? -1.0 : 0.0);
+      if (s_m == 0.0) return 0;
+      if (lf != 0.0)
+      {
+        if (sgn != 0.0 && s_m != sgn) return 0;
+        sgn = s_m;
+      }
+    }
+    if (sgn == 0.0) return 0;
+    L1[(size_t)dq * N] = sgn;
+  }
+  std::vector<double> coef;
+  coef.insert(coef.end(), Dm.begin(), Dm.end());
+  coef.insert(coef.end(), c5.begin(), c5.end());
+  coef.insert(coef.end(), Lf.begin(), Lf.end());
+  coef.insert(coef.end(), L1.begin(), L1.end());
+  std::vector<int> idx;
+  idx.insert(idx.end(), pf.begin(), pf.end());
+  idx.insert(idx.end(), fdq.begin(), fdq.end());
+  idx.insert(idx.end(), fbase.begin(), fbase.end());
+  if (F->t_coef) { (void)hipFree(F->t_coef); F->t_coef = nullptr; }
+  if (F->t_idx) { (void)hipFree(F->t_idx); F->t_idx = nullptr; }
+  if (upload((void **)&F->t_coef, coef.data(), sizeof(double) * coef.size())) return 1;
+  if (upload((void **)&F->t_idx, idx.data(), sizeof(int) * idx.size())) return 1;
+  F->tensor_ok = true;
+  return 0;
+}
+
 static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allow_unpaired = false)
 {
   HFX_CHECK(e->ele_type == 4 || e->ele_type == 1, "fused path: tensor-product elements only (hexes, quads)");
@@ -964,6 +1135,7 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
     }
     if (upload((void **)&F->o1m_dim, md.data(), sizeof(int) * md.size())) return 1;
     if (dispatch_build_packed(e, F, N, mv, mi)) return 1;
+    if (tensor_build(e, F, N, mv, mi, md)) return 1;
   }
 
   const long plane_f = (long)e->n_fpts * e->n_eles;
@@ -1797,6 +1969,367 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flu
   }
 }
 
+
+// =======================================================================================
+// Sum-factorised ("tensor") form of split_flux_kernel.  On a tensor-product element every operator
+// row is a 1-D stencil along one pencil of N points, with coefficients that depend only on the
+// position along the pencil.  The contractions are therefore done PENCIL-wise: a work item reads
+// its N inputs from LDS once and produces N outputs (N^2 FMAs against the 1-D matrix, which is
+// wave-uniform and lives in scalar registers), instead of one thread per output row reading N
+// inputs and N dictionary values (2N LDS reads + unpacking per output).  ~3x fewer LDS and VALU
+// instructions; the FMAs of an output run over ascending column exactly as in the row form.
+// =======================================================================================
+#ifndef HFX_SPLIT2T_WAVES
+#define HFX_SPLIT2T_WAVES 2
+#endif
+
+// constant address space: loads with a wave-uniform address are selected as scalar loads
+typedef const double __attribute__((address_space(4))) *cdptr;
+
+template <int ND, int N>
+struct TGeo
+{
+  using G = Geo<ND, N>;
+  static constexpr int L = ipow(N, ND - 1);           // pencils per direction
+  static constexpr int ITEMS_D = G::NF * L;           // (field, pencil) items per direction
+  static constexpr int SP = ((ITEMS_D + 63) / 64) * 64; // padded so that a wave works on one direction
+  static constexpr int TB = SGeo<ND, N>::TB;
+  static constexpr int ROUNDS = (ND * SP + TB - 1) / TB;
+  static constexpr int C_D = 0, C_5 = N * N, C_LF = C_5 + ND * 2 * N, C_L1 = C_LF + ND * 2 * N;
+  static constexpr int I_PF = 0, I_FDQ = ND * L * 2, I_FB = I_FDQ + G::NFP;
+};
+
+// LDS read that the load/store optimiser leaves alone: merged pairs become ds_read2_b64, which runs at
+// half the rate of two ds_read_b64 and banks modulo 32 dwords instead of 64 (MI355X_MICROARCH.md, LDS)
+__device__ __forceinline__ double ldsv(const double *p)
+{
+  return *(const volatile __attribute__((address_space(3))) double *)p;
+}
+
+// transformed gradient along direction D on one pencil: sg = Dm x + c5[.][0] delta_a + c5[.][1] delta_b
+template <int ND, int N, int D>
+__device__ __forceinline__ void pencil_grad(cdptr coef, const double *su_p, const double *sda, const double *sdb, double *sg_p)
+{
+  using T = TGeo<ND, N>;
+  constexpr int S = ipow(N, D);
+  double x[N];
+#pragma unroll
+  for (int m = 0; m < N; m++) x[m] = ldsv(su_p + m * S);
+  const double da = ldsv(sda), db = ldsv(sdb);
+#pragma unroll
+  for (int mp = 0; mp < N; mp++)
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < N; m++) acc += coef[T::C_D + mp * N + m] * x[m];
+    acc += coef[T::C_5 + (D * 2 + 0) * N + mp] * da;
+    acc += coef[T::C_5 + (D * 2 + 1) * N + mp] * db;
+    sg_p[mp * S] = acc;
+  }
+}
+
+// d/dxi_D of one pencil of the transformed flux
+template <int ND, int N, int D>
+__device__ __forceinline__ void pencil_div(cdptr coef, const double *st_p, double *sp_p)
+{
+  using T = TGeo<ND, N>;
+  constexpr int S = ipow(N, D);
+  double x[N];
+#pragma unroll
+  for (int m = 0; m < N; m++) x[m] = ldsv(st_p + m * S);
+#pragma unroll
+  for (int mp = 0; mp < N; mp++)
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < N; m++) acc += coef[T::C_D + mp * N + m] * x[m];
+    sp_p[mp * S] = acc;
+  }
+}
+
+template <int ND, int N, int WV>
+__global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kernel(const Split2Args a,
+                                                                                               const double *coef_g,
+                                                                                               const int *tidx)
+{
+  using G = Geo<ND, N>;
+  using T = TGeo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TB = T::TB, NG = NF * ND, L = T::L, ROUNDS = T::ROUNDS;
+  constexpr int R1 = cmax(NF * (NU + NFP), NG * NU);
+  __shared__ double sA[R1];      // su | sd, later st
+  __shared__ double sB[NG * NU]; // sg, later the per-direction parts of the divergence
+  double *const su = sA, *const sd = sA + NF * NU, *const st = sA, *const sg = sB, *const sp = sB;
+  const cdptr coef = (cdptr)(uintptr_t)coef_g;
+  const int t = threadIdx.x;
+  const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
+  const bool is_u = t < NU, is_f = t < NFP;
+  const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
+  const bool viscous = a.P.viscous;
+
+  // flux-point role: the 1-D extrapolation rows of this point and its pencil
+  const int dq = tidx[T::I_FDQ + tf], d_f = dq >> 1;
+  const int bf = tidx[T::I_FB + tf], sf = (d_f == 0) ? 1 : (d_f == 1 ? N : N * N);
+  double Lrow[N];
+#pragma unroll
+  for (int m = 0; m < N; m++) Lrow[m] = coef_g[T::C_LF + dq * N + m];
+  const double sgn1 = coef_g[T::C_L1 + dq * N]; // merged opp_1 row = sgn1 * Lrow (tnorm = +-1)
+  // pencil role: ROUNDS work items (field, direction, pencil); a wave's items share the direction
+  int it_d[ROUNDS], it_o[ROUNDS], it_fa[ROUNDS], it_fb[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++)
+  {
+    const int slot = t + TB * r;
+    int d = slot / T::SP;
+    const int w = slot - d * T::SP;
+    const bool on = d < ND && w < T::ITEMS_D;
+    const int k = on ? w / L : 0, line = on ? w - (w / L) * L : 0;
+    if (d >= ND) d = ND - 1;
+    int base;
+    if (ND == 2)
+      base = d == 0 ? N * line : line;
+    else
+      base = d == 0 ? N * line : (d == 1 ? (line % N) + N * N * (line / N) : line);
+    it_d[r] = on ? d : -1;
+    it_o[r] = (k + NF * d) * NU + base;
+    it_fa[r] = k * NFP + tidx[T::I_PF + (d * L + line) * 2 + 0];
+    it_fb[r] = k * NFP + tidx[T::I_PF + (d * L + line) * 2 + 1];
+  }
+
+  // ---- software pipeline: the inputs of element e+1 (state, delta, volume metrics) are fetched into
+  // registers during phases C/D of element e -- phases with few live registers -- and land in LDS at the
+  // top of the next iteration.  All barriers order LDS traffic only, so these loads and the result
+  // stores stay in flight across them.
+  constexpr int UNP = (NF * NU + TB - 1) / TB, DNP = (NF * NFP + TB - 1) / TB;
+  double pf_u[UNP], pf_d[DNP], JG[ND * ND], inv_detjac = 0.0;
+  auto fetch = [&](long e) {
+#pragma unroll
+    for (int i = 0; i < UNP; i++)
+    {
+      const int q = t + TB * i;
+      if (q < NF * NU)
+      {
+        const int f = q / NU, p2 = q - f * NU;
+        pf_u[i] = a.u0[p2 + NU * e + f * plane_u];
+      }
+    }
+    if (viscous)
+    {
+#pragma unroll
+      for (int i = 0; i < DNP; i++)
+      {
+        const int q = t + TB * i;
+        if (q < NF * NFP)
+        {
+          const int f = q / NFP, p2 = q - f * NFP;
+          pf_d[i] = a.delta[p2 + NFP * e + f * plane_f];
+        }
+      }
+    }
+    const long p = tu + NU * e;
+#pragma unroll
+    for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
+    inv_detjac = viscous ? 1.0 / a.detjac_upts[p] : 0.0;
+  };
+  if ((long)blockIdx.x < ne) fetch(blockIdx.x);
+
+  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  {
+    const long p = tu + NU * e, o = tf + NFP * e;
+    // the pencil addresses of the flux-point role are loop invariant; left alone the compiler hoists
+    // one address register per (plane, m) out of the element loop.  Rebuild the N of them here from an
+    // opaque copy and let the plane offsets be immediates.
+    int am[N];
+    {
+      int bfo = bf;
+      asm volatile("" : "+v"(bfo));
+#pragma unroll
+      for (int m = 0; m < N; m++) am[m] = bfo + m * sf;
+    }
+#pragma unroll
+    for (int i = 0; i < UNP; i++)
+      if (t + TB * i < NF * NU) su[t + TB * i] = pf_u[i];
+    if (viscous)
+    {
+#pragma unroll
+      for (int i = 0; i < DNP; i++)
+        if (t + TB * i < NF * NFP) sd[t + TB * i] = pf_d[i];
+    }
+    lds_barrier();
+
+    // ---- A: transformed gradient, pencil-wise; flux-point solution, point-wise
+    double JF[ND * ND], nrm[ND], inv_df = 0.0;
+    if (viscous)
+    {
+      // flux-point metrics: issued here, used at the start of B
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) JF[q] = a.JGinv_fpts[o * (ND * ND) + q];
+      inv_df = 1.0 / a.detjac_fpts[o];
+#pragma unroll
+      for (int m = 0; m < ND; m++) nrm[m] = a.norm_fpts[o + m * plane_f];
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++)
+      {
+        const int d = __builtin_amdgcn_readfirstlane(it_d[r] < 0 ? (int)((t + TB * r) / T::SP < ND ? (t + TB * r) / T::SP : ND - 1) : it_d[r]);
+        if (it_d[r] >= 0)
+        {
+          const double *su_p = su + (it_o[r] - NF * d * NU);
+          const double *sda = sd + it_fa[r], *sdb = sd + it_fb[r];
+          double *sg_p = sg + it_o[r];
+          if (d == 0)
+            pencil_grad<ND, N, 0>(coef, su_p, sda, sdb, sg_p);
+          else if (d == 1)
+            pencil_grad<ND, N, 1>(coef, su_p, sda, sdb, sg_p);
+          else
+            pencil_grad<ND, N, ND - 1>(coef, su_p, sda, sdb, sg_p);
+        }
+      }
+    }
+    double u[NF], uf[NF];
+    if (is_u)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) u[k] = ldsv(&su[k * NU + tu]);
+    }
+    if (viscous && is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&su[k * NU + am[m]]);
+        uf[k] = s;
+      }
+    }
+    lds_barrier(); // sg complete; su / sd are dead: their region becomes st
+
+    // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
+    if (viscous && is_f)
+    {
+      double grf[NG], fq[NG];
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double tg[ND], cg[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&sg[(k + NF * d) * NU + am[m]]);
+          tg[d] = s;
+        }
+        to_physical<ND>(inv_df, JF, tg, cg);
+#pragma unroll
+        for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
+      }
+      if (a.grad_fpts)
+#pragma unroll
+        for (int q = 0; q < NG; q++) a.grad_fpts[o + q * plane_f] = grf[q];
+      calc_visf<ND, true>(a.P, uf, grf, fq);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < ND; l++) s += fq[k + NF * l] * nrm[l];
+        a.fn_fpts[o + k * plane_f] = s;
+      }
+    }
+    if (is_u)
+    {
+      double tfl[NG];
+      {
+        double f[NG];
+        calc_invf<ND, true>(a.P.gamma, u, f);
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+#pragma unroll
+          for (int l = 0; l < ND; l++)
+          {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+            tfl[k + NF * l] = s;
+          }
+      }
+      if (viscous)
+      {
+        double gr[NG], f[NG];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double tg[ND], cg[ND];
+#pragma unroll
+          for (int d = 0; d < ND; d++) tg[d] = ldsv(&sg[(k + NF * d) * NU + tu]);
+          to_physical<ND>(inv_detjac, JG, tg, cg);
+#pragma unroll
+          for (int d = 0; d < ND; d++) gr[k + NF * d] = cg[d];
+        }
+        if (a.grad_upts)
+#pragma unroll
+          for (int q = 0; q < NG; q++) a.grad_upts[p + q * plane_u] = gr[q];
+        calc_visf<ND, true>(a.P, u, gr, f);
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+#pragma unroll
+          for (int l = 0; l < ND; l++)
+          {
+            double s = tfl[k + NF * l];
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+            tfl[k + NF * l] = s;
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < NG; q++) st[q * NU + tu] = tfl[q];
+    }
+    lds_barrier(); // st complete; sg is dead: its region takes the divergence parts
+
+    // ---- C: next element's inputs on their way; divergence parts pencil-wise, normal flux at the flux points
+    if (e + gridDim.x < ne) fetch(e + gridDim.x);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++)
+    {
+      const int d = __builtin_amdgcn_readfirstlane(it_d[r] < 0 ? (int)((t + TB * r) / T::SP < ND ? (t + TB * r) / T::SP : ND - 1) : it_d[r]);
+      if (it_d[r] >= 0)
+      {
+        if (d == 0)
+          pencil_div<ND, N, 0>(coef, st + it_o[r], sp + it_o[r]);
+        else if (d == 1)
+          pencil_div<ND, N, 1>(coef, st + it_o[r], sp + it_o[r]);
+        else
+          pencil_div<ND, N, ND - 1>(coef, st + it_o[r], sp + it_o[r]);
+      }
+    }
+    if (is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&st[(k + NF * d_f) * NU + am[m]]);
+        a.ntd_fpts[o + k * plane_f] = sgn1 * s;
+      }
+    }
+    lds_barrier();
+    if (is_u)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = ldsv(&sp[k * NU + tu]);
+        s += ldsv(&sp[(k + NF) * NU + tu]);
+        if (ND == 3) s += ldsv(&sp[(k + NF * (ND - 1)) * NU + tu]);
+        a.div[p + k * plane_u] = s;
+      }
+    }
+    // no barrier: the next iteration's writes to sA (dead since the last barrier) do not touch sB, and
+    // its writes to sB come after its first barrier
+  }
+}
+
 struct Split2FaceArgs
 {
   long npairs;
@@ -1890,7 +2423,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB)) void split_update_kernel(const S
       dvin[k] = a.div[p + k * plane_u];
       u1v[k] = a.need_u1 ? a.u1[p + k * plane_u] : 0.0;
     }
-    __syncthreads();
+    lds_barrier();
     if (is_u)
     {
 #pragma unroll
@@ -1938,13 +2471,13 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB)) void split_update_kernel(const S
         su[k][tu] = un;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (is_f)
     {
 #pragma unroll
       for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, O0, PW>(pw, tab, &su[k][0], 0.0);
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -1993,7 +2526,16 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   if (variant == 3)
   {
     if (which == 0 || which == 2)
-      hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+    {
+      static const bool dict_only = getenv("HFX_SPLIT_DICT") != nullptr; // A/B switch for measurements
+      static const int waves = getenv("HFX_SPLIT2T_WAVES") ? atoi(getenv("HFX_SPLIT2T_WAVES")) : HFX_SPLIT2T_WAVES;
+      if (F->tensor_ok && !dict_only && waves == 2)
+        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+      else if (F->tensor_ok && !dict_only)
+        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 3>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+      else
+        hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+    }
   }
   else if (P.viscous && (which == 0 || which == 2))
   {
