@@ -138,15 +138,15 @@ def main():
     ex = None
     if world > 1:
         import exchange
-        if args.mode not in ("auto", "split", "methods"):
+        if args.mode not in ("auto", "split", "split3", "methods"):
             raise SystemExit("N>1 runs the split fused path or the per-method path")
-        ex = exchange.for_case(case, device=torch.device("cuda", local_rank))
+        ex = exchange.for_case(case, device=torch.device("cuda", local_rank), projected_flux=args.mode in ("auto", "split3"))
         case.set_exchange(ex)
 
     mode = args.mode
     fused_ok = False
     if world > 1:
-        mode = "split" if mode == "auto" else mode
+        mode = "split3" if mode == "auto" else mode
     elif mode in ("auto", "fused", "split", "split3"):
         rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(1))
         fused_ok = (rc == 0)

@@ -2711,6 +2711,7 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
   a.tconf = e->arr[HFX_NORM_TCONF_FPTS];
   a.delta = (what == 3) ? nullptr : e->arr[HFX_DELTA_DISU_FPTS];
   a.out_disu = f->out_disu; a.out_grad = f->out_grad; a.in_disu = f->in_disu; a.in_grad = f->in_grad;
+  a.fn = e->fused ? e->fused->fn_fpts : nullptr;
   a.P = e->ctx->phys();
   const dim3 g((unsigned)((a.npairs + 255) / 256)), b(256);
   hipStream_t st = e->ctx->stream;
@@ -2721,6 +2722,8 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
   case 2: hipLaunchKernelGGL(mpi_pack_grad_kernel<ND>, g, b, 0, st, a); break;
   case 3: hipLaunchKernelGGL((mpi_common_invflux_kernel<ND, true>), g, b, 0, st, a); break;
   case 4: hipLaunchKernelGGL((mpi_common_viscflux_kernel<ND, true>), g, b, 0, st, a); break;
+  case 5: hipLaunchKernelGGL(mpi_pack_fn_kernel<ND>, g, b, 0, st, a); break;
+  case 6: hipLaunchKernelGGL(mpi_common_flux2_kernel<ND>, g, b, 0, st, a); break;
   }
   HFX_HIP(hipGetLastError());
   return 0;
@@ -2742,6 +2745,7 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     return 0;
   };
   const bool last = in_step == nst - 1;
+  const int variant = (e->ctx->fused_mode == 2) ? 2 : 3; // 3: fluxes in the gradient kernel, Fn on the wire
   switch (phase)
   {
   case 0:
@@ -2749,18 +2753,29 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     return first ? mpi_all(0) : 0;
   case 1:
     if (!p.viscous) return 0;
-    return split_stage(e, int_faces, n_int, in_step, false, 1); // interior LDG common solution
+    return split_stage(e, int_faces, n_int, in_step, false, 1, variant); // interior LDG common solution
   case 2:
+    if (variant == 3)
+    {
+      if (p.viscous && mpi_all(1)) return 1;
+      if (split_stage(e, int_faces, n_int, in_step, false, 2, 3)) return 1; // gradient + fluxes; allocates fn_fpts
+      return p.viscous ? mpi_all(5) : 0;
+    }
     if (!p.viscous) return 0;
     if (mpi_all(1)) return 1;
-    if (split_stage(e, int_faces, n_int, in_step, false, 2)) return 1; // corrected gradients
+    if (split_stage(e, int_faces, n_int, in_step, false, 2, 2)) return 1; // corrected gradients
     return mpi_all(2);
   case 3:
-    if (split_stage(e, int_faces, n_int, in_step, last, 3)) return 1; // interior common fluxes
-    return mpi_all(3);
+    if (split_stage(e, int_faces, n_int, in_step, last, 3, variant)) return 1; // interior common fluxes
+    return variant == 3 ? 0 : mpi_all(3);
   case 4:
-    if (p.viscous && mpi_all(4)) return 1;
-    if (split_stage(e, int_faces, n_int, in_step, last, 4)) return 1; // residual, RK, new disu_fpts (swaps)
+    if (variant == 3)
+    {
+      if (mpi_all(6)) return 1;
+    }
+    else if (p.viscous && mpi_all(4))
+      return 1;
+    if (split_stage(e, int_faces, n_int, in_step, last, 4, variant)) return 1; // residual, RK, new disu_fpts (swaps)
     return mpi_all(0);
   default:
     HFX_CHECK(false, "hfx_stage_partitioned: phase %d out of range", phase);

@@ -795,11 +795,11 @@ int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f)
 int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n)
 {
   HFX_CHECK(f && f->is_mpi && dev && n, "hfx_mpi_inters_buffer: bad argument");
-  HFX_CHECK(which >= 0 && which <= 3, "hfx_mpi_inters_buffer: which must be 0..3");
+  HFX_CHECK(which >= 0 && which <= 5, "hfx_mpi_inters_buffer: which must be 0..5");
   const long nd = (long)f->n_inters * f->n_fpts_per_inter * f->left->n_fields;
-  double *b[4] = {f->out_disu, f->in_disu, f->out_grad, f->in_grad};
+  double *b[6] = {f->out_disu, f->in_disu, f->out_grad, f->in_grad, f->out_grad, f->in_grad};
   *dev = b[which];
-  *n = (which < 2) ? nd : nd * f->left->n_dims;
+  *n = (which == 2 || which == 3) ? nd * f->left->n_dims : nd;
   return 0;
 }
 

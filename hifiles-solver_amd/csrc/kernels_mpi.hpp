@@ -17,6 +17,7 @@ struct MpiArgs
   const int *L, *Rlut;
   long plane; // n_fpts*n_eles of the left block
   const double *disu, *grad, *norm, *tdA;
+  const double *fn; // split variant 3: viscous flux of the left side projected on its own normal
   double *tconf, *delta;
   double *out_disu, *out_grad;
   const double *in_disu, *in_grad;
@@ -162,6 +163,67 @@ __global__ __launch_bounds__(256) void mpi_common_viscflux_kernel(const MpiArgs 
     }
     fn -= a.P.ldg_tau * (ur[k] - ul[k]);
     a.tconf[il + k * a.plane] += fn * tl;
+  }
+}
+
+// ---- split variant 3: the neighbour sends its projected viscous flux Fn = F_v(u,grad).n_own (n_fields
+// doubles per flux point) instead of the gradient (n_fields*n_dims): a third of the bytes on the wire.
+// The record layout is out_buffer_disu's; the gradient buffers carry it.
+template <int ND>
+__global__ __launch_bounds__(256) void mpi_pack_fn_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const int j = (int)(q - i * a.nfpi);
+  const long il = a.L[q];
+#pragma unroll
+  for (int k = 0; k < NF; k++) a.out_grad[j + (long)a.nfpi * (k + NF * i)] = a.fn[il + k * a.plane];
+}
+
+// total common flux of a partition face from the exchanged solution and projected fluxes (left side only)
+template <int ND>
+__global__ __launch_bounds__(256) void mpi_common_flux2_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const long il = a.L[q];
+  const int jr = a.Rlut[q];
+  double ul[NF], ur[NF], n[ND], fn[NF];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu[il + k * a.plane];
+    ur[k] = a.in_disu[jr + (long)a.nfpi * (k + NF * i)];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.norm[il + m * a.plane];
+  if (a.P.riemann == 0)
+    riemann_flux_t<ND, 0, true>(a.P, ul, ur, n, fn);
+  else if (a.P.riemann == 2)
+    riemann_flux_t<ND, 2, true>(a.P, ul, ur, n, fn);
+  else
+    riemann_flux_t<ND, 3, true>(a.P, ul, ur, n, fn);
+  const double tl = a.tdA[il];
+  if (a.P.viscous)
+  {
+    const double beta = ldg_switch<ND>(a.P.ldg_beta, n);
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      // the neighbour projected on ITS normal = -n
+      double fv = (0.5 + beta) * a.fn[il + k * a.plane] - (0.5 - beta) * a.in_grad[jr + (long)a.nfpi * (k + NF * i)];
+      fv -= a.P.ldg_tau * (ur[k] - ul[k]);
+      a.tconf[il + k * a.plane] = fn[k] * tl + fv * tl;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < NF; k++) a.tconf[il + k * a.plane] = fn[k] * tl;
   }
 }
 

@@ -117,15 +117,16 @@ class Exchange:
         (self.start if phase == 0 else self.wait)(kind)
 
 
-def for_case(case, group=None, device=None):
-    """Exchange wired to the device buffers of a partitioned hfx_host.Case that is on the device."""
+def for_case(case, group=None, device=None, projected_flux=False):
+    """Exchange wired to the device buffers of a partitioned hfx_host.Case that is on the device.
+    projected_flux: kind 1 moves buffers 4/5 (what hfx_stage_partitioned sends in fused mode 3)."""
     import hfx
     L, Rlut, nout = case.mpi_faces()
     h = case.mpi_handle()
     if not h:
         return None
     device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    t = [device_tensor(*hfx.mpi_buffer(h, w), device) for w in range(4)]
+    t = [device_tensor(*hfx.mpi_buffer(h, w), device) for w in ((0, 1, 4, 5) if projected_flux else (0, 1, 2, 3))]
     stream = torch.cuda.ExternalStream(case.stream(), device=device)
     p = case.params()
     bufs = {0: (t[0], t[1])}

@@ -164,7 +164,9 @@ int hfx_mpi_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int n_fpts
 /* the packing half of mpi_inters::send_solution / send_corrected_gradient (src/mpi_inters.cpp:218-229,278-289) */
 int hfx_mpi_inters_pack_solution(hfx_inters *f);
 int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f);
-/* device pointers and lengths (doubles) of the four buffers: which = 0 out_disu, 1 in_disu, 2 out_grad, 3 in_grad */
+/* device pointers and lengths (doubles) of the buffers: which = 0 out_disu, 1 in_disu, 2 out_grad, 3 in_grad;
+ * 4 / 5 = the leading n_fpts_per_inter*n_fields*n_inters doubles of out_grad / in_grad, which is what
+ * hfx_stage_partitioned sends in fused mode 3 (the projected viscous flux instead of the gradient) */
 int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
@@ -193,8 +195,12 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int 
  *                                                                          -> caller WAITS for the gradient
  *   phase 4: viscous common flux on partition faces, residual, RK update (in_step), the new state's
  *            flux-point solution packed into out_buffer_disu               -> caller STARTS solution exchange
- * Inviscid runs skip phases 1-2 (they return at once).  `first` != 0 on the first stage after the caller
- * changed disu_upts(0). */
+ * Inviscid runs have nothing to send after phase 2.  `first` != 0 on the first stage after the caller
+ * changed disu_upts(0).  With the context's fused mode 2 the kernels are those of hfx_run_steps(fused=2)
+ * and the second exchange carries the corrected gradient (buffers 2/3, as the reference does); otherwise
+ * (default) those of fused=3, and the second exchange carries each side's viscous flux projected on
+ * its own normal (buffers 4/5: n_fields instead of n_fields*n_dims doubles per flux point) and the
+ * partition faces' common flux is evaluated in phase 4. */
 int hfx_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
                           int n_mpi, int phase, int in_step, int first);
 

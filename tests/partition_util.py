@@ -127,7 +127,11 @@ def gpu_worker(rank, world, port, n_local, pgrid, cfg, n_steps, outdir, mode, ba
     try:
         c = H.Case(list(n_local), rank=rank, pgrid=list(pgrid), **cfg)
         c.to_device(dev)
-        ex = exchange.for_case(c, device=torch.device("cuda", dev))
+        if mode == "fused2":
+            import ctypes as C
+            import hfx
+            hfx.check(hfx.lib().hfx_ctx_set_fused_mode(c.handles()[0], C.c_int(2)))
+        ex = exchange.for_case(c, device=torch.device("cuda", dev), projected_flux=(mode == "fused"))
         if ex is not None:
             c.set_exchange(ex)
         if mode == "methods":

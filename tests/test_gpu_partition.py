@@ -1,7 +1,8 @@
 """N>1 path on the GPU: 2 and 4 ranks (all on the box's one card, exchange over gloo with host staging)
 drive libhfx's partition-face kernels -- through the mirrored CalcResidual with the reference's
 send/receive call order, and through hfx_stage_partitioned (split fused kernels) -- and must reproduce
-the single-rank oracle of the global box."""
+the single-rank oracle of the global box.  "fused" = fused mode 3 (projected viscous flux on the wire),
+"fused2" = fused mode 2 (corrected gradient on the wire, as the reference)."""
 import numpy as np
 import pytest
 
@@ -16,7 +17,7 @@ def rel(a, b):
     return np.abs(a - b).max() / (s if s > 0 else 1.0)
 
 
-@pytest.mark.parametrize("mode", ["methods", "fused"])
+@pytest.mark.parametrize("mode", ["methods", "fused", "fused2"])
 @pytest.mark.parametrize("n_local,pgrid,kw", [
     ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=3)),
     ([4, 4, 2], [1, 1, 2], dict(riemann_solve_type=0, order=3)),
