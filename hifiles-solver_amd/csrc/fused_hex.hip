@@ -2669,8 +2669,11 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
   for (auto &x : ev) (void)hipEventDestroy(x);
   for (int i = 0; i < 8; i++) ms[i] = 0.0;
   for (int w = 0; w < 4; w++) ms[w] = acc[w] / reps;
-  snprintf(names, names_len, "%s", variant == 3 ? "face_delta_kernel,split_flux_kernel,face_flux2_kernel,split_update_kernel"
-                                                : "face_delta_kernel,split_gradient_kernel,face_flux_kernel,split_residual_kernel");
+  const bool tensor = e->fused->tensor_ok && getenv("HFX_SPLIT_DICT") == nullptr;
+  snprintf(names, names_len, "%s",
+           variant == 3 ? (tensor ? "face_delta_kernel,split_flux_tensor_kernel,face_flux2_kernel,split_update_kernel"
+                                  : "face_delta_kernel,split_flux_kernel,face_flux2_kernel,split_update_kernel")
+                        : "face_delta_kernel,split_gradient_kernel,face_flux_kernel,split_residual_kernel");
   return 0;
 }
 
