@@ -1147,6 +1147,17 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
   for (int b = 0; b < nfb; b++)
   {
     hfx_inters *f = faces[b];
+    if (f->is_bdy)
+    {
+      // boundary points: one-sided kernels; bit2 asks the flux kernel to store the gradient there
+      HFX_CHECK(f->left == e, "fused path: boundary block of another element block");
+      for (size_t q = 0; q < f->hL.size(); q++)
+      {
+        nbr[f->hL[q]] = f->hL[q];
+        meta[f->hL[q]] |= 4;
+      }
+      continue;
+    }
     HFX_CHECK(f->left == e && f->right == e, "fused path: face blocks must connect the element block to itself");
     const long np = (long)f->n_inters * f->n_fpts_per_inter;
     for (long q = 0; q < np; q++)
@@ -1292,6 +1303,8 @@ static int fused_stage(hfx_eles *e, int in_step, bool last_stage, int which = 0)
 int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
+  for (int b = 0; b < nfb; b++)
+    HFX_CHECK(!faces[b]->is_bdy, "the gather-style fused path (fused=1) has no boundary faces: use fused=2 or 3");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
   if (n_steps <= 0) return 0;
@@ -1781,6 +1794,7 @@ struct Split2Args
   double *div;      // div_tdisf (flux kernel) -> read by the update kernel, which may overwrite it with div_tconf
   double *disu_next;
   double *grad_upts, *grad_fpts; // optional outputs (NULL: not written)
+  const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
   const double *src, *dt_local;
   unsigned long long *nan_flag;
   Phys P;
@@ -1951,7 +1965,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flu
 #pragma unroll
           for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
         }
-        if (a.grad_fpts)
+        if (a.grad_fpts && (a.meta == nullptr || (a.meta[o] & 4)))
 #pragma unroll
           for (int q = 0; q < NG; q++) a.grad_fpts[o + q * plane_f] = grf[q];
         calc_visf<ND, true>(a.P, uf, grf, fq);
@@ -2223,7 +2237,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 #pragma unroll
         for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
       }
-      if (a.grad_fpts)
+      if (a.grad_fpts && (a.meta == nullptr || (a.meta[o] & 4)))
 #pragma unroll
         for (int q = 0; q < NG; q++) a.grad_fpts[o + q * plane_f] = grf[q];
       calc_visf<ND, true>(a.P, uf, grf, fq);
@@ -2509,7 +2523,11 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.u0 = ea.u0; e2.u1 = ea.u1; e2.delta = ea.delta; e2.tconf = ea.tconf;
     e2.fn_fpts = F->fn_fpts; e2.ntd_fpts = e->arr[HFX_NORM_TDISF_FPTS]; e2.div = ea.div_out;
     e2.disu_next = ea.disu_next;
-    e2.grad_upts = nullptr; e2.grad_fpts = nullptr;
+    bool any_bdy = false;
+    for (int b = 0; b < nfb; b++) any_bdy = any_bdy || faces[b]->is_bdy;
+    e2.grad_upts = nullptr;
+    e2.grad_fpts = (any_bdy && P.viscous) ? e->arr[HFX_GRAD_DISU_FPTS] : nullptr; // boundary points only
+    e2.meta = F->meta;
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;
     e2.adv_type = ea.adv_type; e2.in_step = ea.in_step; e2.dt_local_on = ea.dt_local_on; e2.write_div = ea.write_div;
     e2.need_u1 = ea.need_u1; e2.dt = ea.dt; e2.rk_a = ea.rk_a; e2.rk_b = ea.rk_b;
@@ -2518,6 +2536,12 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   {
     for (int b = 0; b < nfb; b++)
     {
+      if (faces[b]->is_bdy)
+      {
+        // ghost state -> inviscid common flux and LDG common solution of the boundary points
+        if (hfx_bdy_launch_internal(faces[b], 0, 1)) return 1;
+        continue;
+      }
       const SplitFaceArgs a = face_args(faces[b]);
       if (a.npairs == 0) continue;
       hipLaunchKernelGGL((face_delta_kernel<ND>), dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
@@ -2547,6 +2571,11 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   {
     for (int b = 0; b < nfb; b++)
     {
+      if (faces[b]->is_bdy)
+      {
+        if (hfx_bdy_launch_internal(faces[b], P.viscous ? 1 : 0, 1)) return 1;
+        continue;
+      }
       const SplitFaceArgs a = face_args(faces[b]);
       if (a.npairs == 0) continue;
       const unsigned nb = (unsigned)((a.npairs + 255) / 256);

@@ -9,6 +9,7 @@
 #include "fused_hex.hpp"
 #include "hfx_internal.hpp"
 #include "kernels_ops.hpp"
+#include "kernels_bdy.hpp"
 #include "kernels_mpi.hpp"
 #include "kernels_point.hpp"
 
@@ -711,9 +712,106 @@ int hfx_inters_destroy(hfx_inters *f)
   if (f->R) (void)hipFree(f->R);
   for (double *b : {f->out_disu, f->in_disu, f->out_grad, f->in_grad})
     if (b) (void)hipFree(b);
+  if (f->boundary_id) (void)hipFree(f->boundary_id);
+  if (f->bcs) (void)hipFree(f->bcs);
   delete f;
   return 0;
 }
+
+// ---- bdy_inters ----------------------------------------------------------------------
+int hfx_bdy_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, const int *L, const int *boundary_id,
+                          const hfx_bc *bcs, int n_bcs, double R_ref, hfx_inters **out)
+{
+  HFX_CHECK(ctx && left && out, "hfx_bdy_inters_create: NULL argument");
+  HFX_CHECK(n_inters >= 0 && nfpi > 0 && n_bcs >= 0, "hfx_bdy_inters_create: bad sizes");
+  HFX_CHECK(n_inters == 0 || (L && boundary_id && bcs && n_bcs > 0), "hfx_bdy_inters_create: NULL table");
+  const long np = (long)n_inters * nfpi;
+  const long pl = (long)left->n_fpts * left->n_eles;
+  for (long q = 0; q < np; q++) HFX_CHECK(L[q] >= 0 && L[q] < pl, "boundary face table L[%ld] = %d out of range", q, L[q]);
+  for (int i = 0; i < n_inters; i++)
+  {
+    HFX_CHECK(boundary_id[i] >= 0 && boundary_id[i] < n_bcs, "boundary_id[%d] = %d out of range", i, boundary_id[i]);
+    const hfx_bc &b = bcs[boundary_id[i]];
+    HFX_CHECK(b.flag >= HFX_BC_SUB_IN_SIMP && b.flag <= HFX_BC_SLIP_WALL_DUAL && b.flag != HFX_BC_CYCLIC,
+              "Boundary condition not implemented yet (bc_flag %d)", b.flag); /* src/input.cpp:341 */
+    HFX_CHECK(!((b.flag == HFX_BC_ISOTHERM_WALL || b.flag == HFX_BC_ADIABAT_WALL) && b.use_wm),
+              "boundary group %d uses the wall model, which is not part of this path", boundary_id[i]);
+    HFX_CHECK(b.flag != HFX_BC_ADIABAT_WALL || ctx->params.viscous || !ctx->have_params,
+              "Adiabatic wall boundary only available to viscous simulation"); /* src/input.cpp:427 */
+  }
+  hfx_inters *f = new hfx_inters();
+  f->ctx = ctx; f->left = left; f->right = nullptr; f->n_inters = n_inters; f->n_fpts_per_inter = nfpi;
+  f->is_bdy = true;
+  f->n_bcs = n_bcs;
+  f->R_ref = R_ref;
+  f->hL.assign(L, L + np);
+  const size_t ni = (size_t)std::max<long>(np, 1);
+  HFX_HIP(hipMalloc((void **)&f->L, sizeof(int) * ni));
+  HFX_HIP(hipMemcpy(f->L, L, sizeof(int) * (size_t)np, hipMemcpyHostToDevice));
+  HFX_HIP(hipMalloc((void **)&f->boundary_id, sizeof(int) * (size_t)std::max(n_inters, 1)));
+  HFX_HIP(hipMemcpy(f->boundary_id, boundary_id, sizeof(int) * (size_t)n_inters, hipMemcpyHostToDevice));
+  HFX_HIP(hipMalloc((void **)&f->bcs, sizeof(hfx_bc) * (size_t)std::max(n_bcs, 1)));
+  HFX_HIP(hipMemcpy(f->bcs, bcs, sizeof(hfx_bc) * (size_t)n_bcs, hipMemcpyHostToDevice));
+  left->faces_attached.push_back(f);
+  fused_invalidate(left);
+  *out = f;
+  return 0;
+}
+
+int hfx_bdy_inters_set_ramp_counter(hfx_inters *f, int ramp_counter)
+{
+  HFX_CHECK(f && f->is_bdy, "not a boundary-face block");
+  f->ramp_counter = ramp_counter;
+  return 0;
+}
+
+static BdyArgs bdy_args(hfx_inters *f)
+{
+  BdyArgs a{};
+  hfx_eles *l = f->left;
+  a.npts = (long)f->n_inters * f->n_fpts_per_inter;
+  a.nfpi = f->n_fpts_per_inter;
+  a.L = f->L; a.boundary_id = f->boundary_id; a.bcs = f->bcs;
+  a.plane = (long)l->n_fpts * l->n_eles;
+  a.disu = l->arr[HFX_DISU_FPTS]; a.grad = l->arr[HFX_GRAD_DISU_FPTS];
+  a.norm = l->norm_fpts; a.tdA = l->tdA_fpts;
+  a.tconf = l->arr[HFX_NORM_TCONF_FPTS]; a.delta = l->arr[HFX_DELTA_DISU_FPTS];
+  a.P = f->ctx->phys();
+  a.R_ref = f->R_ref;
+  a.ramp_counter = f->ramp_counter;
+  return a;
+}
+
+// fast != 0: the fused paths' reciprocal-multiply physics
+int hfx_bdy_launch_internal(hfx_inters *f, int visc, int fast)
+{
+  HFX_CHECK(f && f->is_bdy, "not a boundary-face block");
+  HFX_CHECK(f->ctx->have_params, "parameters not set");
+  if (f->n_inters == 0) return 0;
+  const BdyArgs a = bdy_args(f);
+  const dim3 g((unsigned)((a.npts + 255) / 256)), b(256);
+  hipStream_t st = f->ctx->stream;
+  const int nd = f->left->n_dims;
+#define HFX_BDY(K)                                                             \
+  if (nd == 2 && fast) hipLaunchKernelGGL((K<2, true>), g, b, 0, st, a);       \
+  else if (nd == 2) hipLaunchKernelGGL((K<2, false>), g, b, 0, st, a);         \
+  else if (fast) hipLaunchKernelGGL((K<3, true>), g, b, 0, st, a);             \
+  else hipLaunchKernelGGL((K<3, false>), g, b, 0, st, a);
+  if (visc)
+  {
+    HFX_BDY(bdy_viscflux_kernel)
+  }
+  else
+  {
+    HFX_BDY(bdy_invflux_kernel)
+  }
+#undef HFX_BDY
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+int hfx_bdy_inters_evaluate_boundaryConditions_invFlux(hfx_inters *f, double /*time_bound*/) { return hfx_bdy_launch_internal(f, 0, 0); }
+int hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(hfx_inters *f, double /*time_bound*/) { return hfx_bdy_launch_internal(f, 1, 0); }
 
 // ---- mpi_inters ----------------------------------------------------------------------
 int hfx_mpi_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, const int *L, const int *Rlut,
@@ -869,7 +967,9 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
   if (viscous && hfx_eles_calculate_gradient(e)) return 1;
   if (hfx_eles_evaluate_invFlux(e)) return 1;
   for (int b = 0; b < nfb; b++)
-    if (hfx_int_inters_calculate_common_invFlux(faces[b])) return 1;
+    if (!faces[b]->is_bdy && hfx_int_inters_calculate_common_invFlux(faces[b])) return 1;
+  for (int b = 0; b < nfb; b++)
+    if (faces[b]->is_bdy && hfx_bdy_inters_evaluate_boundaryConditions_invFlux(faces[b], 0.0)) return 1;
   if (viscous)
   {
     if (hfx_eles_correct_gradient(e)) return 1;
@@ -878,8 +978,12 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
   if (hfx_eles_extrapolate_totalFlux(e)) return 1;
   if (hfx_eles_calculate_divergence(e)) return 1;
   if (viscous)
+  {
     for (int b = 0; b < nfb; b++)
-      if (hfx_int_inters_calculate_common_viscFlux(faces[b])) return 1;
+      if (!faces[b]->is_bdy && hfx_int_inters_calculate_common_viscFlux(faces[b])) return 1;
+    for (int b = 0; b < nfb; b++)
+      if (faces[b]->is_bdy && hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(faces[b], 0.0)) return 1;
+  }
   return hfx_eles_calculate_corrected_divergence(e);
 }
 

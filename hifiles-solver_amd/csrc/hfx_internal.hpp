@@ -116,4 +116,14 @@ struct hfx_inters
   // partition faces (is_mpi): R holds the received-record slot lut(j); buffers are owned here
   bool is_mpi = false;
   double *out_disu = nullptr, *in_disu = nullptr, *out_grad = nullptr, *in_grad = nullptr;
+  // boundary faces (is_bdy): left side only
+  bool is_bdy = false;
+  int *boundary_id = nullptr; // device (n_inters)
+  hfx_bc *bcs = nullptr;      // device (n_bcs)
+  int n_bcs = 0, ramp_counter = 0;
+  double R_ref = 0.0;
 };
+
+// boundary-face kernels (hfx.hip); visc 0: inviscid sweep (+ LDG common solution), 1: viscous sweep;
+// fast: the fused paths' reciprocal-multiply physics
+extern "C" int hfx_bdy_launch_internal(hfx_inters *f, int visc, int fast);

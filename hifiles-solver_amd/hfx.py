@@ -38,6 +38,36 @@ class ElesDesc(C.Structure):
         ("tdA_fpts", dp), ("norm_fpts", dp)]
 
 
+class Bc(C.Structure):
+    """hfx_bc: one entry of run_input.bc_list after non-dimensionalisation."""
+    _fields_ = [(n, C.c_int) for n in ("flag", "pressure_ramp", "use_wm", "pad")] + \
+               [("rho", C.c_double), ("velocity", C.c_double * 3)] + \
+               [(n, C.c_double) for n in ("p_static", "T_static", "p_total", "T_total", "nx", "ny", "nz",
+                                          "p_ramp_coeff", "T_ramp_coeff", "p_total_old", "T_total_old")]
+
+
+(BC_SUB_IN_SIMP, BC_SUB_OUT_SIMP, BC_SUB_IN_CHAR, BC_SUB_OUT_CHAR, BC_SUP_IN, BC_SUP_OUT, BC_SLIP_WALL, BC_CYCLIC,
+ BC_ISOTHERM_WALL, BC_ADIABAT_WALL, BC_CHAR, BC_SLIP_WALL_DUAL) = range(12)
+
+
+def bc_records(flags, params):
+    """Bc array from the fixture form: flags (3,nbc) = flag, pressure_ramp, use_wm; params (15,nbc) = rho, velocity[3],
+    p_static, T_static, p_total, T_total, nx, ny, nz, p_ramp_coeff, T_ramp_coeff, p_total_old, T_total_old."""
+    fl = np.asarray(flags).reshape(3, -1, order="F")
+    par = np.asarray(params).reshape(15, -1, order="F")
+    out = (Bc * fl.shape[1])()
+    for b in range(fl.shape[1]):
+        r = out[b]
+        r.flag, r.pressure_ramp, r.use_wm = int(fl[0, b]), int(fl[1, b]), int(fl[2, b])
+        q = par[:, b]
+        r.rho = q[0]
+        for d in range(3):
+            r.velocity[d] = q[1 + d]
+        (r.p_static, r.T_static, r.p_total, r.T_total, r.nx, r.ny, r.nz,
+         r.p_ramp_coeff, r.T_ramp_coeff, r.p_total_old, r.T_total_old) = [float(v) for v in q[4:15]]
+    return out
+
+
 def declared_symbols():
     """Names of every function include/hfx.h declares."""
     txt = open(HEADER).read()
@@ -192,6 +222,32 @@ class IntInters:
 
     def calculate_common_invFlux(self): check(lib().hfx_int_inters_calculate_common_invFlux(self.h))
     def calculate_common_viscFlux(self): check(lib().hfx_int_inters_calculate_common_viscFlux(self.h))
+
+    def close(self):
+        if self.h:
+            lib().hfx_inters_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class BdyInters:
+    """Boundary-face block (bdy_inters): left side only, ghost state from the group's record."""
+
+    def __init__(self, ctx, left, L, boundary_id, bcs, R_ref, ramp_counter=0):
+        L = np.asfortranarray(np.array(L, dtype=np.int32))
+        ids = np.ascontiguousarray(np.array(boundary_id, dtype=np.int32).ravel())
+        self.n_fpts_per_inter, self.n_inters = L.shape
+        self.h = C.c_void_p()
+        check(lib().hfx_bdy_inters_create(ctx.h, left.h, C.c_int(self.n_inters), C.c_int(self.n_fpts_per_inter),
+                                          L.ctypes.data_as(ip), ids.ctypes.data_as(ip), bcs, C.c_int(len(bcs)),
+                                          C.c_double(R_ref), C.byref(self.h)))
+        if ramp_counter:
+            check(lib().hfx_bdy_inters_set_ramp_counter(self.h, C.c_int(ramp_counter)))
+
+    def evaluate_boundaryConditions_invFlux(self, time=0.0):
+        check(lib().hfx_bdy_inters_evaluate_boundaryConditions_invFlux(self.h, C.c_double(time)))
+
+    def evaluate_boundaryConditions_viscFlux(self, time=0.0):
+        check(lib().hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(self.h, C.c_double(time)))
 
     def close(self):
         if self.h:

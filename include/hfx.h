@@ -171,9 +171,35 @@ int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
 
+/* ---- boundary faces (reference class bdy_inters) ------------------------ */
+/* bc_flag values of the reference (src/bc.cpp:36-48) */
+enum hfx_bc_flag
+{
+  HFX_BC_SUB_IN_SIMP = 0, HFX_BC_SUB_OUT_SIMP = 1, HFX_BC_SUB_IN_CHAR = 2, HFX_BC_SUB_OUT_CHAR = 3, HFX_BC_SUP_IN = 4,
+  HFX_BC_SUP_OUT = 5, HFX_BC_SLIP_WALL = 6, HFX_BC_CYCLIC = 7, HFX_BC_ISOTHERM_WALL = 8, HFX_BC_ADIABAT_WALL = 9,
+  HFX_BC_CHAR = 10, HFX_BC_SLIP_WALL_DUAL = 11
+};
+/* one entry of run_input.bc_list (include/bc.h:48-62), values AFTER input::read_boundary_param's
+ * non-dimensionalisation (src/input.cpp:440-525); fields a type does not use are ignored */
+typedef struct hfx_bc
+{
+  int flag, pressure_ramp, use_wm, pad;
+  double rho, velocity[3], p_static, T_static, p_total, T_total, nx, ny, nz;
+  double p_ramp_coeff, T_ramp_coeff, p_total_old, T_total_old;
+} hfx_bc;
+/* L(j,i): offset of the face's flux point in the left block's (fpt,ele) plane (what bdy_inters::set_boundary,
+ * src/bdy_inters.cpp:75-135, stores as pointers); boundary_id(i): index into bcs (bdy_inters::boundary_id);
+ * R_ref: run_input.R_ref for viscous runs, run_input.R_gas for inviscid ones (src/bdy_inters.cpp:368-369).
+ * Wall-model groups (use_wm) and the LES inlet are not part of this path and are refused. */
+int hfx_bdy_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int n_fpts_per_inter, const int *L,
+                          const int *boundary_id, const hfx_bc *bcs, int n_bcs, double R_ref, hfx_inters **out);
+int hfx_bdy_inters_set_ramp_counter(hfx_inters *f, int ramp_counter); /* run_input.ramp_counter (pressure ramps) */
+int hfx_bdy_inters_evaluate_boundaryConditions_invFlux(hfx_inters *f, double time_bound);  /* src/bdy_inters.cpp:213 */
+int hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(hfx_inters *f, double time_bound); /* src/bdy_inters.cpp:1024 */
+
 /* ---- the caller contract ---------------------------------------------- */
-/* CalcResidual (src/solver.cpp:50-223) for one element block and its interior
- * face blocks, LES / RANS / forcing off; same call order as the reference. */
+/* CalcResidual (src/solver.cpp:50-223) for one element block and its interior and boundary
+ * face blocks (any mix, in `faces`), LES / RANS / forcing off; same call order as the reference. */
 int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
 /* n_steps time steps = the RK-stage loop of src/HiFiLES.cpp:194-217:
  * for each stage CalcResidual + AdvanceSolution.  `fused`: 0 the per-method path, 1 the gather-style

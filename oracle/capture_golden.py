@@ -54,10 +54,33 @@ BASE = dict(
 BASE.update(TGV_FLUID)
 
 
-def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, **over):
+def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, **over):
     d = dict(BASE)
     d.update(over)
-    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d)
+    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs)
+
+
+# boundary groups for the bdy_inters fixtures: states near the TGV initial state (rho 8.42e-4, T 300, Mach 0.1)
+P_TGV = 0.0008421095852102401 * 286.9 * 300.0
+BC_KEYS = dict(
+    # an inlet group makes InitSolution -> bdy_inters::add_les_inlet read the interface-cubature metrics, which the
+    # reference only sets up when forces are requested (src/eles.cpp:4023): without this key it segfaults
+    calc_force=1, monitor_cp_freq=100000000, area_ref=1.0,
+    bc_In_type="sub_in_char", bc_In_p_total=P_TGV * 1.0070, bc_In_T_total=300.6, bc_In_nx=0.0, bc_In_ny=0.0, bc_In_nz=1.0,
+    bc_Out_type="sub_out_char", bc_Out_p_static=P_TGV * 0.999,
+    bc_WallT_type="isotherm_wall", bc_WallT_T_static=310.0, bc_WallT_u=3.0,
+    bc_WallQ_type="adiabat_wall", bc_WallQ_v=-2.0,
+    bc_Far_type="char", bc_Far_p_static=P_TGV, bc_Far_mach=0.12, bc_Far_T_static=295.0, bc_Far_nx=0.8, bc_Far_ny=0.6, bc_Far_nz=0.0,
+    bc_Slip_type="slip_wall",
+    bc_InS_type="sub_in_simp", bc_InS_rho=0.00085, bc_InS_u=20.0, bc_InS_v=5.0, bc_InS_w=-3.0,
+    bc_OutS_type="sub_out_simp", bc_OutS_p_static=P_TGV * 1.001,
+    bc_SupI_type="sup_in", bc_SupI_p_static=P_TGV * 1.1, bc_SupI_mach=1.5, bc_SupI_T_static=290.0, bc_SupI_nx=0.0, bc_SupI_ny=0.0,
+    bc_SupI_nz=1.0,
+    bc_SupO_type="sup_out",
+    bc_Dual_type="slip_wall_dual",
+    bc_InR_type="sub_in_char", bc_InR_p_total=P_TGV * 1.0070, bc_InR_T_total=300.6, bc_InR_nx=0.0, bc_InR_ny=1.0, bc_InR_nz=0.0,
+    bc_InR_pressure_ramp=1, bc_InR_p_ramp_coeff=0.01, bc_InR_T_ramp_coeff=-1.0, bc_InR_p_total_old=P_TGV * 1.002,
+)
 
 
 CASES = [
@@ -79,6 +102,20 @@ CASES = [
     case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
     case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
     case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+    # boundary faces (bdy_inters): every ghost-state branch that the shipped cases use
+    case("hex_p2_bdy_walls", amp=0.1, level=2, order=2, steps=1,
+         bcs={"z-": "In", "z+": "Out", "y-": "WallT", "y+": "WallQ", "x-": "Far", "x+": "Slip"}, **BC_KEYS),
+    case("hex_p2_bdy_inout", amp=0.1, level=2, order=2, steps=1, riemann_solve_type=0,
+         bcs={"y-": "InS", "y+": "OutS", "z-": "SupI", "z+": "SupO"}, **BC_KEYS),
+    case("hex_p1_bdy_inviscid", amp=0.1, level=2, order=1, steps=2, viscous=0, ic_form=1, riemann_solve_type=2,
+         rho_c_ic=1.2, u_c_ic=30.0, v_c_ic=10.0, w_c_ic=5.0, p_c_ic=101325.0,
+         bcs={"y-": "Dual", "y+": "Slip", "z-": "FarI", "z+": "OutI"},
+         bc_FarI_type="char", bc_FarI_p_static=101325.0, bc_FarI_mach=0.1, bc_FarI_T_static=294.0, bc_FarI_nx=1.0,
+         bc_OutI_type="sub_out_simp", bc_OutI_p_static=101000.0, bc_OutI_T_total=300.0, **BC_KEYS),
+    case("quad_p3_bdy", dims=2, n=4, amp=0.1, level=2, order=3, steps=1,
+         bcs={"y-": "WallT", "y+": "Far2", "x-": "InR", "x+": "Out"},
+         bc_Far2_type="char", bc_Far2_p_static=P_TGV, bc_Far2_mach=0.12, bc_Far2_T_static=295.0, bc_Far2_nx=0.8, bc_Far2_ny=0.6,
+         **BC_KEYS),
 ]
 
 
@@ -105,7 +142,7 @@ def read_dump(path):
 
 def run_case(c):
     with tempfile.TemporaryDirectory() as td:
-        xv = write_neu(os.path.join(td, "mesh.neu"), c["n"], c["dims"], amp=c["amp"])
+        xv = write_neu(os.path.join(td, "mesh.neu"), c["n"], c["dims"], amp=c["amp"], bcs=c.get("bcs"))
         keys = dict(c["keys"])
         keys["n_steps"] = c["steps"]
         if c["dims"] == 2:
@@ -122,7 +159,7 @@ def run_case(c):
         arrs = read_dump(os.path.join(td, "dump.bin"))
     arrs["xv"] = xv
     meta = dict(name=c["name"], n=c["n"], dims=c["dims"], amp=c["amp"], steps=c["steps"],
-                level=c["level"], keys=c["keys"],
+                level=c["level"], keys=c["keys"], bcs=c.get("bcs"),
                 generator="oracle/capture_golden.py via oracle/_ref/ref_harness (genuine reference)")
     arrs["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     os.makedirs(GOLDEN, exist_ok=True)

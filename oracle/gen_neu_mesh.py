@@ -59,7 +59,14 @@ def box_vertices(n, dims, length=2.0 * math.pi, amp=0.0):
         return np.stack([x, y], axis=1)
 
 
-def write_neu(path, n, dims=3, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
+SIDES3 = ("z-", "y-", "x+", "y+", "x-", "z+")  # code faces 0..5 of a hex
+SIDES2 = ("y-", "x+", "y+", "x-")              # code faces 0..3 of a quad
+
+
+def write_neu(path, n, dims=3, length=2.0 * math.pi, amp=0.0, bcname="Cyclic", bcs=None):
+    """bcs: optional {side: boundary-group name} (sides "x-","x+","y-","y+","z-","z+"); sides that are not
+    listed belong to the group `bcname`.  One BOUNDARY CONDITIONS section is written per group
+    (mesh_reader.cpp:310-372 reads n_bdy of them); the group's type comes from the input key bc_<name>_type."""
     if isinstance(n, int):
         n = [n] * dims
     xv = box_vertices(n, dims, length, amp)
@@ -75,7 +82,12 @@ def write_neu(path, n, dims=3, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
         f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\nperiodic_box\n")
         f.write("PROGRAM:                Gambit     VERSION:  2.3.16\n\n")
         f.write("     NUMNP     NELEM     NGRPS    NBSETS     NDFCD     NDFVL\n")
-        f.write("%10d%10d%10d%10d%10d%10d\n" % (nv, ne, 1, 1, dims, dims))
+        groups = []
+        for side in (SIDES3 if dims == 3 else SIDES2):
+            g = (bcs or {}).get(side, bcname)
+            if g not in groups:
+                groups.append(g)
+        f.write("%10d%10d%10d%10d%10d%10d\n" % (nv, ne, 1, len(groups), dims, dims))
         f.write("ENDOFSECTION\n   NODAL COORDINATES 2.3.16\n")
         for i in range(nv):
             f.write("%10d" % (i + 1) + "".join(" %.17e" % c for c in xv[i]) + "\n")
@@ -97,33 +109,36 @@ def write_neu(path, n, dims=3, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
                         f.write("%8d %2d %2d " % (e, 4, 8) + "".join("%8d" % v for v in nodes[:7]) + "\n")
                         f.write(" " * 15 + "%8d\n" % nodes[7])
                         # gambit face ids (mesh_reader.cpp:336-350): code face 0<-1, 3<-2, 5<-3, 1<-4, 4<-5, 2<-6
-                        if k == 0: bfaces.append((e, 4, 1))       # z-min : code face 0
-                        if j == 0: bfaces.append((e, 4, 4))       # y-min : code face 1
-                        if i == nx - 1: bfaces.append((e, 4, 6))  # x-max : code face 2
-                        if j == ny - 1: bfaces.append((e, 4, 2))  # y-max : code face 3
-                        if i == 0: bfaces.append((e, 4, 5))       # x-min : code face 4
-                        if k == nz - 1: bfaces.append((e, 4, 3))  # z-max : code face 5
+                        if k == 0: bfaces.append((e, 4, 1, "z-"))       # z-min : code face 0
+                        if j == 0: bfaces.append((e, 4, 4, "y-"))       # y-min : code face 1
+                        if i == nx - 1: bfaces.append((e, 4, 6, "x+"))  # x-max : code face 2
+                        if j == ny - 1: bfaces.append((e, 4, 2, "y+"))  # y-max : code face 3
+                        if i == 0: bfaces.append((e, 4, 5, "x-"))       # x-min : code face 4
+                        if k == nz - 1: bfaces.append((e, 4, 3, "z+"))  # z-max : code face 5
                     else:
                         # quad slots 0:(0,0) 1:(1,0) 2:(0,1) 3:(1,1); file order -> slots 0,1,3,2
                         slot = {r + 2 * s: vid(i + r, j + s) for s in range(2) for r in range(2)}
                         nodes = [slot[0], slot[1], slot[3], slot[2]]
                         f.write("%8d %2d %2d " % (e, 2, 4) + "".join("%8d" % v for v in nodes) + "\n")
                         # quad faces (eles_quads.cpp:209-248): 0: eta=-1, 1: xi=+1, 2: eta=+1, 3: xi=-1; gambit k = face+1
-                        if j == 0: bfaces.append((e, 2, 1))
-                        if i == nx - 1: bfaces.append((e, 2, 2))
-                        if j == ny - 1: bfaces.append((e, 2, 3))
-                        if i == 0: bfaces.append((e, 2, 4))
+                        if j == 0: bfaces.append((e, 2, 1, "y-"))
+                        if i == nx - 1: bfaces.append((e, 2, 2, "x+"))
+                        if j == ny - 1: bfaces.append((e, 2, 3, "y+"))
+                        if i == 0: bfaces.append((e, 2, 4, "x-"))
         f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
         f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n" % (1, ne, 2, 1))
         f.write("                           fluid\n       0\n")
         ids = list(range(1, ne + 1))
         for s in range(0, ne, 10):
             f.write("".join("%8d" % v for v in ids[s:s + 10]) + "\n")
-        f.write("ENDOFSECTION\n BOUNDARY CONDITIONS 2.3.16\n")
-        f.write("%32s%8d%8d%8d%8d\n" % (bcname, 1, len(bfaces), 0, 6))
-        for (el, ty, fc) in bfaces:
-            f.write("%10d%5d%5d\n" % (el, ty, fc))
         f.write("ENDOFSECTION\n")
+        for g in groups:
+            mine = [b for b in bfaces if (bcs or {}).get(b[3], bcname) == g]
+            f.write(" BOUNDARY CONDITIONS 2.3.16\n")
+            f.write("%32s%8d%8d%8d%8d\n" % (g, 1, len(mine), 0, 6))
+            for (el, ty, fc, _) in mine:
+                f.write("%10d%5d%5d\n" % (el, ty, fc))
+            f.write("ENDOFSECTION\n")
     return xv
 
 

@@ -774,6 +774,372 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, con
 }
 
 /* ------------------------------------------------------------------------ */
+/* boundary faces                                                            */
+
+/* src/bdy_inters.cpp:340-1019, equation 0 (Navier-Stokes / Euler), RANS off, wall model off */
+void orc_set_boundary_conditions(int sol_spec, const orc_bc *bc, int nd, int viscous, const double *u_l, double *u_r,
+                                 const double *norm, double gamma, double R_ref, int ramp_counter)
+{
+  double rho_l, rho_r = 0., v_l[MAXD], v_r[MAXD] = {0., 0., 0.}, e_l, e_r = 0., p_l, p_r, T_l, T_r, vn_l, v_sq, machn_l;
+  const int bc_flag = bc->flag;
+  (void)viscous;
+  rho_l = u_l[0];
+  for (int i = 0; i < nd; i++) v_l[i] = u_l[i + 1] / u_l[0];
+  e_l = u_l[nd + 1];
+  v_sq = 0.;
+  for (int i = 0; i < nd; i++) v_sq += (v_l[i] * v_l[i]);
+  p_l = (gamma - 1.0) * (e_l - 0.5 * rho_l * v_sq);
+  T_l = p_l / (rho_l * R_ref);
+
+  if (bc_flag == ORC_SUB_IN_SIMP)
+  {
+    rho_r = bc->rho;
+    for (int i = 0; i < nd; i++) v_r[i] = bc->velocity[i];
+    v_sq = 0.;
+    for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+    e_r = p_l / (gamma - 1.0) + 0.5 * rho_r * v_sq;
+  }
+  else if (bc_flag == ORC_SUB_OUT_SIMP)
+  {
+    vn_l = 0.;
+    for (int i = 0; i < nd; i++) vn_l += v_l[i] * norm[i];
+    machn_l = fabs(vn_l) / sqrt(gamma * p_l / rho_l);
+    if (vn_l < 0)
+    {
+      for (int i = 0; i < nd; i++) v_r[i] = vn_l * norm[i];
+      v_sq = 0.;
+      for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+      T_r = bc->T_total - 0.5 * v_sq * (gamma - 1.0) / (R_ref * gamma);
+      p_r = bc->p_static * pow((1.0 + 0.5 * (gamma - 1.0) * (v_sq / (gamma * R_ref * T_r))), -gamma / (gamma - 1.0));
+      rho_r = p_r / (R_ref * T_r);
+      e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+    }
+    else if (vn_l >= 0 && machn_l >= 1)
+    {
+      rho_r = rho_l;
+      for (int i = 0; i < nd; i++) v_r[i] = v_l[i];
+      e_r = e_l;
+    }
+    else
+    {
+      for (int i = 0; i < nd; i++) v_r[i] = v_l[i];
+      rho_r = rho_l;
+      p_r = bc->p_static;
+      v_sq = 0.;
+      for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+      e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+    }
+  }
+  else if (bc_flag == ORC_SUB_IN_CHAR)
+  {
+    double V_r, c_l, c_r_sq, c_total_sq, R_plus, aa, bb, cc, dd, Mach_sq, alpha, p_total_temp, T_total_temp;
+    if (bc->pressure_ramp)
+    {
+      if (bc->p_ramp_coeff)
+      {
+        p_total_temp = bc->p_total_old + (bc->p_total - bc->p_total_old) * bc->p_ramp_coeff * ramp_counter;
+        if (p_total_temp >= bc->p_total) p_total_temp = bc->p_total;
+      }
+      else
+        p_total_temp = bc->p_total;
+      if (bc->T_ramp_coeff > 0)
+      {
+        T_total_temp = bc->T_total_old + (bc->T_total - bc->T_total_old) * bc->T_ramp_coeff * ramp_counter;
+        if (T_total_temp >= bc->T_total) T_total_temp = bc->T_total;
+      }
+      else if (bc->T_ramp_coeff < 0)
+        T_total_temp = T_l * pow(p_total_temp / p_l, (gamma - 1.0) / gamma);
+      else
+        T_total_temp = bc->T_total;
+    }
+    else
+    {
+      p_total_temp = bc->p_total;
+      T_total_temp = bc->T_total;
+    }
+    const double n_free_stream[3] = {bc->nx, bc->ny, bc->nz};
+    vn_l = 0.;
+    for (int i = 0; i < nd; i++) vn_l += v_l[i] * norm[i];
+    c_l = sqrt(gamma * p_l / rho_l);
+    R_plus = vn_l + 2.0 * c_l / (gamma - 1.0);
+    c_total_sq = gamma * R_ref * T_total_temp;
+    alpha = 0.;
+    for (int i = 0; i < nd; i++) alpha += norm[i] * n_free_stream[i];
+    aa = 1.0 + 0.5 * (gamma - 1.0) * alpha * alpha;
+    bb = -(gamma - 1.0) * alpha * R_plus;
+    cc = 0.5 * (gamma - 1.0) * R_plus * R_plus - 2.0 * c_total_sq / (gamma - 1.0);
+    dd = bb * bb - 4.0 * aa * cc;
+    dd = sqrt(dd > 0.0 ? dd : 0.0); /* std::max(dd, 0.0) */
+    V_r = (-bb + dd) / (2.0 * aa);
+    V_r = V_r > 0.0 ? V_r : 0.0;
+    v_sq = V_r * V_r;
+    c_r_sq = c_total_sq - 0.5 * (gamma - 1.0) * v_sq;
+    Mach_sq = v_sq / (c_r_sq);
+    Mach_sq = Mach_sq < 1.0 ? Mach_sq : 1.0;
+    v_sq = Mach_sq * c_r_sq;
+    V_r = sqrt(v_sq);
+    c_r_sq = c_total_sq - 0.5 * (gamma - 1.0) * v_sq;
+    for (int i = 0; i < nd; i++) v_r[i] = V_r * n_free_stream[i];
+    T_r = c_r_sq / (gamma * R_ref);
+    p_r = p_total_temp * pow(T_r / T_total_temp, gamma / (gamma - 1.0));
+    rho_r = p_r / (R_ref * T_r);
+    e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+  }
+  else if (bc_flag == ORC_SUB_OUT_CHAR)
+  {
+    double c_l, c_r, R_plus, s, vn_r;
+    vn_l = 0.;
+    for (int i = 0; i < nd; i++) vn_l += v_l[i] * norm[i];
+    c_l = sqrt(gamma * p_l / rho_l);
+    R_plus = vn_l + 2.0 * c_l / (gamma - 1.0);
+    s = p_l / pow(rho_l, gamma);
+    p_r = bc->p_static;
+    rho_r = pow(p_r / s, 1.0 / gamma);
+    c_r = sqrt(gamma * p_r / rho_r);
+    vn_r = R_plus - 2.0 * c_r / (gamma - 1.0);
+    v_sq = 0.;
+    for (int i = 0; i < nd; i++)
+    {
+      v_r[i] = v_l[i] + (vn_r - vn_l) * norm[i];
+      v_sq += (v_r[i] * v_r[i]);
+    }
+    e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+  }
+  else if (bc_flag == ORC_SUP_IN)
+  {
+    rho_r = bc->rho;
+    for (int i = 0; i < nd; i++) v_r[i] = bc->velocity[i];
+    p_r = bc->p_static;
+    v_sq = 0.;
+    for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+    e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+  }
+  else if (bc_flag == ORC_SUP_OUT)
+  {
+    rho_r = rho_l;
+    for (int i = 0; i < nd; i++) v_r[i] = v_l[i];
+    e_r = e_l;
+  }
+  else if (bc_flag == ORC_SLIP_WALL)
+  {
+    rho_r = rho_l;
+    vn_l = 0.;
+    for (int i = 0; i < nd; i++) vn_l += v_l[i] * norm[i];
+    if (sol_spec == 0)
+      for (int i = 0; i < nd; i++) v_r[i] = v_l[i] - 2 * vn_l * norm[i];
+    else
+      for (int i = 0; i < nd; i++) v_r[i] = v_l[i] - vn_l * norm[i];
+    v_sq = 0.;
+    for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+    e_r = p_l / (gamma - 1.0) + 0.5 * rho_r * v_sq;
+  }
+  else if (bc_flag == ORC_ISOTHERM_WALL)
+  {
+    T_r = bc->T_static;
+    rho_r = rho_l;
+    if (sol_spec == 0)
+      for (int i = 0; i < nd; i++) v_r[i] = 2 * bc->velocity[i] - v_l[i];
+    else
+      for (int i = 0; i < nd; i++) v_r[i] = bc->velocity[i];
+    v_sq = 0.;
+    for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+    e_r = rho_r * (R_ref / (gamma - 1.0) * T_r) + 0.5 * rho_r * v_sq;
+  }
+  else if (bc_flag == ORC_ADIABAT_WALL)
+  {
+    rho_r = rho_l;
+    if (sol_spec == 0)
+      for (int i = 0; i < nd; i++) v_r[i] = 2 * bc->velocity[i] - v_l[i];
+    else
+      for (int i = 0; i < nd; i++) v_r[i] = bc->velocity[i];
+    v_sq = 0.;
+    for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+    e_r = p_l / (gamma - 1.0) + 0.5 * rho_r * v_sq;
+  }
+  else if (bc_flag == ORC_CHAR)
+  {
+    double c_star, vn_star, vn_r, r_plus, r_minus, c_l, c_r, one_over_s, mach;
+    vn_l = 0.;
+    for (int i = 0; i < nd; i++) vn_l += v_l[i] * norm[i];
+    vn_r = 0;
+    for (int i = 0; i < nd; i++) vn_r += bc->velocity[i] * norm[i];
+    c_l = sqrt(gamma * p_l / rho_l);
+    c_r = sqrt(gamma * bc->p_static / bc->rho);
+    mach = fabs(vn_l) / c_l;
+    if (vn_l < 0)
+    {
+      if (mach >= 1)
+      {
+        r_minus = vn_r - 2. / (gamma - 1.) * c_r;
+        r_plus = vn_r + 2. / (gamma - 1.) * c_r;
+      }
+      else
+      {
+        r_plus = vn_l + 2. / (gamma - 1.) * c_l;
+        r_minus = vn_r - 2. / (gamma - 1.) * c_r;
+      }
+      c_star = 0.25 * (gamma - 1.) * (r_plus - r_minus);
+      vn_star = 0.5 * (r_plus + r_minus);
+      one_over_s = pow(bc->rho, gamma) / bc->p_static;
+      rho_r = pow(1. / gamma * (one_over_s * c_star * c_star), 1. / (gamma - 1.));
+      for (int i = 0; i < nd; i++) v_r[i] = vn_star * norm[i] + (bc->velocity[i] - vn_r * norm[i]);
+      v_sq = 0.;
+      for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+      p_r = rho_r / gamma * c_star * c_star;
+      e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+    }
+    else
+    {
+      if (mach >= 1)
+      {
+        r_minus = vn_l - 2. / (gamma - 1.) * c_l;
+        r_plus = vn_l + 2. / (gamma - 1.) * c_l;
+      }
+      else
+      {
+        r_plus = vn_l + 2. / (gamma - 1.) * c_l;
+        r_minus = vn_r - 2. / (gamma - 1.) * c_r;
+      }
+      c_star = 0.25 * (gamma - 1.) * (r_plus - r_minus);
+      vn_star = 0.5 * (r_plus + r_minus);
+      one_over_s = pow(rho_l, gamma) / p_l;
+      rho_r = pow(1. / gamma * (one_over_s * c_star * c_star), 1. / (gamma - 1.));
+      for (int i = 0; i < nd; i++) v_r[i] = vn_star * norm[i] + (v_l[i] - vn_l * norm[i]);
+      v_sq = 0.;
+      for (int i = 0; i < nd; i++) v_sq += (v_r[i] * v_r[i]);
+      p_r = rho_r / gamma * c_star * c_star;
+      e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+    }
+  }
+  else if (bc_flag == ORC_SLIP_WALL_DUAL)
+  {
+    rho_r = rho_l;
+    vn_l = 0.;
+    for (int i = 0; i < nd; i++) vn_l += v_l[i] * norm[i];
+    for (int i = 0; i < nd; i++) v_r[i] = v_l[i] - 2 * vn_l * norm[i];
+    e_r = e_l;
+  }
+  u_r[0] = rho_r;
+  for (int i = 0; i < nd; i++) u_r[i + 1] = rho_r * v_r[i];
+  u_r[nd + 1] = e_r;
+}
+
+/* src/bdy_inters.cpp:1138-1189 ; gradients stored (field, dim) */
+void orc_set_boundary_gradients(const orc_bc *bc, int nd, const double *u_r, const double *grad_ul, double *grad_ur,
+                                const double *norm)
+{
+  const int nf = nd + 2, bc_flag = bc->flag;
+  if (bc_flag == ORC_CHAR || bc_flag == ORC_SUP_IN || bc_flag == ORC_SUB_IN_SIMP || bc_flag == ORC_SUB_OUT_SIMP)
+    for (int q = 0; q < nf * nd; q++) grad_ur[q] = 0.;
+  else
+    for (int q = 0; q < nf * nd; q++) grad_ur[q] = grad_ul[q];
+  if (bc_flag == ORC_ADIABAT_WALL)
+  {
+    double v_sq = 0., inte, grad_vel[MAXD * MAXD], grad_inte[MAXD];
+#define GU(l, k) grad_ur[(l) + nf * (k)]
+    for (int i = 0; i < nd; i++) v_sq += (u_r[i + 1] * u_r[i + 1]);
+    inte = (u_r[nd + 1] - 0.5 * v_sq / u_r[0]) / u_r[0];
+    for (int j = 0; j < nd; j++)
+      for (int i = 0; i < nd; i++) grad_vel[i + nd * j] = (GU(i + 1, j) - GU(0, j) * u_r[i + 1] / u_r[0]) / u_r[0];
+    if (nd == 2)
+    {
+      for (int i = 0; i < nd; i++)
+        grad_inte[i] = GU(3, i) - (inte * GU(0, i) + 0.5 * v_sq / (u_r[0] * u_r[0]) * GU(0, i) + u_r[1] * grad_vel[0 + nd * i] +
+                                   u_r[2] * grad_vel[1 + nd * i]);
+      for (int i = 0; i < nd; i++) GU(3, i) -= (grad_inte[0] * norm[0] + grad_inte[1] * norm[1]) * norm[i];
+    }
+    else
+    {
+      for (int i = 0; i < nd; i++)
+        grad_inte[i] = GU(4, i) - (inte * GU(0, i) + 0.5 * v_sq / (u_r[0] * u_r[0]) * GU(0, i) + u_r[1] * grad_vel[0 + nd * i] +
+                                   u_r[2] * grad_vel[1 + nd * i] + u_r[3] * grad_vel[2 + nd * i]);
+      for (int i = 0; i < nd; i++)
+        GU(4, i) -= (grad_inte[0] * norm[0] + grad_inte[1] * norm[1] + grad_inte[2] * norm[2]) * norm[i];
+    }
+#undef GU
+  }
+}
+
+static int orc_is_wall(int f)
+{
+  return f == ORC_SLIP_WALL || f == ORC_ISOTHERM_WALL || f == ORC_ADIABAT_WALL || f == ORC_SLIP_WALL_DUAL;
+}
+
+/* src/bdy_inters.cpp:213-338 */
+void orc_bdy_evaluate_boundaryConditions_invFlux(const orc_bdy_inters *F, orc_eles *e, const orc_params *P)
+{
+  const int nd = e->n_dims, nf = e->n_fields;
+  const long plane = (long)e->n_fpts * e->n_eles;
+  const int nfi = F->n_fpts_per_inter;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < F->n_inters; i++)
+  {
+    const orc_bc *bc = &F->bcs[F->boundary_id[i]];
+    for (int j = 0; j < nfi; j++)
+    {
+      const long il = F->L[j + (long)nfi * i];
+      double ul[MAXF], ur[MAXF], fl[MAXF * MAXD], fr[MAXF * MAXD], norm[MAXD], fn[MAXF], uc[MAXF];
+      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      for (int k = 0; k < nf; k++) ul[k] = e->disu_fpts[il + k * plane];
+      orc_set_boundary_conditions(0, bc, nd, P->viscous, ul, ur, norm, P->gamma, F->R_ref, F->ramp_counter);
+      orc_calc_invf(nd, P->gamma, ul, fl);
+      orc_calc_invf(nd, P->gamma, ur, fr);
+      if (bc->flag == ORC_SLIP_WALL_DUAL)
+      {
+        for (int k = 0; k < nf; k++)
+        {
+          fn[k] = 0.;
+          for (int l = 0; l < nd; l++) fn[k] += fl[k + nf * l] * norm[l];
+        }
+      }
+      else if (P->riemann_solve_type == 0)
+        orc_rusanov_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      else if (P->riemann_solve_type == 2)
+        orc_roeM_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      else
+        orc_hllc_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
+      for (int k = 0; k < nf; k++) e->norm_tconf_fpts[il + k * plane] = fn[k] * e->tdA_fpts[il];
+      if (P->viscous)
+      {
+        if (orc_is_wall(bc->flag))
+          orc_set_boundary_conditions(1, bc, nd, P->viscous, ul, ur, norm, P->gamma, F->R_ref, F->ramp_counter);
+        orc_ldg_solution(1, nd, ul, ur, uc, P->ldg_beta, norm);
+        for (int k = 0; k < nf; k++) e->delta_disu_fpts[il + k * plane] = (uc[k] - ul[k]);
+      }
+    }
+  }
+}
+
+/* src/bdy_inters.cpp:1024-1136, faces without wall model */
+void orc_bdy_evaluate_boundaryConditions_viscFlux(const orc_bdy_inters *F, orc_eles *e, const orc_params *P)
+{
+  const int nd = e->n_dims, nf = e->n_fields;
+  const long plane = (long)e->n_fpts * e->n_eles;
+  const int nfi = F->n_fpts_per_inter;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < F->n_inters; i++)
+  {
+    const orc_bc *bc = &F->bcs[F->boundary_id[i]];
+    if (bc->flag == ORC_SLIP_WALL) continue;
+    for (int j = 0; j < nfi; j++)
+    {
+      const long il = F->L[j + (long)nfi * i];
+      double ul[MAXF], ur[MAXF], gl[MAXF * MAXD], gr[MAXF * MAXD], fl[MAXF * MAXD], fr[MAXF * MAXD], norm[MAXD], fn[MAXF];
+      for (int k = 0; k < nf; k++) ul[k] = e->disu_fpts[il + k * plane];
+      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      for (int k = 0; k < nd; k++)
+        for (int l = 0; l < nf; l++) gl[l + nf * k] = e->grad_disu_fpts[il + (l + (long)nf * k) * plane];
+      orc_set_boundary_conditions(1, bc, nd, P->viscous, ul, ur, norm, P->gamma, F->R_ref, F->ramp_counter);
+      orc_set_boundary_gradients(bc, nd, ur, gl, gr, norm);
+      orc_calc_visf(nd, P, ur, gr, fr);
+      for (int q = 0; q < nf * nd; q++) fl[q] = 0.; /* unused by flux_spec 1 */
+      orc_ldg_flux(1, nd, ul, ur, fl, fr, norm, fn, P->ldg_tau, P->ldg_beta);
+      for (int k = 0; k < nf; k++) e->norm_tconf_fpts[il + k * plane] += fn[k] * e->tdA_fpts[il];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
 /* partition faces                                                           */
 
 /* src/mpi_inters.cpp:225-229 : counter order inter -> field -> fpt */
@@ -868,12 +1234,14 @@ void orc_mpi_calculate_common_viscFlux(const orc_mpi_inters *F, orc_eles *e, con
 
 /* ------------------------------------------------------------------------ */
 /* src/solver.cpp:50-223, single rank, LES / RANS / forcing / over_int off   */
-long orc_CalcResidual(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *P)
+long orc_CalcResidual_bdy(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_bdy_inters *bdy,
+                          int n_bdy_blocks, const orc_params *P)
 {
   orc_extrapolate_solution(e);
   if (P->viscous) orc_calculate_gradient(e);
   orc_evaluate_invFlux(e, P);
   for (int b = 0; b < n_face_blocks; b++) orc_int_calculate_common_invFlux(&faces[b], e, P);
+  for (int b = 0; b < n_bdy_blocks; b++) orc_bdy_evaluate_boundaryConditions_invFlux(&bdy[b], e, P);
   if (P->viscous)
   {
     orc_correct_gradient(e);
@@ -882,12 +1250,21 @@ long orc_CalcResidual(orc_eles *e, const orc_int_inters *faces, int n_face_block
   orc_extrapolate_totalFlux(e);
   orc_calculate_divergence(e);
   if (P->viscous)
+  {
     for (int b = 0; b < n_face_blocks; b++) orc_int_calculate_common_viscFlux(&faces[b], e, P);
+    for (int b = 0; b < n_bdy_blocks; b++) orc_bdy_evaluate_boundaryConditions_viscFlux(&bdy[b], e, P);
+  }
   return orc_calculate_corrected_divergence(e);
 }
 
+long orc_CalcResidual(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *P)
+{
+  return orc_CalcResidual_bdy(e, faces, n_face_blocks, 0, 0, P);
+}
+
 /* one time step = the RK-stage loop of src/HiFiLES.cpp:201-217 */
-long orc_rk_step(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *P)
+long orc_rk_step_bdy(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_bdy_inters *bdy,
+                     int n_bdy_blocks, const orc_params *P)
 {
   int RKSteps = 1;
   if (P->adv_type == 1 || P->adv_type == 2)
@@ -898,9 +1275,14 @@ long orc_rk_step(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, co
     RKSteps = 14;
   for (int s = 0; s < RKSteps; s++)
   {
-    long bad = orc_CalcResidual(e, faces, n_face_blocks, P);
+    long bad = orc_CalcResidual_bdy(e, faces, n_face_blocks, bdy, n_bdy_blocks, P);
     if (bad >= 0) return bad;
     orc_AdvanceSolution(e, P, s);
   }
   return -1;
+}
+
+long orc_rk_step(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *P)
+{
+  return orc_rk_step_bdy(e, faces, n_face_blocks, 0, 0, P);
 }

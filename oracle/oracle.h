@@ -89,6 +89,32 @@ typedef struct orc_mpi_inters
   double *out_grad, *in_grad; /* (n_fpts_per_inter,n_fields,n_dims,n_inters) */
 } orc_mpi_inters;
 
+/* boundary faces (reference class bdy_inters, src/bdy_inters.cpp).  One record per entry of
+ * run_input.bc_list (include/bc.h:48-62), values AFTER input::read_boundary_param's
+ * non-dimensionalisation (src/input.cpp:440-525). */
+enum
+{
+  ORC_SUB_IN_SIMP = 0, ORC_SUB_OUT_SIMP = 1, ORC_SUB_IN_CHAR = 2, ORC_SUB_OUT_CHAR = 3, ORC_SUP_IN = 4,
+  ORC_SUP_OUT = 5, ORC_SLIP_WALL = 6, ORC_CYCLIC = 7, ORC_ISOTHERM_WALL = 8, ORC_ADIABAT_WALL = 9, ORC_CHAR = 10,
+  ORC_SLIP_WALL_DUAL = 11 /* src/bc.cpp:36-48 */
+};
+typedef struct orc_bc
+{
+  int flag, pressure_ramp, use_wm, pad;
+  double rho, velocity[3], p_static, T_static, p_total, T_total, nx, ny, nz;
+  double p_ramp_coeff, T_ramp_coeff, p_total_old, T_total_old;
+} orc_bc;
+typedef struct orc_bdy_inters
+{
+  int n_inters, n_fpts_per_inter;
+  const int *L;           /* (n_fpts_per_inter,n_inters) left offsets */
+  const int *boundary_id; /* (n_inters) index into bcs */
+  const orc_bc *bcs;
+  int n_bcs;
+  double R_ref;     /* run_input.R_ref (viscous) / run_input.R_gas (inviscid), src/bdy_inters.cpp:368-369 */
+  int ramp_counter; /* run_input.ramp_counter */
+} orc_bdy_inters;
+
 void orc_set_threads(int n);
 
 /* src/funcs.cpp:49-123 */
@@ -128,6 +154,14 @@ void orc_int_calculate_common_invFlux(const orc_int_inters *f, orc_eles *e, cons
 void orc_int_calculate_common_viscFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p); /* :254 */
 
 /* partition faces: src/mpi_inters.cpp */
+/* boundary faces, src/bdy_inters.cpp (wall model, LES inlet, RANS off) */
+void orc_set_boundary_conditions(int sol_spec, const orc_bc *bc, int n_dims, int viscous, const double *u_l, double *u_r,
+                                 const double *norm, double gamma, double R_ref, int ramp_counter);            /* :340-1019 */
+void orc_set_boundary_gradients(const orc_bc *bc, int n_dims, const double *u_r, const double *grad_ul, double *grad_ur,
+                                const double *norm);                                                           /* :1138-1189 */
+void orc_bdy_evaluate_boundaryConditions_invFlux(const orc_bdy_inters *f, orc_eles *e, const orc_params *p);  /* :213-338 */
+void orc_bdy_evaluate_boundaryConditions_viscFlux(const orc_bdy_inters *f, orc_eles *e, const orc_params *p); /* :1024-1136 */
+
 void orc_mpi_pack_solution(const orc_mpi_inters *f, const orc_eles *e);           /* :218-229 */
 void orc_mpi_pack_corrected_gradient(const orc_mpi_inters *f, const orc_eles *e); /* :278-289 */
 void orc_mpi_calculate_common_invFlux(const orc_mpi_inters *f, orc_eles *e, const orc_params *p);  /* :400 */
@@ -135,6 +169,11 @@ void orc_mpi_calculate_common_viscFlux(const orc_mpi_inters *f, orc_eles *e, con
 
 /* the caller contract: src/solver.cpp:50-223 (single rank, LES/RANS/forcing off) */
 long orc_CalcResidual(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *p);
+/* the same with boundary-face blocks, in the reference's order (src/solver.cpp:124-129,190-195) */
+long orc_CalcResidual_bdy(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_bdy_inters *bdy,
+                          int n_bdy_blocks, const orc_params *p);
+long orc_rk_step_bdy(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_bdy_inters *bdy,
+                     int n_bdy_blocks, const orc_params *p);
 /* RK loop body of src/HiFiLES.cpp:201-217 for n_stages consecutive stages starting at stage 0 */
 long orc_rk_step(orc_eles *e, const orc_int_inters *faces, int n_face_blocks, const orc_params *p);
 

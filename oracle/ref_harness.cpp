@@ -227,6 +227,71 @@ int main(int argc, char *argv[])
       put_i(s + "R", R.data(), {nf, ni});
     }
   }
+  // boundary faces: left offsets, the bc_list index of every face, and bc_list itself after
+  // input::read_boundary_param's non-dimensionalisation
+  {
+    // bdy_inters::inlet.nbs is read by evaluate_boundaryConditions_* (src/bdy_inters.cpp:249) but only
+    // ever written by add_les_inlet (LES runs): give it the value an LES-off run means
+    for (int t = 0; t < FlowSol.n_bdy_inter_types; t++) FlowSol.mesh_bdy_inters(t).inlet.nbs = 0;
+    bool any = false;
+    for (int t = 0; t < FlowSol.n_bdy_inter_types; t++)
+    {
+      bdy_inters &B = FlowSol.mesh_bdy_inters(t);
+      if (B.n_inters == 0) continue;
+      any = true;
+      string s = "bdy" + to_string(t) + "_";
+      int nf = B.n_fpts_per_inter, ni = B.n_inters;
+      vector<int32_t> L((size_t)nf * ni), id(ni);
+      for (int i = 0; i < ni; i++)
+      {
+        id[i] = B.boundary_id(i);
+        for (int j = 0; j < nf; j++)
+        {
+          L[j + (size_t)nf * i] = (int32_t)(B.disu_fpts_l(j, i, 0) - E->disu_fpts.get_ptr_cpu());
+          if (B.norm_tconf_fpts_l(j, i, 0) - E->norm_tconf_fpts.get_ptr_cpu() != L[j + (size_t)nf * i] ||
+              B.tdA_fpts_l(j, i) - E->tdA_fpts.get_ptr_cpu() != L[j + (size_t)nf * i] ||
+              B.norm_fpts(j, i, 0) - E->norm_fpts.get_ptr_cpu() != L[j + (size_t)nf * i])
+          {
+            fprintf(stderr, "harness: boundary face table layout assumption violated\n");
+            return 1;
+          }
+        }
+      }
+      put_i(s + "L", L.data(), {nf, ni});
+      put_i(s + "id", id.data(), {ni});
+    }
+    if (any)
+    {
+      const int nb = run_input.bc_list.get_dim(0);
+      vector<int32_t> flags(nb * 3);
+      vector<double> par(nb * 15, 0.0);
+      for (int b = 0; b < nb; b++)
+      {
+        bc &c = run_input.bc_list(b);
+        const int fl = c.get_bc_flag();
+        flags[b * 3 + 0] = fl;
+        flags[b * 3 + 1] = (fl == SUB_IN_CHAR) ? c.pressure_ramp : 0;
+        flags[b * 3 + 2] = (fl == ISOTHERM_WALL || fl == ADIABAT_WALL) ? (run_input.wall_model ? c.use_wm : 0) : 0;
+        double *q = &par[b * 15];
+        const bool has_vel = (fl == SUB_IN_SIMP || fl == SUP_IN || fl == ISOTHERM_WALL || fl == CHAR || fl == ADIABAT_WALL);
+        if (fl == SUB_IN_SIMP || fl == SUP_IN || fl == CHAR) q[0] = c.rho;
+        if (has_vel) for (int d = 0; d < 3; d++) q[1 + d] = c.velocity(d);
+        if (fl == SUB_OUT_SIMP || fl == SUB_OUT_CHAR || fl == SUP_IN || fl == CHAR) q[4] = c.p_static;
+        if (fl == SUP_IN || fl == ISOTHERM_WALL || fl == CHAR) q[5] = c.T_static;
+        if (fl == SUB_IN_CHAR) q[6] = c.p_total;
+        if (fl == SUB_IN_CHAR || fl == SUB_OUT_SIMP || fl == SUB_OUT_CHAR) q[7] = c.T_total;
+        if (fl == SUB_IN_CHAR || fl == SUP_IN || fl == CHAR) { q[8] = c.nx; q[9] = c.ny; q[10] = c.nz; }
+        if (fl == SUB_IN_CHAR && c.pressure_ramp)
+        {
+          q[11] = c.p_ramp_coeff; q[12] = c.T_ramp_coeff; q[13] = c.p_total_old; q[14] = c.T_total_old;
+        }
+      }
+      put_i("bc_flags", flags.data(), {3, nb});
+      put_d("bc_params", par.data(), {15, nb});
+      put_scalar("bc_R_ref", run_input.viscous ? run_input.R_ref : run_input.R_gas);
+      put_scalar("ramp_counter", run_input.ramp_counter);
+    }
+  }
   if (level >= 1)
   {
     put_arr("detjac_upts", E->detjac_upts);

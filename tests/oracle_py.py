@@ -35,6 +35,35 @@ class IntInters(C.Structure):
     _fields_ = [("n_inters", C.c_int), ("n_fpts_per_inter", C.c_int), ("L", ip), ("R", ip)]
 
 
+class Bc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("flag", "pressure_ramp", "use_wm", "pad")] + \
+               [("rho", C.c_double), ("velocity", C.c_double * 3)] + \
+               [(n, C.c_double) for n in ("p_static", "T_static", "p_total", "T_total", "nx", "ny", "nz",
+                                          "p_ramp_coeff", "T_ramp_coeff", "p_total_old", "T_total_old")]
+
+
+class BdyInters(C.Structure):
+    _fields_ = [("n_inters", C.c_int), ("n_fpts_per_inter", C.c_int), ("L", ip), ("boundary_id", ip),
+                ("bcs", C.POINTER(Bc)), ("n_bcs", C.c_int), ("R_ref", C.c_double), ("ramp_counter", C.c_int)]
+
+
+def bc_records(data):
+    """bc_list of a fixture (`bc_flags` (3,nbc), `bc_params` (15,nbc), written by oracle/ref_harness.cpp) as Bc records."""
+    fl = np.asarray(data["bc_flags"]).reshape(3, -1, order="F")
+    par = np.asarray(data["bc_params"]).reshape(15, -1, order="F")
+    out = (Bc * fl.shape[1])()
+    for b in range(fl.shape[1]):
+        r = out[b]
+        r.flag, r.pressure_ramp, r.use_wm = int(fl[0, b]), int(fl[1, b]), int(fl[2, b])
+        q = par[:, b]
+        r.rho = q[0]
+        for d in range(3):
+            r.velocity[d] = q[1 + d]
+        (r.p_static, r.T_static, r.p_total, r.T_total, r.nx, r.ny, r.nz,
+         r.p_ramp_coeff, r.T_ramp_coeff, r.p_total_old, r.T_total_old) = [float(v) for v in q[4:15]]
+    return out
+
+
 _lib = None
 
 
@@ -48,6 +77,8 @@ def load():
         _lib = C.CDLL(so)
         _lib.orc_CalcResidual.restype = C.c_long
         _lib.orc_rk_step.restype = C.c_long
+        _lib.orc_CalcResidual_bdy.restype = C.c_long
+        _lib.orc_rk_step_bdy.restype = C.c_long
         _lib.orc_calculate_corrected_divergence.restype = C.c_long
         _lib.orc_compute_res_upts.restype = C.c_double
         _lib.orc_calc_dt_local.restype = C.c_double
@@ -107,6 +138,17 @@ class Case:
                 L = np.asfortranarray(np.array(data["int%d_L" % t], dtype=np.int32))
                 R = np.asfortranarray(np.array(data["int%d_R" % t], dtype=np.int32))
                 self.faces.append((L, R))
+        # boundary-face blocks
+        self.bdy = []
+        for t in range(3):
+            if "bdy%d_L" % t in data:
+                L = np.asfortranarray(np.array(data["bdy%d_L" % t], dtype=np.int32))
+                ids = np.ascontiguousarray(np.array(data["bdy%d_id" % t], dtype=np.int32).ravel())
+                self.bdy.append((L, ids))
+        if self.bdy:
+            self.bcs = bc_records(data)
+            self.bc_R_ref = float(np.ravel(data["bc_R_ref"])[0])
+            self.ramp_counter = int(np.ravel(data["ramp_counter"])[0])
         # params
         s = lambda k, dflt=None: float(np.ravel(data[k])[0]) if k in data else dflt
         p = Params()
@@ -147,6 +189,23 @@ class Case:
             arr[i].L = iptr(L); arr[i].R = iptr(R)
         self._f = arr
         return arr, len(self.faces)
+
+
+def _c_bdy(self):
+    arr = (BdyInters * max(1, len(self.bdy)))()
+    for i, (L, ids) in enumerate(self.bdy):
+        arr[i].n_fpts_per_inter, arr[i].n_inters = L.shape
+        arr[i].L = iptr(L)
+        arr[i].boundary_id = ids.ctypes.data_as(ip)
+        arr[i].bcs = self.bcs
+        arr[i].n_bcs = len(self.bcs)
+        arr[i].R_ref = self.bc_R_ref
+        arr[i].ramp_counter = self.ramp_counter
+    self._b = arr
+    return arr, len(self.bdy)
+
+
+Case.c_bdy = _c_bdy
 
 
 class MpiInters(C.Structure):

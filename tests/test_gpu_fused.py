@@ -30,6 +30,10 @@ def test_fused_vs_reference(ctx, name, mode):
     e, faces = build(ctx, d)
     nstage = int(d["sizes"][7])
     steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
+    if mode == 1 and "bdy" in name:
+        with pytest.raises(hfx.HfxError):  # the gather-style kernels have no boundary faces
+            hfx.run_steps(e, faces, 1, fused=mode)
+        steps = []
     for st in steps:
         hfx.run_steps(e, faces, 1, fused=mode)
         assert relerr(e.download(hfx.DISU_UPTS0), d["u_step%d_stage%d" % (st, nstage - 1)]) < 1e-11, st

@@ -19,7 +19,8 @@ import oracle_py as O
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hex_*.npz")))
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+BDY = [n for n in ALL if "bdy" in n]
 RTOL1 = 1e-12
 # div_tconf is a difference of terms ~1e3 times larger than itself (pressure-dominated energy
 # flux), so its relative rounding error is correspondingly larger
@@ -48,6 +49,11 @@ def build(ctx, d, mode=hfx.CONTRACT_AUTO):
     for t in range(3):
         if "int%d_L" % t in d:
             faces.append(hfx.IntInters(ctx, e, e, d["int%d_L" % t], d["int%d_R" % t]))
+    for t in range(3):
+        if "bdy%d_L" % t in d:
+            faces.append(hfx.BdyInters(ctx, e, d["bdy%d_L" % t], d["bdy%d_id" % t],
+                                       hfx.bc_records(d["bc_flags"], d["bc_params"]),
+                                       float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
     e.upload(hfx.DISU_UPTS0, d["u_init"])
     return e, faces
 
@@ -88,6 +94,43 @@ def test_every_intermediate(ctx, mode):
             got = e.compute_res_upts(nt, fld)
             want = d["s0_res_sums"][fld, nt - 1]
             assert abs(got - want) <= 1e-11 * abs(want)
+    for f in faces:
+        f.close()
+    e.close()
+
+
+@pytest.mark.parametrize("name", BDY)
+def test_boundary_intermediates(ctx, name):
+    """bdy_inters: the face arrays after the inviscid and the viscous sweep (interior + boundary blocks)."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e, faces = build(ctx, d)
+    inner = [f for f in faces if isinstance(f, hfx.IntInters)]
+    bdy = [f for f in faces if isinstance(f, hfx.BdyInters)]
+    visc = int(np.ravel(d["viscous"])[0])
+    assert bdy
+    e.extrapolate_solution()
+    if visc:
+        e.calculate_gradient()
+    e.evaluate_invFlux()
+    for f in inner:
+        f.calculate_common_invFlux()
+    for f in bdy:
+        f.evaluate_boundaryConditions_invFlux()
+    assert relerr(e.download(hfx.NORM_TCONF_FPTS), d["s0_norm_tconf_fpts_inv"]) < RTOL1
+    if visc:
+        assert relerr(e.download(hfx.DELTA_DISU_FPTS), d["s0_delta_disu_fpts"]) < RTOL1
+        e.correct_gradient()
+        e.evaluate_viscFlux()
+    e.extrapolate_totalFlux()
+    e.calculate_divergence()
+    if visc:
+        for f in inner:
+            f.calculate_common_viscFlux()
+        for f in bdy:
+            f.evaluate_boundaryConditions_viscFlux()
+        assert relerr(e.download(hfx.NORM_TCONF_FPTS), d["s0_norm_tconf_fpts"]) < RTOL1
+    e.calculate_corrected_divergence()
+    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOLD
     for f in faces:
         f.close()
     e.close()

@@ -16,7 +16,7 @@ import pytest
 import oracle_py as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "hex_*.npz")))
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
 
 # The oracle repeats the reference's operation order; remaining differences are compiler-level
 # (x87-free SSE2 both sides, no FMA) so the tolerance is a few ulps of the array's scale.
@@ -40,11 +40,12 @@ def test_stage_states(oracle, name):
     c = O.Case(d)
     e = c.c_eles()
     f, nfb = c.c_faces()
+    bd, nbd = c.c_bdy()
     nstage = int(d["sizes"][7])
     steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
     for st in steps:
         for rk in range(nstage):
-            bad = oracle.orc_CalcResidual(C.byref(e), f, nfb, C.byref(c.params))
+            bad = oracle.orc_CalcResidual_bdy(C.byref(e), f, nfb, bd, nbd, C.byref(c.params))
             assert bad == -1
             if st == 0 and rk == 0:
                 assert relerr(c.arr["div_tconf_upts"], d["s0_div_tconf_upts"]) < RTOL
@@ -105,3 +106,44 @@ def test_threads_do_not_change_results(oracle):
         outs.append(c.arr["u0"].copy())
     oracle.orc_set_threads(1)
     assert np.array_equal(outs[0], outs[1])
+
+
+BDY = [n for n in ALL if "bdy" in n]
+
+
+@pytest.mark.parametrize("name", BDY)
+def test_boundary_intermediates(oracle, name):
+    """bdy_inters (src/bdy_inters.cpp): common flux / common solution after the inviscid sweep and the total
+    common flux after the viscous sweep, interior and boundary faces together, against the genuine reference."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c = O.Case(d)
+    e = c.c_eles()
+    f, nfb = c.c_faces()
+    bd, nbd = c.c_bdy()
+    assert nbd >= 1
+    P, E, a = C.byref(c.params), C.byref(e), c.arr
+    oracle.orc_extrapolate_solution(E)
+    if c.viscous:
+        oracle.orc_calculate_gradient(E)
+    oracle.orc_evaluate_invFlux(E, P)
+    for b in range(nfb):
+        oracle.orc_int_calculate_common_invFlux(C.byref(f[b]), E, P)
+    for b in range(nbd):
+        oracle.orc_bdy_evaluate_boundaryConditions_invFlux(C.byref(bd[b]), E, P)
+    # pow() of libm vs the reference's build: a few ulps
+    assert relerr(a["norm_tconf_fpts"], d["s0_norm_tconf_fpts_inv"]) < 1e-12
+    if c.viscous:
+        assert relerr(a["delta_disu_fpts"], d["s0_delta_disu_fpts"]) < 1e-12
+        oracle.orc_correct_gradient(E)
+        assert relerr(a["grad_disu_fpts"], d["s0_grad_disu_fpts"]) < 1e-12
+        oracle.orc_evaluate_viscFlux(E, P)
+    oracle.orc_extrapolate_totalFlux(E)
+    oracle.orc_calculate_divergence(E)
+    if c.viscous:
+        for b in range(nfb):
+            oracle.orc_int_calculate_common_viscFlux(C.byref(f[b]), E, P)
+        for b in range(nbd):
+            oracle.orc_bdy_evaluate_boundaryConditions_viscFlux(C.byref(bd[b]), E, P)
+        assert relerr(a["norm_tconf_fpts"], d["s0_norm_tconf_fpts"]) < 1e-12
+    assert oracle.orc_calculate_corrected_divergence(E) == -1
+    assert relerr(a["div_tconf_upts"], d["s0_div_tconf_upts"]) < 1e-12
