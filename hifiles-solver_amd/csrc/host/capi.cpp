@@ -49,6 +49,20 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
     for (int i = 0; i <= d->order; i++) in.loc_1d_upts_override(i) = d->loc_1d_upts[i];
   }
   if (in.setup_params(g_err)) { delete c; return 1; }
+  for (int i = 0; i < d->n_bcs; i++)
+  {
+    const hfxh_bc_desc &b = d->bcs[i];
+    bc_spec s;
+    s.flag = b.flag; s.pressure_ramp = b.pressure_ramp;
+    s.rho = b.rho; s.u = b.u; s.v = b.v; s.w = b.w; s.p_static = b.p_static; s.T_static = b.T_static;
+    s.p_total = b.p_total; s.T_total = b.T_total; s.T_total_given = b.T_total >= 0;
+    s.nx = b.nx; s.ny = b.ny; s.nz = b.nz; s.mach = b.mach;
+    s.p_ramp_coeff = b.p_ramp_coeff; s.T_ramp_coeff = b.T_ramp_coeff; s.p_total_old = b.p_total_old;
+    s.T_total_old = b.T_total_old; s.T_total_old_given = b.T_total_old >= 0;
+    in.bc_specs.push_back(s);
+  }
+  if (in.read_boundary_param(g_err)) { delete c; return 1; }
+  for (int i = 0; i < 6; i++) c->mesh.side_bc[i] = (d->n_bcs > 0) ? d->side_bc[i] : -1;
 
   c->mesh.dims = d->dims;
   c->S.nproc = d->nproc > 0 ? d->nproc : 1;
@@ -146,6 +160,28 @@ extern "C" int hfxh_case_get_faces(hfxh_case *c, const int **L, const int **R, i
   return 0;
 }
 
+static bdy_inters *the_bdy_faces(hfxh_case *c) { return &c->S.mesh_bdy_inters(c->S.n_dims == 3 ? 2 : 0); }
+
+extern "C" int hfxh_case_get_bdy_faces(hfxh_case *c, const int **L, const int **boundary_id, int *n_fpts_per_inter, int *n_inters)
+{
+  bdy_inters *B = the_bdy_faces(c);
+  *L = B->disu_fpts_l.get_ptr_cpu();
+  *boundary_id = B->boundary_id.get_ptr_cpu();
+  *n_fpts_per_inter = B->n_fpts_per_inter;
+  *n_inters = B->n_inters;
+  return 0;
+}
+
+extern "C" int hfxh_case_get_bcs(hfxh_case *c, const hfx_bc **bcs, int *n_bcs, double *R_ref, int *ramp_counter)
+{
+  input &in = c->S.run_input;
+  *bcs = in.bc_list.data();
+  *n_bcs = (int)in.bc_list.size();
+  *R_ref = in.bc_R_ref();
+  *ramp_counter = in.ramp_counter;
+  return 0;
+}
+
 static mpi_inters *the_mpi_faces(hfxh_case *c) { return &c->S.mesh_mpi_inters(c->S.n_dims == 3 ? 2 : 0); }
 
 extern "C" int hfxh_case_get_mpi_faces(hfxh_case *c, const int **L, const int **Rlut, int *n_fpts_per_inter, int *n_inters,
@@ -184,6 +220,8 @@ extern "C" int hfxh_case_to_device(hfxh_case *c, int device)
   c->faces.clear();
   for (int i = 0; i < c->S.n_int_inter_types; i++)
     if (c->S.mesh_int_inters(i).device()) c->faces.push_back(c->S.mesh_int_inters(i).device());
+  for (int i = 0; i < c->S.n_bdy_inter_types; i++)
+    if (c->S.mesh_bdy_inters(i).device()) c->faces.push_back(c->S.mesh_bdy_inters(i).device());
   return 0;
 }
 
@@ -204,6 +242,7 @@ extern "C" int hfxh_case_CalcResidual(hfxh_case *c)
   if (E->failed()) { g_err = E->last_error(); return 1; }
   if (the_faces(c)->failed()) { g_err = the_faces(c)->last_error(); return 1; }
   if (the_mpi_faces(c)->failed()) { g_err = the_mpi_faces(c)->last_error(); return 1; }
+  if (the_bdy_faces(c)->failed()) { g_err = the_bdy_faces(c)->last_error(); return 1; }
   return 0;
 }
 

@@ -95,3 +95,91 @@ void input::fill(hfx_params &p) const
   for (int i = 0; i < 16; i++) { p.RK_a[i] = 0; p.RK_b[i] = 0; }
   for (int i = 0; i < p.n_rk; i++) { p.RK_a[i] = RK_a(i); p.RK_b[i] = RK_b(i); }
 }
+
+// input::read_boundary_param (src/input.cpp:328-525): defaults, derived values and non-dimensionalisation
+int input::read_boundary_param(std::string &err)
+{
+  bc_list.assign(bc_specs.size(), hfx_bc{});
+  ramp_counter = 0;
+  for (size_t i = 0; i < bc_specs.size(); i++)
+  {
+    const bc_spec &in = bc_specs[i];
+    hfx_bc &b = bc_list[i];
+    b.flag = in.flag;
+    if (in.flag < HFX_BC_SUB_IN_SIMP || in.flag > HFX_BC_SLIP_WALL_DUAL)
+    {
+      err = "Boundary condition not implemented yet";
+      return 1;
+    }
+    double vel[3] = {in.u, in.v, in.w};
+    b.rho = in.rho;
+    b.p_static = in.p_static; b.T_static = in.T_static; b.p_total = in.p_total;
+    b.T_total = in.T_total;
+    b.nx = in.nx; b.ny = in.ny; b.nz = in.nz;
+    switch (in.flag)
+    {
+    case HFX_BC_SUB_IN_SIMP:
+      if (viscous)
+      {
+        b.rho /= rho_ref;
+        for (int j = 0; j < 3; j++) vel[j] /= uvw_ref;
+      }
+      break;
+    case HFX_BC_SUB_IN_CHAR:
+      b.pressure_ramp = in.pressure_ramp;
+      if (in.pressure_ramp)
+      {
+        ramp_counter = 1; /* src/input.cpp:377 */
+        b.p_ramp_coeff = in.p_ramp_coeff; b.T_ramp_coeff = in.T_ramp_coeff;
+        b.p_total_old = in.p_total_old;
+        b.T_total_old = in.T_total_old_given ? in.T_total_old : T_free_stream;
+      }
+      if (viscous)
+      {
+        b.T_total /= T_ref; b.p_total /= p_ref;
+        if (in.pressure_ramp) { b.p_total_old /= p_ref; b.T_total_old /= T_ref; }
+      }
+      break;
+    case HFX_BC_SUB_OUT_SIMP:
+    case HFX_BC_SUB_OUT_CHAR:
+      if (!in.T_total_given) b.T_total = T_free_stream; /* src/input.cpp:387 */
+      if (viscous) { b.p_static /= p_ref; b.T_total /= T_ref; }
+      break;
+    case HFX_BC_SUP_IN:
+    case HFX_BC_CHAR:
+      b.rho = in.p_static / (R_gas * in.T_static);
+      vel[0] = in.mach * std::sqrt(gamma * R_gas * in.T_static) * in.nx;
+      vel[1] = in.mach * std::sqrt(gamma * R_gas * in.T_static) * in.ny;
+      vel[2] = in.mach * std::sqrt(gamma * R_gas * in.T_static) * in.nz;
+      if (viscous)
+      {
+        b.rho /= rho_ref; b.p_static /= p_ref; b.T_static /= T_ref;
+        for (int j = 0; j < 3; j++) vel[j] /= uvw_ref;
+      }
+      break;
+    case HFX_BC_ISOTHERM_WALL:
+      if (!viscous) { err = "Isothermal wall boundary only available to viscous simulation"; return 1; }
+      b.T_static /= T_ref;
+      for (int j = 0; j < 3; j++) vel[j] /= uvw_ref;
+      break;
+    case HFX_BC_ADIABAT_WALL:
+      if (!viscous) { err = "Adiabatic wall boundary only available to viscous simulation"; return 1; }
+      for (int j = 0; j < 3; j++) vel[j] /= uvw_ref;
+      break;
+    default:
+      break;
+    }
+    // keep only what the type reads (the reference leaves the other members uninitialised)
+    const int f = in.flag;
+    const bool has_vel = (f == HFX_BC_SUB_IN_SIMP || f == HFX_BC_SUP_IN || f == HFX_BC_ISOTHERM_WALL || f == HFX_BC_CHAR ||
+                          f == HFX_BC_ADIABAT_WALL);
+    for (int j = 0; j < 3; j++) b.velocity[j] = has_vel ? vel[j] : 0.0;
+    if (!(f == HFX_BC_SUB_IN_SIMP || f == HFX_BC_SUP_IN || f == HFX_BC_CHAR)) b.rho = 0.0;
+    if (!(f == HFX_BC_SUB_OUT_SIMP || f == HFX_BC_SUB_OUT_CHAR || f == HFX_BC_SUP_IN || f == HFX_BC_CHAR)) b.p_static = 0.0;
+    if (!(f == HFX_BC_SUP_IN || f == HFX_BC_ISOTHERM_WALL || f == HFX_BC_CHAR)) b.T_static = 0.0;
+    if (f != HFX_BC_SUB_IN_CHAR) b.p_total = 0.0;
+    if (!(f == HFX_BC_SUB_IN_CHAR || f == HFX_BC_SUB_OUT_SIMP || f == HFX_BC_SUB_OUT_CHAR)) b.T_total = 0.0;
+    if (!(f == HFX_BC_SUB_IN_CHAR || f == HFX_BC_SUP_IN || f == HFX_BC_CHAR)) b.nx = b.ny = b.nz = 0.0;
+  }
+  return 0;
+}

@@ -4,9 +4,22 @@
 // Not a global: each `solution` owns one.
 #pragma once
 #include <string>
+#include <vector>
 
 #include "../../../include/hfx.h"
 #include "hf_array.hpp"
+
+// one boundary group as the input file gives it: `bc_<name>_type` and the type's parameters, DIMENSIONAL
+// (/root/reference/src/input.cpp:328-437)
+struct bc_spec
+{
+  int flag = HFX_BC_CYCLIC; // src/bc.cpp:36-48
+  double rho = 0, u = 0, v = 0, w = 0, p_static = 0, T_static = 0, p_total = 0, T_total = 0;
+  double nx = 1., ny = 0., nz = 0., mach = 0;
+  int pressure_ramp = 0;
+  double p_ramp_coeff = 0, T_ramp_coeff = 0, p_total_old = 0, T_total_old = 0;
+  bool T_total_given = false, T_total_old_given = false;
+};
 
 struct input
 {
@@ -38,6 +51,14 @@ struct input
   double c_sth = 0, mu_inf = 0, rt_inf = 0, uvw_c_ic = 0, mu_c_ic = 0;
   hf_array<double> RK_a, RK_b, RK_c;
   double time = 0.0;
+
+  // ---- boundary groups: bc_specs in, bc_list (non-dimensional records for the device) out
+  std::vector<bc_spec> bc_specs;
+  std::vector<hfx_bc> bc_list;
+  int ramp_counter = 0;
+  // input::read_boundary_param (src/input.cpp:328-525) after setup_params()
+  int read_boundary_param(std::string &err);
+  double bc_R_ref() const { return viscous ? R_ref : R_gas; } // src/bdy_inters.cpp:368-369
 
   // returns 0 or sets err (the reference's FatalError texts)
   int setup_params(std::string &err);

@@ -201,3 +201,69 @@ void mpi_inters::receive_corrected_gradient()
 }
 void mpi_inters::calculate_common_invFlux() { HFX_MPI_CALL(hfx_mpi_inters_calculate_common_invFlux(dev)); }
 void mpi_inters::calculate_common_viscFlux() { HFX_MPI_CALL(hfx_mpi_inters_calculate_common_viscFlux(dev)); }
+
+// ---- bdy_inters -----------------------------------------------------------------------------
+bdy_inters::~bdy_inters()
+{
+  if (dev) hfx_inters_destroy(dev);
+}
+
+void bdy_inters::setup(int in_n_inters, int in_inter_type, input *in)
+{
+  n_inters = in_n_inters;
+  inters_type = in_inter_type;
+  run_input = in;
+  order = in->order;
+  viscous = in->viscous;
+  if (inters_type == 0) { n_fpts_per_inter = order + 1; n_dims = 2; }
+  else if (inters_type == 1) { n_fpts_per_inter = (order + 2) * (order + 1) / 2; n_dims = 3; }
+  else { n_fpts_per_inter = (order + 1) * (order + 1); n_dims = 3; }
+  n_fields = n_dims + 2;
+  boundary_id.setup(n_inters);
+  disu_fpts_l.setup(n_fpts_per_inter, n_inters);
+}
+
+void bdy_inters::set_boundary(int in_inter, int bc_id, int in_ele_type_l, int in_ele_l, int in_local_inter_l,
+                              struct solution *FlowSol)
+{
+  boundary_id(in_inter) = bc_id;
+  if (in_ele_type < 0) in_ele_type = in_ele_type_l;
+  if (in_ele_type != in_ele_type_l)
+  {
+    if (err.empty()) err = "bdy_inters: one boundary-face block must belong to one element class";
+    return;
+  }
+  eles *el = FlowSol->mesh_eles(in_ele_type_l);
+  for (int j = 0; j < n_fpts_per_inter; j++) disu_fpts_l(j, in_inter) = el->get_fpt_offset(in_ele_l, in_local_inter_l, j);
+}
+
+int bdy_inters::mv_all_cpu_gpu(hfx_ctx *ctx, struct solution *FlowSol)
+{
+  if (n_inters == 0) return 0;
+  eles *el = FlowSol->mesh_eles(in_ele_type);
+  if (hfx_bdy_inters_create(ctx, el->device(), n_inters, n_fpts_per_inter, disu_fpts_l.get_ptr_cpu(),
+                            boundary_id.get_ptr_cpu(), run_input->bc_list.data(), (int)run_input->bc_list.size(),
+                            run_input->bc_R_ref(), &dev))
+  {
+    err = hfx_last_error();
+    return 1;
+  }
+  if (hfx_bdy_inters_set_ramp_counter(dev, run_input->ramp_counter))
+  {
+    err = hfx_last_error();
+    return 1;
+  }
+  return 0;
+}
+
+void bdy_inters::evaluate_boundaryConditions_invFlux(struct solution * /*FlowSol*/, double time_bound)
+{
+  if (n_inters != 0 && hfx_bdy_inters_evaluate_boundaryConditions_invFlux(dev, time_bound) != 0 && err.empty())
+    err = hfx_last_error();
+}
+
+void bdy_inters::evaluate_boundaryConditions_viscFlux(double time_bound)
+{
+  if (n_inters != 0 && hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(dev, time_bound) != 0 && err.empty())
+    err = hfx_last_error();
+}

@@ -84,3 +84,31 @@ private:
   void *exchange_user = nullptr;
   std::string err;
 };
+
+// Host-side mirror of the reference's boundary-face class (include/bdy_inters.h:31-105).
+class bdy_inters
+{
+public:
+  ~bdy_inters();
+  void setup(int in_n_inters, int in_inter_type, input *in_run_input); // src/bdy_inters.cpp:62
+  // bdy_inters::set_boundary (src/bdy_inters.cpp:75-135): same arguments
+  void set_boundary(int in_inter, int bc_id, int in_ele_type_l, int in_ele_l, int in_local_inter_l, struct solution *FlowSol);
+  int mv_all_cpu_gpu(hfx_ctx *ctx, struct solution *FlowSol);
+  void evaluate_boundaryConditions_invFlux(struct solution *FlowSol, double time_bound); // :213
+  void evaluate_boundaryConditions_viscFlux(double time_bound);                            // :1024
+
+  int get_n_inters() const { return n_inters; }
+  hfx_inters *device() { return dev; }
+  const std::string &last_error() const { return err; }
+  bool failed() const { return !err.empty(); }
+
+  int inters_type = 0, order = 0, viscous = 0, n_inters = 0, n_fpts_per_inter = 0, n_fields = 0, n_dims = 0;
+  int in_ele_type = -1;
+  hf_array<int> boundary_id;  // index into run_input.bc_list
+  hf_array<int> disu_fpts_l;  // left offsets
+  input *run_input = nullptr;
+
+private:
+  hfx_inters *dev = nullptr;
+  std::string err;
+};

@@ -7,6 +7,7 @@ solution::~solution()
 {
   // face blocks reference element blocks: release them first
   mesh_int_inters.setup(0);
+  mesh_bdy_inters.setup(0);
   mesh_mpi_inters.setup(0);
   mesh_eles_quads.free_device();
   mesh_eles_hexas.free_device();
@@ -95,6 +96,30 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
   const int dims = mesh.dims, nx = mesh.n[0], ny = mesh.n[1], nz = (dims == 3) ? mesh.n[2] : 1;
   const int NV = mesh.nv();
   if ((int)mesh.xv.size() != NV * dims) { S->err = "box mesh: vertex array has the wrong size"; return 1; }
+  // local face -> (axis, direction, neighbour's local face)
+  static const int hex_face[6][3] = {{2, -1, 5}, {1, -1, 3}, {0, 1, 4}, {1, 1, 1}, {0, -1, 2}, {2, 1, 0}};
+  static const int quad_face[4][3] = {{1, -1, 2}, {0, 1, 3}, {1, 1, 0}, {0, -1, 1}};
+  const int nfaces_loc = (dims == 3) ? 6 : 4;
+  // a side is periodic when it has no group or a cyclic one; a direction when both of its sides are
+  auto side_group = [&](int f) {
+    const int g = mesh.side_bc[f];
+    if (g < 0) return -1;
+    if (g >= (int)in.bc_specs.size()) return -2;
+    return in.bc_specs[g].flag == HFX_BC_CYCLIC ? -1 : g;
+  };
+  bool periodic[3] = {true, true, true};
+  for (int f = 0; f < nfaces_loc; f++)
+  {
+    const int *fd = (dims == 3) ? hex_face[f] : quad_face[f];
+    const int g = side_group(f);
+    if (g == -2) { S->err = "box mesh: side refers to a boundary group that does not exist"; return 1; }
+    if (g >= 0) periodic[fd[0]] = false;
+  }
+  for (int f = 0; f < nfaces_loc; f++)
+  {
+    const int *fd = (dims == 3) ? hex_face[f] : quad_face[f];
+    if (!periodic[fd[0]] && side_group(f) < 0) { S->err = "box mesh: one side of a direction is cyclic, the other is not"; return 1; }
+  }
   {
     const int nn[3] = {nx, ny, nz};
     int np = 1;
@@ -102,7 +127,7 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
     {
       np *= mesh.pgrid[d];
       if (mesh.pgrid[d] < 1 || mesh.pcoord[d] < 0 || mesh.pcoord[d] >= mesh.pgrid[d]) { S->err = "box mesh: bad process grid"; return 1; }
-      if (mesh.pgrid[d] == 1 && nn[d] < 3) { S->err = "box mesh: need >= 3 cells per direction (periodic matching)"; return 1; }
+      if (mesh.pgrid[d] == 1 && periodic[d] && nn[d] < 3) { S->err = "box mesh: need >= 3 cells per direction (periodic matching)"; return 1; }
       if (mesh.pgrid[d] > 1 && nn[d] < 2) { S->err = "box mesh: need >= 2 cells per partitioned direction"; return 1; }
     }
     if (np != S->nproc) { S->err = "box mesh: process grid does not match nproc"; return 1; }
@@ -155,17 +180,22 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
   S->mesh_int_inters.setup(S->n_int_inter_types);
   S->mesh_mpi_inters.setup(S->n_mpi_inter_types);
   const int ftype = (dims == 3) ? 2 : 0;
-  // local face -> (axis, direction, neighbour's local face)
-  static const int hex_face[6][3] = {{2, -1, 5}, {1, -1, 3}, {0, 1, 4}, {1, 1, 1}, {0, -1, 2}, {2, 1, 0}};
-  static const int quad_face[4][3] = {{1, -1, 2}, {0, 1, 3}, {1, 1, 0}, {0, -1, 1}};
-  const int nfaces_loc = (dims == 3) ? 6 : 4;
   const int nn[3] = {nx, ny, nz};
+  // is the neighbour through face f of local cell (c) beyond a non-periodic end of the GLOBAL box?
+  auto beyond_domain = [&](const int *fd, const int *c) {
+    const int d = fd[0];
+    if (periodic[d]) return false;
+    const int gc = c[d] + mesh.pcoord[d] * nn[d] + fd[1];
+    return gc < 0 || gc >= nn[d] * mesh.pgrid[d];
+  };
   const double tol = 1e-8 * mesh.length;
 
   // pass 1: count.  A face whose neighbour cell lives on another rank is a partition face
   // (src/mesh.cpp match_mpifaces / src/geometry.cpp:566-663 build the same lists from ParMETIS output).
   struct mpi_face { int nbr, key_e, key_f, e, f; };
+  struct bdy_face { int e, f, g; };
   std::vector<mpi_face> mf;
+  std::vector<bdy_face> bf;
   int n_int = 0;
   for (int k = 0; k < nz; k++)
     for (int j = 0; j < ny; j++)
@@ -177,6 +207,13 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
           const int *fd = (dims == 3) ? hex_face[f] : quad_face[f];
           const int d = fd[0];
           int c[3] = {i, j, k};
+          if (beyond_domain(fd, c))
+          {
+            // boundary faces in the order the cells meet them (src/geometry.cpp:617-663)
+            bdy_face b = {e, f, side_group(f)};
+            bf.push_back(b);
+            continue;
+          }
           c[d] += fd[1];
           const bool outside = c[d] < 0 || c[d] >= nn[d];
           c[d] = (c[d] + nn[d]) % nn[d];
@@ -202,6 +239,10 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
   S->n_mpi_inters = (int)mf.size();
 
   for (int t = 0; t < 3; t++) S->mesh_int_inters(t).setup(t == ftype ? n_int : 0, t, &in);
+  S->mesh_bdy_inters.setup(S->n_bdy_inter_types);
+  for (int t = 0; t < 3; t++) S->mesh_bdy_inters(t).setup(t == ftype ? (int)bf.size() : 0, t, &in);
+  for (size_t m = 0; m < bf.size(); m++) S->mesh_bdy_inters(ftype).set_boundary((int)m, bf[m].g, etype, bf[m].e, bf[m].f, S);
+  if (S->mesh_bdy_inters(ftype).failed()) { S->err = S->mesh_bdy_inters(ftype).last_error(); return 1; }
   for (int t = 0; t < 3; t++)
   {
     S->mesh_mpi_inters(t).setup(t == ftype ? S->n_mpi_inters : 0, t, &in);
@@ -225,6 +266,7 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
           const int *fd = (dims == 3) ? hex_face[f] : quad_face[f];
           const int d = fd[0];
           int c[3] = {i, j, k};
+          if (beyond_domain(fd, c)) continue; // boundary face
           c[d] += fd[1];
           if ((c[d] < 0 || c[d] >= nn[d]) && mesh.pgrid[d] > 1) continue; // partition face
           c[d] = (c[d] + nn[d]) % nn[d];
@@ -288,6 +330,8 @@ int MoveToDevice(solution *S, int device)
       if (S->mesh_eles(i)->mv_all_cpu_gpu(S->ctx)) { S->err = S->mesh_eles(i)->last_error(); return 1; }
   for (int i = 0; i < S->n_int_inter_types; i++)
     if (S->mesh_int_inters(i).mv_all_cpu_gpu(S->ctx, S)) { S->err = S->mesh_int_inters(i).last_error(); return 1; }
+  for (int i = 0; i < S->n_bdy_inter_types; i++)
+    if (S->mesh_bdy_inters(i).mv_all_cpu_gpu(S->ctx, S)) { S->err = S->mesh_bdy_inters(i).last_error(); return 1; }
   for (int i = 0; i < S->n_mpi_inter_types; i++)
     if (S->mesh_mpi_inters(i).mv_all_cpu_gpu(S->ctx, S)) { S->err = S->mesh_mpi_inters(i).last_error(); return 1; }
   return 0;
@@ -313,6 +357,8 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   each_ele(&eles::evaluate_invFlux);
   /*! Compute the transformed normal inviscid numerical fluxes, common solution and corrections. */
   for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_invFlux();
+  for (i = 0; i < FlowSol->n_bdy_inter_types; i++)
+    FlowSol->mesh_bdy_inters(i).evaluate_boundaryConditions_invFlux(FlowSol, FlowSol->time);
   if (FlowSol->nproc > 1)
   {
     for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_solution();
@@ -336,6 +382,7 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   {
     /*! Compute transformed normal interface viscous flux and add to transformed normal inviscid flux. */
     for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_viscFlux();
+    for (i = 0; i < FlowSol->n_bdy_inter_types; i++) FlowSol->mesh_bdy_inters(i).evaluate_boundaryConditions_viscFlux(FlowSol->time);
     /*! Evaluate the MPI interfaces. */
     if (FlowSol->nproc > 1)
     {
@@ -379,6 +426,12 @@ int RunSteps(solution *FlowSol, int n_steps)
       FlowSol->err = FlowSol->mesh_mpi_inters(j).last_error();
       return 1;
     }
+  for (int j = 0; j < FlowSol->n_bdy_inter_types; j++)
+    if (FlowSol->mesh_bdy_inters(j).failed())
+    {
+      FlowSol->err = FlowSol->mesh_bdy_inters(j).last_error();
+      return 1;
+    }
   return 0;
 }
 
@@ -403,6 +456,8 @@ int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
   std::vector<hfx_inters *> fi, fm;
   for (int j = 0; j < FlowSol->n_int_inter_types; j++)
     if (FlowSol->mesh_int_inters(j).get_n_inters()) fi.push_back(FlowSol->mesh_int_inters(j).device());
+  for (int j = 0; j < FlowSol->n_bdy_inter_types; j++) // boundary blocks ride with the interior ones
+    if (FlowSol->mesh_bdy_inters(j).get_n_inters()) fi.push_back(FlowSol->mesh_bdy_inters(j).device());
   for (int j = 0; j < FlowSol->n_mpi_inter_types; j++)
     if (FlowSol->mesh_mpi_inters(j).get_n_inters()) fm.push_back(FlowSol->mesh_mpi_inters(j).device());
   const int RKSteps = FlowSol->run_input.n_rk_stages();

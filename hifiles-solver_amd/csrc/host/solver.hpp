@@ -22,6 +22,8 @@ struct solution
   eles_hexas mesh_eles_hexas;
   int n_int_inter_types = 3;
   hf_array<int_inters> mesh_int_inters;
+  int n_bdy_inter_types = 3;
+  hf_array<bdy_inters> mesh_bdy_inters; // include/solution.h:84-86
   // partition faces (include/solution.h:88-94, _MPI only in the reference)
   int n_mpi_inter_types = 3;
   hf_array<mpi_inters> mesh_mpi_inters;
@@ -46,6 +48,10 @@ struct box_mesh
   // structured block split is the documented stand-in.
   int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
   int rank_of(int px, int py, int pz) const { return px + pgrid[0] * (py + pgrid[1] * pz); }
+  // boundary group of each side of the GLOBAL box, indexed by the element-local face number (hex: z- y- x+ y+ x-
+  // z+, quad: y- x+ y+ x-): index into run_input.bc_specs; -1 or a cyclic group = periodic.  A direction is
+  // periodic when both of its sides are.
+  int side_bc[6] = {-1, -1, -1, -1, -1, -1};
   std::vector<double> xv; // (nv, dims) column-major
   int nv() const { return (n[0] + 1) * (n[1] + 1) * (dims == 3 ? n[2] + 1 : 1); }
   int ne() const { return n[0] * n[1] * (dims == 3 ? n[2] : 1); }

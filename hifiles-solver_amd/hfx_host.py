@@ -23,7 +23,21 @@ class CaseDesc(C.Structure):
                [(k, C.c_double) for k in ("gamma", "prandtl", "S_gas", "T_gas", "R_gas", "mu_gas",
                                           "Mach_free_stream", "rho_free_stream", "L_free_stream", "T_free_stream",
                                           "rho_c_ic", "Mach_c_ic", "T_c_ic", "u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic")] + \
-               [("rank", C.c_int), ("nproc", C.c_int), ("pgrid", C.c_int * 3)]
+               [("rank", C.c_int), ("nproc", C.c_int), ("pgrid", C.c_int * 3),
+                ("n_bcs", C.c_int), ("bcs", C.c_void_p), ("side_bc", C.c_int * 6)]
+
+
+class BcDesc(C.Structure):
+    """hfxh_bc_desc: one boundary group, dimensional inputs as in the reference's input file."""
+    _fields_ = [("flag", C.c_int), ("pressure_ramp", C.c_int)] + \
+               [(k, C.c_double) for k in ("rho", "u", "v", "w", "p_static", "T_static", "p_total", "T_total", "nx", "ny", "nz",
+                                          "mach", "p_ramp_coeff", "T_ramp_coeff", "p_total_old", "T_total_old")]
+
+
+BC_TYPES = {"sub_in_simp": 0, "sub_out_simp": 1, "sub_in_char": 2, "sub_out_char": 3, "sup_in": 4, "sup_out": 5,
+            "slip_wall": 6, "cyclic": 7, "isotherm_wall": 8, "adiabat_wall": 9, "char": 10, "slip_wall_dual": 11}
+SIDES3 = ("z-", "y-", "x+", "y+", "x-", "z+")  # element-local face numbers of a hex
+SIDES2 = ("y-", "x+", "y+", "x-")
 
 EXCHANGE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
 
@@ -55,11 +69,30 @@ def check(rc):
 
 
 class Case:
-    def __init__(self, n, xv=None, loc_1d_upts=None, rank=0, pgrid=None, **kw):
-        """n: cells per direction of THIS rank's block; pgrid: ranks per direction (None: one rank)."""
+    def __init__(self, n, xv=None, loc_1d_upts=None, rank=0, pgrid=None, bcs=None, sides=None, **kw):
+        """n: cells per direction of THIS rank's block; pgrid: ranks per direction (None: one rank).
+        bcs: list of boundary groups, each a dict with `type` (the reference's bc type name) and the type's
+        dimensional parameters (rho,u,v,w,p_static,T_static,p_total,T_total,nx,ny,nz,mach,pressure_ramp,...);
+        sides: {"x-": index into bcs, ...}; sides that are not listed are periodic."""
         d = CaseDesc()
         cfg = dict(TGV)
         cfg.update(kw)
+        self._bcs = None
+        if bcs:
+            self._bcs = (BcDesc * len(bcs))()
+            for i, b in enumerate(bcs):
+                r = self._bcs[i]
+                r.nx, r.T_total, r.T_total_old = 1.0, -1.0, -1.0
+                for k, v in b.items():
+                    if k == "type":
+                        r.flag = BC_TYPES[v]
+                    else:
+                        setattr(r, k, v)
+            d.n_bcs = len(bcs)
+            d.bcs = C.cast(self._bcs, C.c_void_p)
+            names = SIDES3 if cfg.get("dims", 3) == 3 else SIDES2
+            for f in range(6):
+                d.side_bc[f] = (sides or {}).get(names[f], -1) if f < len(names) else -1
         self.rank, self.pgrid = rank, (list(pgrid) if pgrid is not None else None)
         if pgrid is not None:
             d.rank, d.nproc = rank, int(np.prod(pgrid))
@@ -109,6 +142,33 @@ class Case:
         r = np.ctypeslib.as_array(R, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
         return l, r
 
+    def bdy_faces(self):
+        """(L, boundary_id) of the boundary-face block."""
+        L, ids = ip(), ip()
+        nf, ni = C.c_int(), C.c_int()
+        check(lib().hfxh_case_get_bdy_faces(self.h, C.byref(L), C.byref(ids), C.byref(nf), C.byref(ni)))
+        if ni.value == 0:
+            return np.zeros((nf.value, 0), dtype=np.int32, order="F"), np.zeros(0, dtype=np.int32)
+        n = nf.value * ni.value
+        l = np.ctypeslib.as_array(L, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
+        return l, np.ctypeslib.as_array(ids, shape=(ni.value,)).copy()
+
+    def bc_list(self):
+        """(flags (3,nbc), params (15,nbc), R_ref, ramp_counter): run_input.bc_list after non-dimensionalisation,
+        in the fixtures' array form."""
+        p = C.POINTER(hfx.Bc)()
+        n, rc = C.c_int(), C.c_int()
+        R = C.c_double()
+        check(lib().hfxh_case_get_bcs(self.h, C.byref(p), C.byref(n), C.byref(R), C.byref(rc)))
+        fl = np.zeros((3, n.value), dtype=np.int32, order="F")
+        par = np.zeros((15, n.value), order="F")
+        for b in range(n.value):
+            r = p[b]
+            fl[:, b] = (r.flag, r.pressure_ramp, r.use_wm)
+            par[:, b] = [r.rho, r.velocity[0], r.velocity[1], r.velocity[2], r.p_static, r.T_static, r.p_total, r.T_total,
+                         r.nx, r.ny, r.nz, r.p_ramp_coeff, r.T_ramp_coeff, r.p_total_old, r.T_total_old]
+        return fl, par, R.value, rc.value
+
     def mpi_faces(self):
         """(L, Rlut, Nout_proc) of the partition-face block."""
         L, R, nout = ip(), ip(), ip()
@@ -154,6 +214,11 @@ class Case:
         L, R = self.faces()
         t = 2 if self.n_dims == 3 else 0
         d["int%d_L" % t], d["int%d_R" % t] = L, R
+        bL, bid = self.bdy_faces()
+        if bid.size:
+            d["bdy%d_L" % t], d["bdy%d_id" % t] = bL, bid
+            d["bc_flags"], d["bc_params"], R_ref, rc = self.bc_list()
+            d["bc_R_ref"], d["ramp_counter"] = np.array([R_ref]), np.array([rc], dtype=np.int32)
         for k in ("gamma", "prandtl", "rt_inf", "mu_inf", "c_sth", "fix_vis", "ldg_beta", "ldg_tau", "dt",
                   "viscous", "riemann_solve_type", "vis_riemann_solve_type", "adv_type", "dt_type"):
             d[k] = np.array([getattr(p, k)], dtype=np.float64)

@@ -18,6 +18,16 @@ extern "C" {
 
 typedef struct hfxh_case hfxh_case;
 
+/* one boundary group: `bc_<name>_type` (as hfx_bc_flag) and its parameters as the reference's input file
+ * gives them, DIMENSIONAL (/root/reference/src/input.cpp:328-437); T_total / T_total_old < 0: not given
+ * (default T_free_stream) */
+typedef struct hfxh_bc_desc
+{
+  int flag, pressure_ramp;
+  double rho, u, v, w, p_static, T_static, p_total, T_total, nx, ny, nz, mach;
+  double p_ramp_coeff, T_ramp_coeff, p_total_old, T_total_old;
+} hfxh_bc_desc;
+
 /* inputs are DIMENSIONAL, exactly the keys of the reference's input file
  * (/root/reference/src/input.cpp:62-327); they are non-dimensionalised as input::setup_params does */
 typedef struct hfxh_case_desc
@@ -44,6 +54,13 @@ typedef struct hfxh_case_desc
    * cells per direction and edge `length`; rank = px + pgrid[0]*(py + pgrid[1]*pz).  Stands in for the
    * reference's ParMETIS partition (src/mesh.cpp:72-314). */
   int rank, nproc, pgrid[3];
+  /* boundary groups (n_bcs 0: fully periodic).  side_bc[f], f = element-local face number of the side of the
+   * GLOBAL box (hexes: z- y- x+ y+ x- z+; quads: y- x+ y+ x-), is an index into bcs; a group of type
+   * HFX_BC_CYCLIC (or index -1) makes the side periodic.  Mirrors the mesh file's boundary groups + the input
+   * file's bc_<name>_* keys. */
+  int n_bcs;
+  const hfxh_bc_desc *bcs;
+  int side_bc[6];
 } hfxh_case_desc;
 
 const char *hfxh_last_error(void);
@@ -58,6 +75,10 @@ int hfxh_case_params(hfxh_case *c, hfx_params *p);
 int hfxh_case_get_array(hfxh_case *c, const char *name, const double **ptr, int dims[4]);
 int hfxh_case_get_faces(hfxh_case *c, const int **L, const int **R, int *n_fpts_per_inter, int *n_inters);
 
+/* boundary faces (bdy_inters): left offsets L(j,i), boundary_id(i), and the non-dimensional bc_list
+ * (what input::read_boundary_param leaves in run_input.bc_list) with R_ref and ramp_counter */
+int hfxh_case_get_bdy_faces(hfxh_case *c, const int **L, const int **boundary_id, int *n_fpts_per_inter, int *n_inters);
+int hfxh_case_get_bcs(hfxh_case *c, const hfx_bc **bcs, int *n_bcs, double *R_ref, int *ramp_counter);
 /* partition faces (mpi_inters): left offsets L(j,i), received-record slots Rlut(j,i), and Nout_proc[nproc]
  * = faces shared with each rank; a rank's faces are contiguous and ordered by rank */
 int hfxh_case_get_mpi_faces(hfxh_case *c, const int **L, const int **Rlut, int *n_fpts_per_inter, int *n_inters,

@@ -151,3 +151,22 @@ def test_full_size_residual_norms_vs_reference_stdout():
     c.close()
     want = np.array([0.00070019, 0.05031596, 0.05031596, 0.06433493, 0.11799063])
     assert np.all(np.abs(np.array(r) - want) < 6e-9), r
+
+
+@pytest.mark.parametrize("mode", ["methods", 2, 3])
+@pytest.mark.parametrize("name", ["hex_p2_bdy_walls", "hex_p2_bdy_inout", "hex_p1_bdy_inviscid", "quad_p3_bdy"])
+def test_boundary_case_through_the_mirror(name, mode):
+    """Boundary faces end to end: host-mirror setup (mesh sides -> bdy_inters, bc_list non-dimensionalisation)
+    + the mirrored CalcResidual / the split fused paths, against the genuine reference's state after a step."""
+    import bdy_util
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c, meta = bdy_util.case_from_fixture(d)
+    c.to_device(0)
+    if mode == "methods":
+        c.run(1)
+    else:
+        c.run_steps_lib(1, fused=mode)
+    c.sync_host()
+    last = int(d["sizes"][7]) - 1
+    assert rel(c.array("disu_upts0"), d["u_step0_stage%d" % last]) < 1e-11
+    c.close()

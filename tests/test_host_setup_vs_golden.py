@@ -100,3 +100,26 @@ def test_error_convention_host():
         H.Case(2, order=2)  # fewer than 3 cells per direction
     with pytest.raises(hfx.HfxError):
         H.Case(3, order=2, riemann_solve_type=1)  # Lax-Friedrich with NS (input.cpp:546)
+
+
+@pytest.mark.parametrize("name", ["hex_p2_bdy_walls", "hex_p2_bdy_inout", "hex_p1_bdy_inviscid", "quad_p3_bdy"])
+def test_boundary_tables_vs_reference(name):
+    """bdy_inters setup of the host mirror: same faces, same order, same boundary ids, same non-dimensional
+    bc_list as the genuine reference builds from the mesh file's groups and the input file's bc_* keys."""
+    import bdy_util
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c, meta = bdy_util.case_from_fixture(d)
+    t = 2 if meta["dims"] == 3 else 0
+    L, ids = c.bdy_faces()
+    assert np.array_equal(L, d["bdy%d_L" % t])
+    assert np.array_equal(ids, np.ravel(d["bdy%d_id" % t]))
+    if "int%d_L" % t in d:
+        Li, Ri = c.faces()
+        assert np.array_equal(Li, d["int%d_L" % t]) and np.array_equal(Ri, d["int%d_R" % t])
+    fl, par, R_ref, rc = c.bc_list()
+    assert np.array_equal(fl, d["bc_flags"])
+    assert np.abs(par - d["bc_params"]).max() <= 1e-15 * np.abs(d["bc_params"]).max()
+    assert abs(R_ref - float(np.ravel(d["bc_R_ref"])[0])) <= 1e-15 * abs(R_ref)
+    assert rc == int(np.ravel(d["ramp_counter"])[0])
+    assert rel(c.array("disu_upts0"), d["u_init"]) < 1e-14
+    c.close()
