@@ -1305,6 +1305,7 @@ int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
   for (int b = 0; b < nfb; b++)
     HFX_CHECK(!faces[b]->is_bdy, "the gather-style fused path (fused=1) has no boundary faces: use fused=2 or 3");
+  HFX_CHECK(!e->shock_ready, "the gather-style fused path (fused=1) has no shock capturing: use fused=2 or 3");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
   if (n_steps <= 0) return 0;
@@ -2662,7 +2663,15 @@ int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps,
   if (hfx_eles_extrapolate_solution(e)) return 1;
   for (int s = 0; s < n_steps; s++)
     for (int rk = 0; rk < nst; rk++)
+    {
       if (split_stage(e, faces, nfb, rk, rk == nst - 1, 0, variant)) return 1;
+      if (e->shock_ready)
+      {
+        // the filter changes disu_upts(0) after the stage: redo the flux-point solution of the new state
+        if (hfx_eles_shock_capture(e)) return 1;
+        if (hfx_eles_extrapolate_solution(e)) return 1;
+      }
+    }
   return 0;
 }
 

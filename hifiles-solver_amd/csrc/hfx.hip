@@ -403,7 +403,7 @@ int hfx_eles_create(hfx_ctx *ctx, const hfx_eles_desc *d, hfx_eles **out)
   len[HFX_TDISF_UPTS] = pu * nf * nd; len[HFX_NORM_TDISF_FPTS] = pf * nf; len[HFX_NORM_TCONF_FPTS] = pf * nf;
   len[HFX_DIV_TCONF_UPTS] = pu * nf; len[HFX_DELTA_DISU_FPTS] = pf * nf;
   len[HFX_GRAD_DISU_UPTS] = pu * nf * nd; len[HFX_GRAD_DISU_FPTS] = pf * nf * nd;
-  len[HFX_SRC_UPTS] = pu * nf; len[HFX_DT_LOCAL] = ne;
+  len[HFX_SRC_UPTS] = pu * nf; len[HFX_DT_LOCAL] = ne; len[HFX_SENSOR] = ne;
   for (int i = 0; i < HFX_N_ARRAYS; i++)
   {
     e->arr_len[i] = len[i];
@@ -424,6 +424,9 @@ int hfx_eles_destroy(hfx_eles *e)
 {
   if (!e) return 0;
   free_operator(e->opp_0); free_operator(e->opp_3); free_operator(e->opp_6);
+  free_operator(e->inv_vandermonde); free_operator(e->exp_filter);
+  if (e->persson_num) (void)hipFree(e->persson_num);
+  if (e->persson_den) (void)hipFree(e->persson_den);
   for (int i = 0; i < 3; i++)
   {
     free_operator(e->opp_1[i]); free_operator(e->opp_2[i]); free_operator(e->opp_4[i]); free_operator(e->opp_5[i]);
@@ -718,6 +721,63 @@ int hfx_inters_destroy(hfx_inters *f)
   return 0;
 }
 
+// ---- shock capturing --------------------------------------------------------------------
+int hfx_eles_set_shock_capture(hfx_eles *e, const double *inv_vandermonde, const double *exp_filter,
+                               const double *norm_basis_persson, const int *high_modes, double s0, int shock_det_field)
+{
+  HFX_CHECK(e && inv_vandermonde && exp_filter && norm_basis_persson && high_modes, "hfx_eles_set_shock_capture: NULL argument");
+  HFX_CHECK(shock_det_field == 0 || shock_det_field == 1, "Unsupported shock capturing field."); /* src/eles_hexas.cpp:1034 */
+  free_operator(e->inv_vandermonde);
+  free_operator(e->exp_filter);
+  if (make_operator(e->inv_vandermonde, inv_vandermonde, e->n_upts, e->n_upts)) return 1;
+  if (make_operator(e->exp_filter, exp_filter, e->n_upts, e->n_upts)) return 1;
+  std::vector<double> num(e->n_upts), den(e->n_upts);
+  for (int j = 0; j < e->n_upts; j++)
+  {
+    den[j] = norm_basis_persson[j];
+    num[j] = high_modes[j] ? norm_basis_persson[j] : 0.0;
+  }
+  if (e->persson_num) (void)hipFree(e->persson_num);
+  if (e->persson_den) (void)hipFree(e->persson_den);
+  e->persson_num = e->persson_den = nullptr;
+  if (dev_alloc_copy(&e->persson_num, num.data(), e->n_upts)) return 1;
+  if (dev_alloc_copy(&e->persson_den, den.data(), e->n_upts)) return 1;
+  e->s0 = s0;
+  e->shock_det_field = shock_det_field;
+  e->shock_ready = true;
+  return 0;
+}
+
+int hfx_eles_shock_capture(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0; /* src/eles.cpp:2920 */
+  HFX_CHECK(e->shock_ready, "shock_capture: hfx_eles_set_shock_capture was not called");
+  hfx_ctx *ctx = e->ctx;
+  const long plane = (long)e->n_upts * e->n_eles;
+  double *scratch = e->arr[HFX_TDISF_UPTS]; // free between AdvanceSolution and the next stage's evaluate_invFlux
+  double *u = e->arr[HFX_DISU_UPTS0];
+  // 1. modal coefficients of the sensor field, all elements at once: a dense (n_upts x n_upts) contraction
+  {
+    const Operator *ops[1] = {&e->inv_vandermonde};
+    const double *in[1] = {u + (e->shock_det_field == 0 ? 0 : (long)(e->n_dims + 1) * plane)};
+    if (contract_multi_in(ctx, ops, 1, in, scratch, e->n_eles, 0)) return 1;
+  }
+  // 2. sensor
+  hipLaunchKernelGGL(persson_sensor_kernel, dim3((unsigned)e->n_eles), dim3(64), 0, ctx->stream, e->n_upts, (long)e->n_eles,
+                     scratch, e->persson_num, e->persson_den, e->arr[HFX_SENSOR]);
+  // 3. filtered state of every element (dense contraction), 4. kept where the sensor fires
+  {
+    const Operator *ops[1] = {&e->exp_filter};
+    const double *in[1] = {u};
+    if (contract_multi_in(ctx, ops, 1, in, scratch, (long)e->n_eles * e->n_fields, 0)) return 1;
+  }
+  hipLaunchKernelGGL(shock_select_kernel, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, e->n_upts,
+                     (long)e->n_eles, e->n_fields, e->s0, e->arr[HFX_SENSOR], scratch, u);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- bdy_inters ----------------------------------------------------------------------
 int hfx_bdy_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, const int *L, const int *boundary_id,
                           const hfx_bc *bcs, int n_bcs, double R_ref, hfx_inters **out)
@@ -1000,6 +1060,7 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, i
     {
       if (hfx_CalcResidual(e, faces, nfb)) return 1;
       if (hfx_eles_AdvanceSolution(e, rk, adv)) return 1;
+      if (e->shock_ready && hfx_eles_shock_capture(e)) return 1; /* src/HiFiLES.cpp:214-216 */
     }
   return 0;
 }

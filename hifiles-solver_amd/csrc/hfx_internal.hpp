@@ -90,6 +90,12 @@ struct hfx_eles
   hfx_ctx *ctx = nullptr;
   int n_eles = 0, n_upts = 0, n_fpts = 0, n_fields = 0, n_dims = 0, ele_type = 0, order = 0;
   bool viscous_ops = false;
+  // shock capturing (hfx_eles_set_shock_capture)
+  bool shock_ready = false;
+  hfx::Operator inv_vandermonde, exp_filter;
+  double *persson_num = nullptr, *persson_den = nullptr; // (n_upts) weights of the sensor's two sums
+  double s0 = 0.0;
+  int shock_det_field = 0;
   hfx::Operator opp_0, opp_1[3], opp_2[3], opp_3, opp_4[3], opp_5[3], opp_6;
   // metrics
   double *detjac_upts = nullptr, *JGinv_upts = nullptr, *detjac_fpts = nullptr, *JGinv_fpts = nullptr,

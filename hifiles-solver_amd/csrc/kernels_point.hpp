@@ -288,4 +288,41 @@ __global__ __launch_bounds__(PT_BLOCK) void res_partial_kernel(long plane, int n
   if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
 
+// ---- Persson sensor from the modal coefficients (src/eles_hexas.cpp:1033-1056) -------------
+// sensor(e) = sum_j num(j) modal(j,e)^2 / sum_j den(j) modal(j,e)^2 ; one workgroup (64 lanes) per element
+__global__ __launch_bounds__(64) void persson_sensor_kernel(int n_upts, long n_eles, const double *__restrict__ modal,
+                                                            const double *__restrict__ num, const double *__restrict__ den,
+                                                            double *__restrict__ sensor)
+{
+  const long e = blockIdx.x;
+  if (e >= n_eles) return;
+  double a = 0.0, b = 0.0;
+  for (int j = threadIdx.x; j < n_upts; j += 64)
+  {
+    const double m = modal[j + (long)n_upts * e];
+    const double m2 = m * m;
+    a += m2 * num[j];
+    b += den[j] * m2;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  if (threadIdx.x == 0) sensor[e] = a / b;
+}
+
+// disu_upts(0)(:, e, :) = filt(:, e, :) where sensor(e) >= s0 (src/eles.cpp:2936-2954)
+__global__ __launch_bounds__(PT_BLOCK) void shock_select_kernel(int n_upts, long n_eles, int n_fields, double s0,
+                                                                const double *__restrict__ sensor,
+                                                                const double *__restrict__ filt, double *__restrict__ u)
+{
+  const long plane = (long)n_upts * n_eles;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  if (!(sensor[p / n_upts] >= s0)) return;
+  for (int k = 0; k < n_fields; k++) u[p + k * plane] = filt[p + k * plane];
+}
+
 } // namespace hfx

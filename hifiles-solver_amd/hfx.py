@@ -18,7 +18,7 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 
 (DISU_UPTS0, DISU_UPTS1, DISU_FPTS, TDISF_UPTS, NORM_TDISF_FPTS, NORM_TCONF_FPTS, DIV_TCONF_UPTS,
- DELTA_DISU_FPTS, GRAD_DISU_UPTS, GRAD_DISU_FPTS, SRC_UPTS, DT_LOCAL) = range(12)
+ DELTA_DISU_FPTS, GRAD_DISU_UPTS, GRAD_DISU_FPTS, SRC_UPTS, DT_LOCAL, SENSOR) = range(13)
 CONTRACT_AUTO, CONTRACT_DENSE, CONTRACT_SPARSE = 0, 1, 2
 
 
@@ -163,7 +163,7 @@ class Eles:
             DISU_UPTS0: (nu, ne, nf), DISU_UPTS1: (nu, ne, nf), DISU_FPTS: (nfp, ne, nf),
             TDISF_UPTS: (nu, ne, nf, nd), NORM_TDISF_FPTS: (nfp, ne, nf), NORM_TCONF_FPTS: (nfp, ne, nf),
             DIV_TCONF_UPTS: (nu, ne, nf), DELTA_DISU_FPTS: (nfp, ne, nf), GRAD_DISU_UPTS: (nu, ne, nf, nd),
-            GRAD_DISU_FPTS: (nfp, ne, nf, nd), SRC_UPTS: (nu, ne, nf), DT_LOCAL: (ne,)}
+            GRAD_DISU_FPTS: (nfp, ne, nf, nd), SRC_UPTS: (nu, ne, nf), DT_LOCAL: (ne,), SENSOR: (ne,)}
 
     def upload(self, array_id, a):
         a = _f(a)
@@ -194,6 +194,15 @@ class Eles:
 
     def AdvanceSolution(self, in_step, adv_type):
         self._call("hfx_eles_AdvanceSolution", C.c_int(in_step), C.c_int(adv_type))
+
+    def set_shock_capture(self, inv_vandermonde, exp_filter, norm_basis_persson, high_modes, s0, shock_det_field):
+        a, b = _f(inv_vandermonde), _f(exp_filter)
+        n = np.ascontiguousarray(np.ravel(norm_basis_persson).astype(np.float64))
+        h = np.ascontiguousarray(np.ravel(high_modes).astype(np.int32))
+        check(lib().hfx_eles_set_shock_capture(self.h, a.ctypes.data_as(dp), b.ctypes.data_as(dp), n.ctypes.data_as(dp),
+                                               h.ctypes.data_as(ip), C.c_double(s0), C.c_int(shock_det_field)))
+
+    def shock_capture(self): self._call("hfx_eles_shock_capture")
 
     def check_nan(self):
         v = C.c_long(0)

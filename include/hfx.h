@@ -85,7 +85,8 @@ enum hfx_array_id
   HFX_GRAD_DISU_FPTS = 9, /* (n_fpts,n_eles,n_fields,n_dims) */
   HFX_SRC_UPTS = 10,      /* (n_upts,n_eles,n_fields); zero unless uploaded */
   HFX_DT_LOCAL = 11,      /* (n_eles) */
-  HFX_N_ARRAYS = 12
+  HFX_SENSOR = 12,        /* (n_eles) eles::sensor, written by hfx_eles_shock_capture */
+  HFX_N_ARRAYS = 13
 };
 
 /* which implementation the operator contractions use */
@@ -170,6 +171,18 @@ int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f);
 int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
+
+/* ---- shock capturing (row a16) ------------------------------------------ */
+/* Registers what eles_hexas / eles_quads build when run_input.shock_cap == 1 (src/eles_hexas.cpp:74-85):
+ * inv_vandermonde (n_upts,n_upts), exp_filter (n_upts,n_upts), norm_basis_persson (n_upts), and
+ * high_modes(j) = 1 where a 1-D index of Legendre mode j equals the order (the set summed in
+ * shock_det_persson, src/eles_hexas.cpp:1042-1047); s0 and shock_det_field are run_input's. */
+int hfx_eles_set_shock_capture(hfx_eles *e, const double *inv_vandermonde, const double *exp_filter,
+                               const double *norm_basis_persson, const int *high_modes, double s0, int shock_det_field);
+/* eles::shock_capture (src/eles.cpp:2918-2959), shock_det 0 (Persson) + shock_cap 1 (exponential modal
+ * filter): sensor(ele) -> HFX_SENSOR; disu_upts(0) of every element with sensor >= s0 is filtered.
+ * Called by the caller after AdvanceSolution (src/HiFiLES.cpp:214-216); invalidates disu_fpts. */
+int hfx_eles_shock_capture(hfx_eles *e);
 
 /* ---- boundary faces (reference class bdy_inters) ------------------------ */
 /* bc_flag values of the reference (src/bc.cpp:36-48) */

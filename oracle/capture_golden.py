@@ -102,6 +102,14 @@ CASES = [
     case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
     case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
     case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+    # shock capturing (Persson sensor + exponential modal filter after every RK stage); s0 sits in a gap of the
+    # first stage's sensor distribution so that about a third of the elements are filtered
+    case("hex_p3_shock", amp=0.15, level=1, order=3, steps=2, shock_cap=1, shock_det=0, s0=1.4e-7, expf_fac=36.0,
+         expf_order=4, expf_cutoff=1, shock_det_field=0),
+    case("hex_p2_shock_energy", amp=0.15, level=1, order=2, steps=1, shock_cap=1, shock_det=0, s0=1.11e-6, expf_fac=36.0,
+         expf_order=4, expf_cutoff=0, shock_det_field=1),
+    case("quad_p3_shock", dims=2, n=4, amp=0.1, level=1, order=3, steps=1, shock_cap=1, shock_det=0, s0=1.8616e-7,
+         expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0),
     # boundary faces (bdy_inters): every ghost-state branch that the shipped cases use
     case("hex_p2_bdy_walls", amp=0.1, level=2, order=2, steps=1,
          bcs={"z-": "In", "z+": "Out", "y-": "WallT", "y+": "WallQ", "x-": "Far", "x+": "Slip"}, **BC_KEYS),

@@ -774,6 +774,45 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, con
 }
 
 /* ------------------------------------------------------------------------ */
+/* shock capturing                                                           */
+
+/* eles::shock_capture (src/eles.cpp:2918-2959) with shock_det_persson (src/eles_hexas.cpp:1007-1059) */
+void orc_shock_capture(orc_eles *e, const orc_shock *S)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields, nd = e->n_dims;
+  double *u = e->disu_upts[0];
+  const int fld = (S->shock_det_field == 0) ? 0 : nd + 1;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int ic = 0; ic < ne; ic++)
+  {
+    double modal[512];
+    /* step 1: modal = inv_vandermonde * u(:, ic, fld) */
+    orc_dgemm(nu, 1, nu, 1.0, 0.0, S->inv_vandermonde, u + (long)nu * ic + (long)fld * nu * ne, modal);
+    /* step 2 */
+    for (int j = 0; j < nu; j++) modal[j] = modal[j] * modal[j];
+    /* step 3 */
+    double s = 0;
+    for (int j = 0; j < nu; j++)
+      if (S->high_modes[j]) s += modal[j] * S->norm_basis_persson[j];
+    /* step 4: inner_product(norm, norm + n, modal, 0.) */
+    double den = 0.;
+    for (int j = 0; j < nu; j++) den = den + S->norm_basis_persson[j] * modal[j];
+    S->sensor[ic] = s / den;
+  }
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < ne; i++)
+    if (S->sensor[i] >= S->s0)
+    {
+      double temp_sol[512 * MAXF], filt_sol[512 * MAXF];
+      for (int j = 0; j < nu; j++)
+        for (int k = 0; k < nf; k++) temp_sol[j + nu * k] = u[j + (long)nu * i + (long)k * nu * ne];
+      orc_dgemm(nu, nf, nu, 1.0, 0.0, S->exp_filter, temp_sol, filt_sol);
+      for (int j = 0; j < nu; j++)
+        for (int k = 0; k < nf; k++) u[j + (long)nu * i + (long)k * nu * ne] = filt_sol[j + nu * k];
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* boundary faces                                                            */
 
 /* src/bdy_inters.cpp:340-1019, equation 0 (Navier-Stokes / Euler), RANS off, wall model off */

@@ -115,6 +115,19 @@ typedef struct orc_bdy_inters
   int ramp_counter; /* run_input.ramp_counter */
 } orc_bdy_inters;
 
+/* shock capturing (src/eles.cpp:2918-2959, src/eles_hexas.cpp:1007-1059): matrices built by the element class
+ * (set_vandermonde / set_exp_filter / calc_norm_basis) */
+typedef struct orc_shock
+{
+  const double *inv_vandermonde;    /* (n_upts,n_upts) */
+  const double *exp_filter;         /* (n_upts,n_upts) */
+  const double *norm_basis_persson; /* (n_upts) */
+  const int *high_modes;            /* (n_upts) 1 where a mode index equals the order */
+  double s0;
+  int shock_det_field; /* 0 density, 1 total energy */
+  double *sensor;      /* (n_eles) out */
+} orc_shock;
+
 void orc_set_threads(int n);
 
 /* src/funcs.cpp:49-123 */
@@ -154,6 +167,8 @@ void orc_int_calculate_common_invFlux(const orc_int_inters *f, orc_eles *e, cons
 void orc_int_calculate_common_viscFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p); /* :254 */
 
 /* partition faces: src/mpi_inters.cpp */
+void orc_shock_capture(orc_eles *e, const orc_shock *s); /* eles::shock_capture, shock_cap 1 + shock_det 0 */
+
 /* boundary faces, src/bdy_inters.cpp (wall model, LES inlet, RANS off) */
 void orc_set_boundary_conditions(int sol_spec, const orc_bc *bc, int n_dims, int viscous, const double *u_l, double *u_r,
                                  const double *norm, double gamma, double R_ref, int ramp_counter);            /* :340-1019 */

@@ -292,6 +292,31 @@ int main(int argc, char *argv[])
       put_scalar("ramp_counter", run_input.ramp_counter);
     }
   }
+  // shock capturing (src/eles.cpp:2918, src/eles_hexas.cpp:953-1059): the registered matrices and the set of
+  // highest modes of the Persson sensor
+  if (run_input.shock_cap)
+  {
+    put_arr("inv_vandermonde", E->inv_vandermonde);
+    put_arr("exp_filter", E->exp_filter);
+    eles_hexas *EH = (n_dims == 3) ? &FlowSol.mesh_eles_hexas : NULL;
+    eles_quads *EQ = (n_dims == 2) ? &FlowSol.mesh_eles_quads : NULL;
+    if (EH) put_arr("norm_basis_persson", EH->norm_basis_persson);
+    if (EQ) put_arr("norm_basis_persson", EQ->norm_basis_persson);
+    vector<int32_t> hi(n_upts);
+    for (int j = 0; j < n_upts; j++)
+    {
+      int x = 0, y = 0, z = 0;
+      if (EH)
+        EH->get_legendre_basis_3D_index(j, run_input.order, x, y, z);
+      else
+        EQ->get_legendre_basis_2D_index(j, run_input.order, x, y);
+      hi[j] = (x == run_input.order || y == run_input.order || (n_dims == 3 && z == run_input.order)) ? 1 : 0;
+    }
+    put_i("persson_high_modes", hi.data(), {n_upts});
+    put_scalar("s0", run_input.s0);
+    put_scalar("shock_det_field", run_input.shock_det_field);
+    put_scalar("shock_cap", run_input.shock_cap);
+  }
   if (level >= 1)
   {
     put_arr("detjac_upts", E->detjac_upts);
@@ -376,7 +401,11 @@ int main(int argc, char *argv[])
       for (int j = 0; j < FlowSol.n_ele_types; j++)
         FlowSol.mesh_eles(j)->AdvanceSolution(rk, run_input.adv_type);
       if (run_input.shock_cap)
+      {
+        if (step == 0 && rk == 0) put_arr("s0_u_before_shock_capture", E->disu_upts(0));
         for (int j = 0; j < FlowSol.n_ele_types; j++) FlowSol.mesh_eles(j)->shock_capture();
+        if (step == 0 && rk == 0) put_arr("s0_sensor", E->sensor);
+      }
 
       if (level >= 1 || rk == RKSteps - 1)
       {

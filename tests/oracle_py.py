@@ -35,6 +35,11 @@ class IntInters(C.Structure):
     _fields_ = [("n_inters", C.c_int), ("n_fpts_per_inter", C.c_int), ("L", ip), ("R", ip)]
 
 
+class Shock(C.Structure):
+    _fields_ = [("inv_vandermonde", dp), ("exp_filter", dp), ("norm_basis_persson", dp), ("high_modes", ip),
+                ("s0", C.c_double), ("shock_det_field", C.c_int), ("sensor", dp)]
+
+
 class Bc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("flag", "pressure_ramp", "use_wm", "pad")] + \
                [("rho", C.c_double), ("velocity", C.c_double * 3)] + \
@@ -138,6 +143,16 @@ class Case:
                 L = np.asfortranarray(np.array(data["int%d_L" % t], dtype=np.int32))
                 R = np.asfortranarray(np.array(data["int%d_R" % t], dtype=np.int32))
                 self.faces.append((L, R))
+        # shock capturing
+        self.shock_cap = int(np.ravel(data["shock_cap"])[0]) if "shock_cap" in data else 0
+        if self.shock_cap:
+            self.arr["inv_vandermonde"] = g("inv_vandermonde")
+            self.arr["exp_filter"] = g("exp_filter")
+            self.arr["norm_basis_persson"] = np.ascontiguousarray(np.ravel(data["norm_basis_persson"]).astype(np.float64))
+            self.hi = np.ascontiguousarray(np.ravel(data["persson_high_modes"]).astype(np.int32))
+            self.arr["sensor"] = np.zeros(ne)
+            self.s0 = float(np.ravel(data["s0"])[0])
+            self.shock_det_field = int(np.ravel(data["shock_det_field"])[0])
         # boundary-face blocks
         self.bdy = []
         for t in range(3):
@@ -189,6 +204,21 @@ class Case:
             arr[i].L = iptr(L); arr[i].R = iptr(R)
         self._f = arr
         return arr, len(self.faces)
+
+
+def _c_shock(self):
+    sh = Shock()
+    sh.inv_vandermonde = fptr(self.arr["inv_vandermonde"])
+    sh.exp_filter = fptr(self.arr["exp_filter"])
+    sh.norm_basis_persson = self.arr["norm_basis_persson"].ctypes.data_as(dp)
+    sh.high_modes = self.hi.ctypes.data_as(ip)
+    sh.s0, sh.shock_det_field = self.s0, self.shock_det_field
+    sh.sensor = self.arr["sensor"].ctypes.data_as(dp)
+    self._sh = sh
+    return sh
+
+
+Case.c_shock = _c_shock
 
 
 def _c_bdy(self):

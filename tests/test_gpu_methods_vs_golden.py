@@ -54,6 +54,9 @@ def build(ctx, d, mode=hfx.CONTRACT_AUTO):
             faces.append(hfx.BdyInters(ctx, e, d["bdy%d_L" % t], d["bdy%d_id" % t],
                                        hfx.bc_records(d["bc_flags"], d["bc_params"]),
                                        float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
+    if "shock_cap" in d and int(np.ravel(d["shock_cap"])[0]):
+        e.set_shock_capture(d["inv_vandermonde"], d["exp_filter"], d["norm_basis_persson"], d["persson_high_modes"],
+                            float(np.ravel(d["s0"])[0]), int(np.ravel(d["shock_det_field"])[0]))
     e.upload(hfx.DISU_UPTS0, d["u_init"])
     return e, faces
 
@@ -149,6 +152,12 @@ def test_stage_states_vs_reference(ctx, name):
             if st == 0 and rk == 0:
                 assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOLD
             e.AdvanceSolution(rk, adv)
+            if "shock_cap" in d:  # src/HiFiLES.cpp:214-216
+                e.shock_capture()
+                if st == 0 and rk == 0:
+                    sens = e.download(hfx.SENSOR)
+                    assert relerr(sens, np.ravel(d["s0_sensor"])) < 1e-9
+                    assert np.array_equal(sens >= float(np.ravel(d["s0"])[0]), np.ravel(d["s0_sensor"]) >= float(np.ravel(d["s0"])[0]))
             key = "u_step%d_stage%d" % (st, rk)
             if key in d:
                 assert relerr(e.download(hfx.DISU_UPTS0), d[key]) < RTOLS, key

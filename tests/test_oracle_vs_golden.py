@@ -41,6 +41,7 @@ def test_stage_states(oracle, name):
     e = c.c_eles()
     f, nfb = c.c_faces()
     bd, nbd = c.c_bdy()
+    sh = c.c_shock() if c.shock_cap else None
     nstage = int(d["sizes"][7])
     steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
     for st in steps:
@@ -55,6 +56,13 @@ def test_stage_states(oracle, name):
                         want = d["s0_res_sums"][fld, nt - 1]
                         assert abs(got - want) <= 1e-12 * abs(want)
             oracle.orc_AdvanceSolution(C.byref(e), C.byref(c.params), rk)
+            if sh is not None:  # src/HiFiLES.cpp:214-216
+                if st == 0 and rk == 0:
+                    assert relerr(c.arr["u0"], d["s0_u_before_shock_capture"]) < RTOL
+                oracle.orc_shock_capture(C.byref(e), C.byref(sh))
+                if st == 0 and rk == 0:
+                    assert relerr(c.arr["sensor"], np.ravel(d["s0_sensor"])) < 1e-11
+                    assert 0 < (c.arr["sensor"] >= c.s0).sum() < c.n_eles  # the filter branch is exercised
             key = "u_step%d_stage%d" % (st, rk)
             if key in d:
                 assert relerr(c.arr["u0"], d[key]) < RTOL, key
