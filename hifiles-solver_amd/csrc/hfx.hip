@@ -173,13 +173,21 @@ static int launch_dense(hfx_ctx *ctx, const Operator &op, const double *B, doubl
   a.in_writeback = wb;
   a.nan_flag = nan_flag;
   const int kpad = (op.k + 3) & ~3;
-  const size_t lds = (size_t)kpad * (DENSE_CT + 1) * sizeof(double);
+  // the B tile holds all k rows of its columns: narrower tiles for operators with many columns
+  int ct = DENSE_CT;
+  while (ct > 16 && (size_t)kpad * (ct + 1) * sizeof(double) > 160 * 1024) ct >>= 1;
+  const size_t lds = (size_t)kpad * (ct + 1) * sizeof(double);
   HFX_CHECK(lds <= 160 * 1024, "dense contraction: k = %d does not fit LDS", op.k);
-  const long nblk = (ncols + DENSE_CT - 1) / DENSE_CT;
+  const long nblk = (ncols + ct - 1) / ct;
   if (nblk == 0) return 0;
-  if (lds > 48 * 1024)
-    HFX_HIP(hipFuncSetAttribute((const void *)dense_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(dense_mfma_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, a);
+#define HFX_DENSE(CT_)                                                                                                  \
+  {                                                                                                                     \
+    if (lds > 48 * 1024)                                                                                                \
+      HFX_HIP(hipFuncSetAttribute((const void *)dense_mfma_kernel<CT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(dense_mfma_kernel<CT_>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, a);                    \
+  }
+  if (ct == 64) HFX_DENSE(64) else if (ct == 32) HFX_DENSE(32) else HFX_DENSE(16)
+#undef HFX_DENSE
   HFX_HIP(hipGetLastError());
   return 0;
 }
@@ -425,6 +433,9 @@ int hfx_eles_destroy(hfx_eles *e)
   if (!e) return 0;
   free_operator(e->opp_0); free_operator(e->opp_3); free_operator(e->opp_6);
   free_operator(e->inv_vandermonde); free_operator(e->exp_filter);
+  free_operator(e->opp_over_int_cubpts); free_operator(e->over_int_filter);
+  for (double *p : {e->JGinv_over_int_cubpts, e->u_cub, e->t_cub})
+    if (p) (void)hipFree(p);
   if (e->persson_num) (void)hipFree(e->persson_num);
   if (e->persson_den) (void)hipFree(e->persson_den);
   for (int i = 0; i < 3; i++)
@@ -718,6 +729,59 @@ int hfx_inters_destroy(hfx_inters *f)
   if (f->boundary_id) (void)hipFree(f->boundary_id);
   if (f->bcs) (void)hipFree(f->bcs);
   delete f;
+  return 0;
+}
+
+// ---- over-integration (polynomial de-aliasing of the inviscid flux) ------------------------
+int hfx_eles_set_over_int(hfx_eles *e, int n_cubpts, const double *opp_over_int_cubpts, const double *over_int_filter,
+                          const double *JGinv_over_int_cubpts)
+{
+  HFX_CHECK(e && opp_over_int_cubpts && over_int_filter && JGinv_over_int_cubpts && n_cubpts > 0,
+            "hfx_eles_set_over_int: bad argument");
+  free_operator(e->opp_over_int_cubpts);
+  free_operator(e->over_int_filter);
+  for (double **p : {&e->JGinv_over_int_cubpts, &e->u_cub, &e->t_cub})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  e->n_cubpts = n_cubpts;
+  if (make_operator(e->opp_over_int_cubpts, opp_over_int_cubpts, n_cubpts, e->n_upts)) return 1;
+  if (make_operator(e->over_int_filter, over_int_filter, e->n_upts, n_cubpts)) return 1;
+  const long pc = (long)n_cubpts * e->n_eles;
+  if (dev_alloc_copy(&e->JGinv_over_int_cubpts, JGinv_over_int_cubpts, pc * e->n_dims * e->n_dims)) return 1;
+  if (dev_alloc_copy(&e->u_cub, nullptr, pc * e->n_fields)) return 1;
+  if (dev_alloc_copy(&e->t_cub, nullptr, pc * e->n_fields * e->n_dims)) return 1;
+  e->over_int_ready = true;
+  fused_invalidate(e);
+  return 0;
+}
+
+int hfx_eles_evaluate_invFlux_over_int(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0; /* src/eles.cpp:1482 */
+  HFX_CHECK(e->over_int_ready, "evaluate_invFlux_over_int: hfx_eles_set_over_int was not called");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  hfx_ctx *ctx = e->ctx;
+  // interpolate the solution to the over-integration cubature points
+  {
+    const Operator *ops[1] = {&e->opp_over_int_cubpts};
+    const double *in[1] = {e->arr[HFX_DISU_UPTS0]};
+    if (contract_multi_in(ctx, ops, 1, in, e->u_cub, (long)e->n_eles * e->n_fields, 0)) return 1;
+  }
+  // flux + transform there
+  const long plane = (long)e->n_cubpts * e->n_eles;
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(invflux_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, plane,
+                       ctx->params.gamma, e->u_cub, e->JGinv_over_int_cubpts, e->t_cub);
+  else
+    hipLaunchKernelGGL(invflux_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, plane,
+                       ctx->params.gamma, e->u_cub, e->JGinv_over_int_cubpts, e->t_cub);
+  HFX_HIP(hipGetLastError());
+  // project back to the solution points (the over-integration filter)
+  {
+    const Operator *ops[1] = {&e->over_int_filter};
+    const double *in[1] = {e->t_cub};
+    if (contract_multi_in(ctx, ops, 1, in, e->arr[HFX_TDISF_UPTS], (long)e->n_eles * e->n_fields * e->n_dims, 0)) return 1;
+  }
   return 0;
 }
 
@@ -1025,7 +1089,7 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
   /* the call order of src/solver.cpp:65-216 */
   if (hfx_eles_extrapolate_solution(e)) return 1;
   if (viscous && hfx_eles_calculate_gradient(e)) return 1;
-  if (hfx_eles_evaluate_invFlux(e)) return 1;
+  if (e->over_int_ready ? hfx_eles_evaluate_invFlux_over_int(e) : hfx_eles_evaluate_invFlux(e)) return 1; /* src/solver.cpp:82-91 */
   for (int b = 0; b < nfb; b++)
     if (!faces[b]->is_bdy && hfx_int_inters_calculate_common_invFlux(faces[b])) return 1;
   for (int b = 0; b < nfb; b++)

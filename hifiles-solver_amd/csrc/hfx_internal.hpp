@@ -90,6 +90,11 @@ struct hfx_eles
   hfx_ctx *ctx = nullptr;
   int n_eles = 0, n_upts = 0, n_fpts = 0, n_fields = 0, n_dims = 0, ele_type = 0, order = 0;
   bool viscous_ops = false;
+  // over-integration (hfx_eles_set_over_int)
+  bool over_int_ready = false;
+  int n_cubpts = 0;
+  hfx::Operator opp_over_int_cubpts, over_int_filter;
+  double *JGinv_over_int_cubpts = nullptr, *u_cub = nullptr, *t_cub = nullptr;
   // shock capturing (hfx_eles_set_shock_capture)
   bool shock_ready = false;
   hfx::Operator inv_vandermonde, exp_filter;

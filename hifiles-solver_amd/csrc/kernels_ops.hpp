@@ -146,10 +146,12 @@ struct DenseArgs
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DENSE_CT = 64; // columns per workgroup
+constexpr int DENSE_CT = 64; // columns per workgroup (32 / 16 for operators with many columns: the B tile holds all of k)
 
+template <int CT>
 __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
 {
+  constexpr int DENSE_CT = CT;
   extern __shared__ double btile[]; // [kpad][DENSE_CT+pad] transposed: bt[kk*LDB + j]
   const int m = a.m, k = a.k;
   const int kpad = (k + 3) & ~3;
@@ -208,9 +210,10 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
     // D[i = lk + 4*reg -> column of the tile][j = li -> operator row]
     const int row = rt * 16 + li;
     const bool row_ok = row < m;
-    f64x4 acc[4];
+    constexpr int NS = CT / 16;
+    f64x4 acc[NS];
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < NS; s++)
     {
 #pragma unroll
       for (int rg = 0; rg < 4; rg++)
@@ -224,14 +227,14 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
       const int kk = kb + lk;
       const double av = (row_ok && kk < k) ? a.A[row + (long)m * kk] : 0.0;
 #pragma unroll
-      for (int s = 0; s < 4; s++)
+      for (int s = 0; s < NS; s++)
       {
         const double bv = btile[kk * LDB + s * 16 + li];
         acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[s], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < NS; s++)
     {
 #pragma unroll
       for (int rg = 0; rg < 4; rg++)

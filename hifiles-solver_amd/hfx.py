@@ -204,6 +204,14 @@ class Eles:
 
     def shock_capture(self): self._call("hfx_eles_shock_capture")
 
+    def set_over_int(self, opp_over_int_cubpts, over_int_filter, JGinv_over_int_cubpts):
+        a, b, c = _f(opp_over_int_cubpts), _f(over_int_filter), _f(JGinv_over_int_cubpts)
+        assert a.shape == (b.shape[1], self.n_upts) and b.shape[0] == self.n_upts
+        check(lib().hfx_eles_set_over_int(self.h, C.c_int(a.shape[0]), a.ctypes.data_as(dp), b.ctypes.data_as(dp),
+                                          c.ctypes.data_as(dp)))
+
+    def evaluate_invFlux_over_int(self): self._call("hfx_eles_evaluate_invFlux_over_int")
+
     def check_nan(self):
         v = C.c_long(0)
         check(lib().hfx_eles_check_nan(self.h, C.byref(v)))

@@ -172,6 +172,15 @@ int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
 
+/* ---- over-integration (row a5) ------------------------------------------- */
+/* Registers what eles_hexas::set_over_int (src/eles_hexas.cpp:1096-1129) and set_transforms build when
+ * run_input.over_int == 1: opp_over_int_cubpts (n_cubpts,n_upts), over_int_filter (n_upts,n_cubpts),
+ * JGinv_over_int_cubpts (n_dims,n_dims,n_cubpts,n_eles).  Once set, hfx_CalcResidual evaluates the inviscid
+ * flux through evaluate_invFlux_over_int as the reference does (src/solver.cpp:82-91). */
+int hfx_eles_set_over_int(hfx_eles *e, int n_cubpts, const double *opp_over_int_cubpts, const double *over_int_filter,
+                          const double *JGinv_over_int_cubpts);
+int hfx_eles_evaluate_invFlux_over_int(hfx_eles *e); /* eles::evaluate_invFlux_over_int, src/eles.cpp:1480-1545 */
+
 /* ---- shock capturing (row a16) ------------------------------------------ */
 /* Registers what eles_hexas / eles_quads build when run_input.shock_cap == 1 (src/eles_hexas.cpp:74-85):
  * inv_vandermonde (n_upts,n_upts), exp_filter (n_upts,n_upts), norm_basis_persson (n_upts), and

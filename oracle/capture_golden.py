@@ -102,6 +102,9 @@ CASES = [
     case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
     case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
     case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+    # over-integration of the inviscid flux (polynomial de-aliasing)
+    case("hex_p2_overint", amp=0.15, level=2, order=2, steps=1, over_int=1, over_int_order=6),
+    case("quad_p3_overint", dims=2, n=4, amp=0.1, level=2, order=3, steps=1, over_int=1, over_int_order=9),
     # shock capturing (Persson sensor + exponential modal filter after every RK stage); s0 sits in a gap of the
     # first stage's sensor distribution so that about a third of the elements are filtered
     case("hex_p3_shock", amp=0.15, level=1, order=3, steps=2, shock_cap=1, shock_det=0, s0=1.4e-7, expf_fac=36.0,

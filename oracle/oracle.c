@@ -9,6 +9,7 @@
 #include "oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <stddef.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -774,6 +775,47 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, con
 }
 
 /* ------------------------------------------------------------------------ */
+/* over-integration                                                          */
+
+/* src/eles.cpp:1480-1545 (BLAS=NO branch) */
+void orc_evaluate_invFlux_over_int(orc_eles *e, const orc_params *P, int nc, const double *opp, const double *filter,
+                                   const double *JGinv_cub)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields, nd = e->n_dims;
+  const long slab = (long)nu * ne;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < ne; i++)
+  {
+    double *ucub = (double *)malloc(sizeof(double) * nc * nf);
+    double *tcub = (double *)malloc(sizeof(double) * nc * nf * nd);
+    for (int k = 0; k < nf; k++) orc_dgemm(nc, 1, nu, 1.0, 0.0, opp, e->disu_upts[0] + (long)nu * i + k * slab, ucub + (long)nc * k);
+    for (int j = 0; j < nc; j++)
+    {
+      double u[MAXF], f[MAXF * MAXD];
+      for (int k = 0; k < nf; k++) u[k] = ucub[j + (long)nc * k];
+      orc_calc_invf(nd, P->gamma, u, f);
+      for (int k = 0; k < nf; k++)
+        for (int l = 0; l < nd; l++)
+        {
+          double t = 0.;
+          for (int m = 0; m < nd; m++) t += JGinv_cub[l + nd * (m + nd * (j + (long)nc * i))] * f[k + nf * m];
+          tcub[j + (long)nc * (k + nf * l)] = t;
+        }
+    }
+    for (int j = 0; j < nu; j++)
+      for (int k = 0; k < nf; k++)
+        for (int l = 0; l < nd; l++)
+        {
+          double t = 0.;
+          for (int m = 0; m < nc; m++) t += filter[j + (long)nu * m] * tcub[m + (long)nc * (k + nf * l)];
+          e->tdisf_upts[j + (long)nu * i + (k + (long)nf * l) * slab] = t;
+        }
+    free(ucub);
+    free(tcub);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
 /* shock capturing                                                           */
 
 /* eles::shock_capture (src/eles.cpp:2918-2959) with shock_det_persson (src/eles_hexas.cpp:1007-1059) */
@@ -1278,7 +1320,10 @@ long orc_CalcResidual_bdy(orc_eles *e, const orc_int_inters *faces, int n_face_b
 {
   orc_extrapolate_solution(e);
   if (P->viscous) orc_calculate_gradient(e);
-  orc_evaluate_invFlux(e, P);
+  if (e->n_cub > 0) /* src/solver.cpp:82-91 */
+    orc_evaluate_invFlux_over_int(e, P, e->n_cub, e->opp_over_int_cubpts, e->over_int_filter, e->JGinv_over_int_cubpts);
+  else
+    orc_evaluate_invFlux(e, P);
   for (int b = 0; b < n_face_blocks; b++) orc_int_calculate_common_invFlux(&faces[b], e, P);
   for (int b = 0; b < n_bdy_blocks; b++) orc_bdy_evaluate_boundaryConditions_invFlux(&bdy[b], e, P);
   if (P->viscous)

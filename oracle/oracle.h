@@ -64,6 +64,11 @@ typedef struct orc_eles
   double *grad_disu_fpts;  /* (n_fpts,n_eles,n_fields,n_dims) */
   const double *src_upts;  /* (n_upts,n_eles,n_fields) or NULL (= 0) */
   const double *dt_local;  /* (n_eles) or NULL */
+  /* over-integration (run_input.over_int): n_cub 0 = off */
+  int n_cub;
+  const double *opp_over_int_cubpts;   /* (n_cub,n_upts) */
+  const double *over_int_filter;       /* (n_upts,n_cub) */
+  const double *JGinv_over_int_cubpts; /* (n_dims,n_dims,n_cub,n_eles) */
 } orc_eles;
 
 /* interior faces (reference class int_inters): the hf_array<double*> tables of
@@ -167,6 +172,9 @@ void orc_int_calculate_common_invFlux(const orc_int_inters *f, orc_eles *e, cons
 void orc_int_calculate_common_viscFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p); /* :254 */
 
 /* partition faces: src/mpi_inters.cpp */
+/* eles::evaluate_invFlux_over_int (src/eles.cpp:1480-1545): opp (n_cub,n_upts), filter (n_upts,n_cub), JGinv (nd,nd,n_cub,n_eles) */
+void orc_evaluate_invFlux_over_int(orc_eles *e, const orc_params *p, int n_cub, const double *opp_over_int_cubpts,
+                                   const double *over_int_filter, const double *JGinv_over_int_cubpts);
 void orc_shock_capture(orc_eles *e, const orc_shock *s); /* eles::shock_capture, shock_cap 1 + shock_det 0 */
 
 /* boundary faces, src/bdy_inters.cpp (wall model, LES inlet, RANS off) */

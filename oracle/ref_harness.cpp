@@ -292,6 +292,14 @@ int main(int argc, char *argv[])
       put_scalar("ramp_counter", run_input.ramp_counter);
     }
   }
+  // over-integration (src/eles_hexas.cpp:1096-1129, src/eles.cpp:1480-1545)
+  if (run_input.over_int)
+  {
+    put_arr("opp_over_int_cubpts", E->opp_over_int_cubpts);
+    put_arr("over_int_filter", E->over_int_filter);
+    put_arr("JGinv_over_int_cubpts", E->JGinv_over_int_cubpts);
+    put_scalar("over_int", run_input.over_int);
+  }
   // shock capturing (src/eles.cpp:2918, src/eles_hexas.cpp:953-1059): the registered matrices and the set of
   // highest modes of the Persson sensor
   if (run_input.shock_cap)

@@ -28,7 +28,8 @@ class Eles(C.Structure):
         ("tdA_fpts", dp), ("norm_fpts", dp),
         ("disu_upts", dp * 2), ("disu_fpts", dp), ("tdisf_upts", dp), ("norm_tdisf_fpts", dp),
         ("norm_tconf_fpts", dp), ("div_tconf_upts", dp), ("delta_disu_fpts", dp),
-        ("grad_disu_upts", dp), ("grad_disu_fpts", dp), ("src_upts", dp), ("dt_local", dp)]
+        ("grad_disu_upts", dp), ("grad_disu_fpts", dp), ("src_upts", dp), ("dt_local", dp),
+        ("n_cub", C.c_int), ("opp_over_int_cubpts", dp), ("over_int_filter", dp), ("JGinv_over_int_cubpts", dp)]
 
 
 class IntInters(C.Structure):
@@ -143,6 +144,12 @@ class Case:
                 L = np.asfortranarray(np.array(data["int%d_L" % t], dtype=np.int32))
                 R = np.asfortranarray(np.array(data["int%d_R" % t], dtype=np.int32))
                 self.faces.append((L, R))
+        # over-integration
+        self.n_cub = 0
+        if "over_int" in data and int(np.ravel(data["over_int"])[0]):
+            for k in ("opp_over_int_cubpts", "over_int_filter", "JGinv_over_int_cubpts"):
+                self.arr[k] = g(k)
+            self.n_cub = self.arr["opp_over_int_cubpts"].shape[0]
         # shock capturing
         self.shock_cap = int(np.ravel(data["shock_cap"])[0]) if "shock_cap" in data else 0
         if self.shock_cap:
@@ -194,6 +201,10 @@ class Case:
                   "delta_disu_fpts", "grad_disu_upts", "grad_disu_fpts"):
             setattr(e, k, fptr(a[k]))
         e.disu_upts[0] = fptr(a["u0"]); e.disu_upts[1] = fptr(a["u1"])
+        e.n_cub = self.n_cub
+        if self.n_cub:
+            for k in ("opp_over_int_cubpts", "over_int_filter", "JGinv_over_int_cubpts"):
+                setattr(e, k, fptr(a[k]))
         self._e = e
         return e
 

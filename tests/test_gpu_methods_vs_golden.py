@@ -54,6 +54,8 @@ def build(ctx, d, mode=hfx.CONTRACT_AUTO):
             faces.append(hfx.BdyInters(ctx, e, d["bdy%d_L" % t], d["bdy%d_id" % t],
                                        hfx.bc_records(d["bc_flags"], d["bc_params"]),
                                        float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
+    if "over_int" in d and int(np.ravel(d["over_int"])[0]):
+        e.set_over_int(d["opp_over_int_cubpts"], d["over_int_filter"], d["JGinv_over_int_cubpts"])
     if "shock_cap" in d and int(np.ravel(d["shock_cap"])[0]):
         e.set_shock_capture(d["inv_vandermonde"], d["exp_filter"], d["norm_basis_persson"], d["persson_high_modes"],
                             float(np.ravel(d["s0"])[0]), int(np.ravel(d["shock_det_field"])[0]))
@@ -97,6 +99,18 @@ def test_every_intermediate(ctx, mode):
             got = e.compute_res_upts(nt, fld)
             want = d["s0_res_sums"][fld, nt - 1]
             assert abs(got - want) <= 1e-11 * abs(want)
+    for f in faces:
+        f.close()
+    e.close()
+
+
+@pytest.mark.parametrize("name", [n for n in ALL if "overint" in n])
+def test_over_integration_flux(ctx, name):
+    """eles::evaluate_invFlux_over_int through two dense FP64 MFMA contractions (n_cub = 343 / 100 columns)."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e, faces = build(ctx, d)
+    e.evaluate_invFlux_over_int()
+    assert relerr(e.download(hfx.TDISF_UPTS), d["s0_tdisf_upts_inv"]) < RTOL1
     for f in faces:
         f.close()
     e.close()

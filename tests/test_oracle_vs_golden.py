@@ -155,3 +155,15 @@ def test_boundary_intermediates(oracle, name):
         assert relerr(a["norm_tconf_fpts"], d["s0_norm_tconf_fpts"]) < 1e-12
     assert oracle.orc_calculate_corrected_divergence(E) == -1
     assert relerr(a["div_tconf_upts"], d["s0_div_tconf_upts"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", [n for n in ALL if "overint" in n])
+def test_over_integration_flux(oracle, name):
+    """eles::evaluate_invFlux_over_int: the de-aliased transformed inviscid flux at the solution points."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c = O.Case(d)
+    assert c.n_cub > c.n_upts
+    e = c.c_eles()
+    oracle.orc_evaluate_invFlux_over_int(C.byref(e), C.byref(c.params), C.c_int(c.n_cub), e.opp_over_int_cubpts,
+                                         e.over_int_filter, e.JGinv_over_int_cubpts)
+    assert relerr(c.arr["tdisf_upts"], d["s0_tdisf_upts_inv"]) < RTOL
