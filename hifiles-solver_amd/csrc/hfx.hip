@@ -447,6 +447,7 @@ int hfx_eles_destroy(hfx_eles *e)
     if (p) (void)hipFree(p);
   for (int i = 0; i < HFX_N_ARRAYS; i++)
     if (e->arr[i]) (void)hipFree(e->arr[i]);
+  if (e->h_ref) (void)hipFree(e->h_ref);
   if (e->nan_flag) (void)hipFree(e->nan_flag);
   if (e->red_buf) (void)hipFree(e->red_buf);
   fused_destroy(e);
@@ -729,6 +730,39 @@ int hfx_inters_destroy(hfx_inters *f)
   if (f->boundary_id) (void)hipFree(f->boundary_id);
   if (f->bcs) (void)hipFree(f->bcs);
   delete f;
+  return 0;
+}
+
+// ---- CFL time stepping --------------------------------------------------------------------
+int hfx_eles_set_h_ref(hfx_eles *e, const double *h_ref)
+{
+  HFX_CHECK(e && h_ref, "hfx_eles_set_h_ref: NULL argument");
+  if (e->h_ref) (void)hipFree(e->h_ref);
+  e->h_ref = nullptr;
+  return dev_alloc_copy(&e->h_ref, h_ref, e->n_eles);
+}
+
+int hfx_eles_calc_dt_local(hfx_eles *e, double CFL, double *dt_min)
+{
+  HFX_CHECK(e && dt_min, "hfx_eles_calc_dt_local: NULL argument");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  *dt_min = 1e12; /* src/solver.cpp:490 */
+  if (e->n_eles == 0) return 0;
+  HFX_CHECK(e->h_ref, "calc_dt_local: hfx_eles_set_h_ref was not called");
+  hipStream_t st = e->ctx->stream;
+  if (!e->arr[HFX_DT_LOCAL]) HFX_HIP(hipMalloc((void **)&e->arr[HFX_DT_LOCAL], sizeof(double) * (size_t)e->n_eles));
+  const double big = 1e12;
+  HFX_HIP(hipMemcpyAsync(e->red_buf, &big, sizeof(double), hipMemcpyHostToDevice, st));
+  const Phys P = e->ctx->phys();
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(dt_local_kernel<2>, dim3((unsigned)e->n_eles), dim3(64), 0, st, e->n_upts, (long)e->n_eles,
+                       e->arr[HFX_DISU_UPTS0], e->h_ref, P, CFL, e->order, e->arr[HFX_DT_LOCAL], (unsigned long long *)e->red_buf);
+  else
+    hipLaunchKernelGGL(dt_local_kernel<3>, dim3((unsigned)e->n_eles), dim3(64), 0, st, e->n_upts, (long)e->n_eles,
+                       e->arr[HFX_DISU_UPTS0], e->h_ref, P, CFL, e->order, e->arr[HFX_DT_LOCAL], (unsigned long long *)e->red_buf);
+  HFX_HIP(hipGetLastError());
+  HFX_HIP(hipMemcpyAsync(dt_min, e->red_buf, sizeof(double), hipMemcpyDeviceToHost, st));
+  HFX_HIP(hipStreamSynchronize(st));
   return 0;
 }
 

@@ -90,6 +90,7 @@ struct hfx_eles
   hfx_ctx *ctx = nullptr;
   int n_eles = 0, n_upts = 0, n_fpts = 0, n_fields = 0, n_dims = 0, ele_type = 0, order = 0;
   bool viscous_ops = false;
+  double *h_ref = nullptr; // (n_eles) eles::h_ref for calc_dt_local
   // over-integration (hfx_eles_set_over_int)
   bool over_int_ready = false;
   int n_cubpts = 0;

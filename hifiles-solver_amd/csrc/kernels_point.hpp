@@ -325,4 +325,53 @@ __global__ __launch_bounds__(PT_BLOCK) void shock_select_kernel(int n_upts, long
   for (int k = 0; k < n_fields; k++) u[p + k * plane] = filt[p + k * plane];
 }
 
+// ---- eles::calc_dt_local (src/eles.cpp:1267-1356) for every element + the minimum -----------
+// one 64-lane workgroup per element; dt_min accumulates through an atomic min on the bit pattern
+// (positive doubles order like unsigned integers)
+template <int ND>
+__global__ __launch_bounds__(64) void dt_local_kernel(int n_upts, long n_eles, const double *__restrict__ U,
+                                                      const double *__restrict__ h_ref, const Phys P, double CFL, int order,
+                                                      double *__restrict__ dt_local, unsigned long long *dt_min_bits)
+{
+  const long e = blockIdx.x;
+  if (e >= n_eles) return;
+  const long plane = (long)n_upts * n_eles;
+  double lam_inv = 0.0, lam_visc = 0.0;
+  for (int i = threadIdx.x; i < n_upts; i += 64)
+  {
+    const long p = i + (long)n_upts * e;
+    const double rho = U[p];
+    double vsq = 0.0;
+#pragma unroll
+    for (int d = 0; d < ND; d++)
+    {
+      const double v = U[p + (d + 1) * plane] / rho;
+      vsq += v * v;
+    }
+    const double pr = (P.gamma - 1.0) * (U[p + (ND + 1) * plane] - 0.5 * rho * vsq);
+    const double c = sqrt(P.gamma * pr / rho);
+    const double inte = pr / ((P.gamma - 1.0) * rho);
+    const double rt_ratio = (P.gamma - 1.0) * inte / (P.rt_inf);
+    double mu = (P.mu_inf) * pow(rt_ratio, 1.5) * (1. + (P.c_sth)) / (rt_ratio + (P.c_sth));
+    mu = mu + P.fix_vis * (P.mu_inf - mu);
+    lam_inv = fmax(lam_inv, sqrt(vsq) + c);
+    lam_visc = fmax(lam_visc, fmax(4.0 / 3.0, P.gamma / P.prandtl) * mu / rho);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    lam_inv = fmax(lam_inv, __shfl_down(lam_inv, off, 64));
+    lam_visc = fmax(lam_visc, __shfl_down(lam_visc, off, 64));
+  }
+  if (threadIdx.x == 0)
+  {
+    const double h = h_ref[e];
+    const double dt_visc = P.viscous ? (CFL * 0.25 * h * h) / (lam_visc) * 1.0 / (2.0 * order + 1.0) : 1e16;
+    const double dt_inv = CFL * h / lam_inv * 1.0 / (2.0 * order + 1.0);
+    const double dt = fmin(dt_visc, dt_inv);
+    dt_local[e] = dt;
+    atomicMin(dt_min_bits, (unsigned long long)__double_as_longlong(dt));
+  }
+}
+
 } // namespace hfx

@@ -204,6 +204,15 @@ class Eles:
 
     def shock_capture(self): self._call("hfx_eles_shock_capture")
 
+    def set_h_ref(self, h_ref):
+        h = np.ascontiguousarray(np.ravel(h_ref).astype(np.float64))
+        check(lib().hfx_eles_set_h_ref(self.h, h.ctypes.data_as(dp)))
+
+    def calc_dt_local(self, CFL):
+        v = C.c_double(0)
+        check(lib().hfx_eles_calc_dt_local(self.h, C.c_double(CFL), C.byref(v)))
+        return v.value
+
     def set_over_int(self, opp_over_int_cubpts, over_int_filter, JGinv_over_int_cubpts):
         a, b, c = _f(opp_over_int_cubpts), _f(over_int_filter), _f(JGinv_over_int_cubpts)
         assert a.shape == (b.shape[1], self.n_upts) and b.shape[0] == self.n_upts

@@ -172,6 +172,13 @@ int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
 
+/* ---- CFL time stepping (calc_time_step, src/solver.cpp:484-549) ---------- */
+int hfx_eles_set_h_ref(hfx_eles *e, const double *h_ref); /* eles::h_ref (n_eles), src/eles.cpp:3985 */
+/* dt_local(ic) = eles::calc_dt_local(ic) (src/eles.cpp:1267-1356) for every element -> HFX_DT_LOCAL, and the
+ * block's minimum.  dt_type 1: the caller takes the minimum over blocks and ranks (all-reduce MIN) and sets
+ * hfx_params.dt; dt_type 2: AdvanceSolution reads HFX_DT_LOCAL. */
+int hfx_eles_calc_dt_local(hfx_eles *e, double CFL, double *dt_min);
+
 /* ---- over-integration (row a5) ------------------------------------------- */
 /* Registers what eles_hexas::set_over_int (src/eles_hexas.cpp:1096-1129) and set_transforms build when
  * run_input.over_int == 1: opp_over_int_cubpts (n_cubpts,n_upts), over_int_filter (n_upts,n_cubpts),

@@ -342,6 +342,23 @@ int main(int argc, char *argv[])
   for (int step = 0; step < n_steps; step++)
   {
     calc_time_step(&FlowSol);
+    if (run_input.dt_type != 0)
+    {
+      // CFL time stepping (src/solver.cpp:484-549, src/eles.cpp:1267-1356)
+      char nm[64];
+      snprintf(nm, sizeof nm, "dt_step%d", step);
+      put_scalar(nm, run_input.dt);
+      if (step == 0)
+      {
+        put_arr("h_ref", E->h_ref);
+        put_scalar("CFL", run_input.CFL);
+      }
+      if (run_input.dt_type == 2)
+      {
+        snprintf(nm, sizeof nm, "dt_local_step%d", step);
+        put_arr(nm, E->dt_local);
+      }
+    }
     for (int rk = 0; rk < RKSteps; rk++)
     {
       if (step == 0 && rk == 0 && level >= 1)

@@ -160,7 +160,20 @@ def test_stage_states_vs_reference(ctx, name):
     nstage = int(d["sizes"][7])
     adv = int(np.ravel(d["adv_type"])[0])
     steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
+    dt_type = int(np.ravel(d["dt_type"])[0])
+    if dt_type != 0:
+        e.set_h_ref(d["h_ref"])
     for st in steps:
+        if dt_type != 0:
+            # calc_time_step (src/solver.cpp:484-549) on the device
+            dt = e.calc_dt_local(float(np.ravel(d["CFL"])[0]))
+            want = float(np.ravel(d["dt_step%d" % st])[0])
+            assert abs(dt - want) <= 1e-11 * want
+            if dt_type == 2:
+                assert relerr(e.download(hfx.DT_LOCAL), np.ravel(d["dt_local_step%d" % st])) < 1e-11
+            p = hfx.params_from(d)
+            p.dt = dt
+            ctx.set_params(p)
         for rk in range(nstage):
             hfx.CalcResidual(e, faces)
             if st == 0 and rk == 0:

@@ -44,7 +44,19 @@ def test_stage_states(oracle, name):
     sh = c.c_shock() if c.shock_cap else None
     nstage = int(d["sizes"][7])
     steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
+    dt_type = int(np.ravel(d["dt_type"])[0])
+    dtl = None
     for st in steps:
+        if dt_type != 0:
+            # calc_time_step (src/solver.cpp:484-549): per-element CFL step, global minimum
+            CFL, order = float(np.ravel(d["CFL"])[0]), int(d["sizes"][5])
+            h = np.ravel(d["h_ref"])
+            dtl = np.array([oracle.orc_calc_dt_local(C.byref(e), C.byref(c.params), i, h[i], CFL, order) for i in range(c.n_eles)])
+            assert abs(dtl.min() - float(np.ravel(d["dt_step%d" % st])[0])) <= 1e-13 * dtl.min()
+            c.params.dt = dtl.min()
+            if dt_type == 2:
+                assert relerr(dtl, np.ravel(d["dt_local_step%d" % st])) < 1e-13
+                e.dt_local = dtl.ctypes.data_as(O.dp)
         for rk in range(nstage):
             bad = oracle.orc_CalcResidual_bdy(C.byref(e), f, nfb, bd, nbd, C.byref(c.params))
             assert bad == -1
