@@ -31,7 +31,7 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
   in.equation = 0;
   in.viscous = d->viscous; in.order = d->order;
   in.riemann_solve_type = d->riemann_solve_type; in.vis_riemann_solve_type = 0;
-  in.ic_form = d->ic_form; in.adv_type = d->adv_type; in.dt_type = 0; in.dt = d->dt;
+  in.ic_form = d->ic_form; in.adv_type = d->adv_type; in.dt_type = d->dt_type; in.dt = d->dt; in.CFL = d->CFL;
   in.ldg_tau = d->ldg_tau; in.ldg_beta = d->ldg_beta;
   in.upts_type_hexa = in.upts_type_quad = d->upts_type;
   in.vcjh_scheme_hexa = in.vcjh_scheme_quad = d->vcjh_scheme;
@@ -249,6 +249,13 @@ extern "C" int hfxh_case_CalcResidual(hfxh_case *c)
 extern "C" int hfxh_case_run(hfxh_case *c, int n_steps)
 {
   if (RunSteps(&c->S, n_steps)) { g_err = c->S.err; return 1; }
+  return 0;
+}
+
+extern "C" int hfxh_case_calc_time_step(hfxh_case *c, double *dt)
+{
+  if (calc_time_step(&c->S)) { g_err = c->S.err; return 1; }
+  *dt = c->S.run_input.dt;
   return 0;
 }
 

@@ -370,6 +370,7 @@ int eles::mv_all_cpu_gpu(hfx_ctx *ctx)
       fail(hfx_last_error());
       return 1;
     }
+  if (hfx_eles_set_h_ref(dev, h_ref.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
   return 0;
 }
 

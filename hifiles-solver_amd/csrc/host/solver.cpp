@@ -161,14 +161,23 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
             }
       }
   if (E->set_transforms()) { S->err = E->last_error(); return 1; }
-  // reference length for CFL time stepping: shortest edge through the element centre is not
-  // needed by the fixed-dt configurations; use the cube root / square root of the volume
-  for (int e = 0; e < E->n_eles; e++)
+  // reference length for CFL time stepping = the shortest edge of the (linear) element
+  // (eles_hexas::calc_h_ref_specific src/eles_hexas.cpp:1551-1571, eles_quads:: src/eles_quads.cpp:1287-1301)
   {
-    double vol = 0.0;
-    for (int j = 0; j < E->n_upts_per_ele; j++) vol += E->detjac_upts(j, e);
-    vol *= std::pow(2.0, dims) / E->n_upts_per_ele;
-    E->h_ref(e) = (dims == 3) ? std::cbrt(vol) : std::sqrt(vol);
+    static const int hex_edge[12][2] = {{0, 1}, {1, 3}, {3, 2}, {2, 0}, {4, 5}, {5, 7}, {7, 6}, {6, 4}, {1, 5}, {3, 7}, {0, 4}, {2, 6}};
+    const int n_edges = (dims == 3) ? 12 : 4;
+    for (int e = 0; e < E->n_eles; e++)
+    {
+      double hmin = 0.0;
+      for (int q = 0; q < n_edges; q++)
+      {
+        double l2 = 0.0;
+        for (int d = 0; d < dims; d++) l2 += std::pow(E->shape(d, hex_edge[q][0], e) - E->shape(d, hex_edge[q][1], e), 2.0);
+        const double l = std::sqrt(l2);
+        if (q == 0 || l < hmin) hmin = l;
+      }
+      E->h_ref(e) = hmin;
+    }
   }
 
   // interior faces.  Same numbering and left/right orientation as the reference derives from the
@@ -394,11 +403,33 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   each_ele(&eles::calculate_corrected_divergence);
 }
 
+// calc_time_step (src/solver.cpp:484-549): per-element CFL steps on the device, minimum over blocks and ranks
+int calc_time_step(solution *FlowSol)
+{
+  input &in = FlowSol->run_input;
+  if (in.dt_type != 1 && in.dt_type != 2) return 0;
+  double dt_min = 1e12;
+  for (int j = 0; j < FlowSol->n_ele_types; j++)
+    if (FlowSol->mesh_eles(j) && FlowSol->mesh_eles(j)->get_n_eles() != 0)
+    {
+      double v = 0.0;
+      if (hfx_eles_calc_dt_local(FlowSol->mesh_eles(j)->device(), in.CFL, &v)) { FlowSol->err = hfx_last_error(); return 1; }
+      if (v < dt_min) dt_min = v;
+    }
+  if (FlowSol->nproc > 1 && FlowSol->reduce_min) dt_min = FlowSol->reduce_min(FlowSol->exchange_user, dt_min); // MPI_Allreduce MIN
+  in.dt = dt_min;
+  hfx_params p;
+  in.fill(p);
+  if (hfx_ctx_set_params(FlowSol->ctx, &p)) { FlowSol->err = hfx_last_error(); return 1; }
+  return 0;
+}
+
 int RunSteps(solution *FlowSol, int n_steps)
 {
   const int RKSteps = FlowSol->run_input.n_rk_stages();
   for (int i_steps = 0; i_steps < n_steps; i_steps++)
   {
+    if (calc_time_step(FlowSol)) return 1; /* src/HiFiLES.cpp:198 */
     for (int i = 0; i < RKSteps; i++)
     {
       CalcResidual(FlowSol->ini_iter + i_steps, i, FlowSol);

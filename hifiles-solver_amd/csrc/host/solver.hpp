@@ -32,6 +32,7 @@ struct solution
   hfx_ctx *ctx = nullptr;
   hfxh_exchange_fn exchange = nullptr;
   void *exchange_user = nullptr;
+  double (*reduce_min)(void *user, double v) = nullptr; // MPI_Allreduce(MIN) of calc_time_step, supplied by the caller
   std::string err;
   ~solution();
 };
@@ -67,6 +68,7 @@ int MoveToDevice(solution *FlowSol, int device);
 
 void CalcResidual(int in_file_num, int in_rk_stage, solution *FlowSol);
 // RK loop of src/HiFiLES.cpp:194-221 through the mirrored class methods
+int calc_time_step(solution *FlowSol); // src/solver.cpp:484-549
 int RunSteps(solution *FlowSol, int n_steps);
 // the same RK loop through the split fused kernels on a partitioned block, exchanging between the
 // phases of hfx_stage_partitioned

@@ -24,7 +24,8 @@ class CaseDesc(C.Structure):
                                           "Mach_free_stream", "rho_free_stream", "L_free_stream", "T_free_stream",
                                           "rho_c_ic", "Mach_c_ic", "T_c_ic", "u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic")] + \
                [("rank", C.c_int), ("nproc", C.c_int), ("pgrid", C.c_int * 3),
-                ("n_bcs", C.c_int), ("bcs", C.c_void_p), ("side_bc", C.c_int * 6)]
+                ("n_bcs", C.c_int), ("bcs", C.c_void_p), ("side_bc", C.c_int * 6),
+                ("dt_type", C.c_int), ("CFL", C.c_double)]
 
 
 class BcDesc(C.Structure):
@@ -255,6 +256,11 @@ class Case:
     def stream(self):
         ctx, e, f, nb = self.handles()
         return hfx.lib().hfx_ctx_stream(ctx)
+
+    def calc_time_step(self):
+        v = C.c_double(0)
+        check(lib().hfxh_case_calc_time_step(self.h, C.byref(v)))
+        return v.value
 
     def sync_host(self):
         check(lib().hfxh_case_sync_host(self.h))

@@ -61,6 +61,9 @@ typedef struct hfxh_case_desc
   int n_bcs;
   const hfxh_bc_desc *bcs;
   int side_bc[6];
+  /* time step: dt_type 0 fixed `dt`, 1 global CFL minimum, 2 local CFL steps (src/input.cpp:141-158) */
+  int dt_type;
+  double CFL;
 } hfxh_case_desc;
 
 const char *hfxh_last_error(void);
@@ -97,6 +100,8 @@ int hfxh_case_run(hfxh_case *c, int n_steps); /* the mirrored RK loop (src/HiFiL
 int hfxh_case_mpi_handle(hfxh_case *c, hfx_inters **f);
 /* the RK loop through hfx_stage_partitioned (split fused kernels), exchanging between its phases */
 int hfxh_case_run_partitioned(hfxh_case *c, int n_steps);
+/* calc_time_step (src/solver.cpp:484-549) on the device; hfxh_case_run calls it before every step */
+int hfxh_case_calc_time_step(hfxh_case *c, double *dt);
 int hfxh_case_sync_host(hfxh_case *c);        /* cp_*_gpu_cpu of state, divergence, gradient */
 
 #ifdef __cplusplus

@@ -170,3 +170,19 @@ def test_boundary_case_through_the_mirror(name, mode):
     last = int(d["sizes"][7]) - 1
     assert rel(c.array("disu_upts0"), d["u_step0_stage%d" % last]) < 1e-11
     c.close()
+
+
+@pytest.mark.parametrize("name,dt_type", [("hex_p2_cfl_global", 1), ("hex_p2_cfl_local", 2)])
+def test_cfl_time_stepping_through_the_mirror(name, dt_type):
+    """calc_time_step on the device inside the mirrored RK loop (dt_type 1: global minimum, 2: local steps)."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    k = json.loads(bytes(d["meta_json"]).decode())["keys"]
+    c = H.Case(3, xv=d["xv"], order=2, dt_type=dt_type, CFL=k["CFL"], adv_type=k["adv_type"], dt=0.0)
+    c.to_device(0)
+    dt = c.calc_time_step()
+    assert abs(dt - float(np.ravel(d["dt_step0"])[0])) < 1e-11 * dt
+    c.run(2)
+    c.sync_host()
+    last = int(d["sizes"][7]) - 1
+    assert rel(c.array("disu_upts0"), d["u_step1_stage%d" % last]) < 1e-11
+    c.close()

@@ -123,3 +123,11 @@ def test_boundary_tables_vs_reference(name):
     assert rc == int(np.ravel(d["ramp_counter"])[0])
     assert rel(c.array("disu_upts0"), d["u_init"]) < 1e-14
     c.close()
+
+
+def test_h_ref_vs_reference():
+    """eles::h_ref = shortest element edge (calc_h_ref_specific), the length scale of the CFL time step."""
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p2_cfl_global.npz")))
+    c = H.Case(3, xv=d["xv"], order=2, dt_type=1, CFL=0.4)
+    assert rel(c.array("h_ref"), np.ravel(d["h_ref"])) < 1e-15
+    c.close()
