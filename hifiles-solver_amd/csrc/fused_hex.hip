@@ -2346,6 +2346,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
   }
 }
 
+
 struct Split2FaceArgs
 {
   long npairs;
@@ -2504,7 +2505,8 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   hipStream_t st = e->ctx->stream;
   const Phys P = e->ctx->phys();
   const long plane_f = (long)e->n_fpts * e->n_eles;
-  const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * 16);
+  static const int grid_per_cu = getenv("HFX_SPLIT_GRID_PER_CU") ? std::max(1, atoi(getenv("HFX_SPLIT_GRID_PER_CU"))) : 16;
+  const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * grid_per_cu);
   auto face_args = [&](hfx_inters *f) {
     SplitFaceArgs a{};
     a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
