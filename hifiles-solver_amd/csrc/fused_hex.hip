@@ -2254,7 +2254,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     }
     if (is_u)
     {
-      double tfl[NG];
+      // the transformed flux is accumulated in this thread's own st column (LDS) instead of 15 registers
       {
         double f[NG];
         calc_invf<ND, true>(a.P.gamma, u, f);
@@ -2266,7 +2266,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
             double s = 0.0;
 #pragma unroll
             for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-            tfl[k + NF * l] = s;
+            st[(k + NF * l) * NU + tu] = s;
           }
       }
       if (viscous)
@@ -2291,14 +2291,12 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 #pragma unroll
           for (int l = 0; l < ND; l++)
           {
-            double s = tfl[k + NF * l];
+            double s = ldsv(&st[(k + NF * l) * NU + tu]);
 #pragma unroll
             for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-            tfl[k + NF * l] = s;
+            st[(k + NF * l) * NU + tu] = s;
           }
       }
-#pragma unroll
-      for (int q = 0; q < NG; q++) st[q * NU + tu] = tfl[q];
     }
     lds_barrier(); // st complete; sg is dead: its region takes the divergence parts
 
