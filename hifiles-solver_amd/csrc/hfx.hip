@@ -434,6 +434,9 @@ int hfx_eles_destroy(hfx_eles *e)
   free_operator(e->opp_0); free_operator(e->opp_3); free_operator(e->opp_6);
   free_operator(e->inv_vandermonde); free_operator(e->exp_filter);
   free_operator(e->opp_over_int_cubpts); free_operator(e->over_int_filter);
+  free_operator(e->opp_volume_cubpts);
+  for (double *p : {e->weight_volume_cubpts, e->vol_detjac_vol_cubpts, e->iq_u, e->iq_g})
+    if (p) (void)hipFree(p);
   for (double *p : {e->JGinv_over_int_cubpts, e->u_cub, e->t_cub})
     if (p) (void)hipFree(p);
   if (e->persson_num) (void)hipFree(e->persson_num);
@@ -730,6 +733,69 @@ int hfx_inters_destroy(hfx_inters *f)
   if (f->boundary_id) (void)hipFree(f->boundary_id);
   if (f->bcs) (void)hipFree(f->bcs);
   delete f;
+  return 0;
+}
+
+// ---- integral diagnostics -------------------------------------------------------------------
+int hfx_eles_set_volume_cubpts(hfx_eles *e, int n_cubpts, const double *opp_volume_cubpts, const double *weight_volume_cubpts,
+                               const double *vol_detjac_vol_cubpts)
+{
+  HFX_CHECK(e && opp_volume_cubpts && weight_volume_cubpts && vol_detjac_vol_cubpts && n_cubpts > 0,
+            "hfx_eles_set_volume_cubpts: bad argument");
+  free_operator(e->opp_volume_cubpts);
+  for (double **p : {&e->weight_volume_cubpts, &e->vol_detjac_vol_cubpts, &e->iq_u, &e->iq_g})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  e->n_vol_cubpts = n_cubpts;
+  if (make_operator(e->opp_volume_cubpts, opp_volume_cubpts, n_cubpts, e->n_upts)) return 1;
+  if (dev_alloc_copy(&e->weight_volume_cubpts, weight_volume_cubpts, n_cubpts)) return 1;
+  if (dev_alloc_copy(&e->vol_detjac_vol_cubpts, vol_detjac_vol_cubpts, (long)n_cubpts * e->n_eles)) return 1;
+  return 0;
+}
+
+int hfx_eles_CalcIntegralQuantities(hfx_eles *e, int n_q, const int *quantity_ids, double *integral_quantities)
+{
+  HFX_CHECK(e && quantity_ids && integral_quantities, "hfx_eles_CalcIntegralQuantities: NULL argument");
+  HFX_CHECK(n_q >= 0 && n_q <= IQ_MAX, "hfx_eles_CalcIntegralQuantities: at most %d quantities per call", IQ_MAX);
+  if (e->n_eles == 0 || n_q == 0) return 0;
+  HFX_CHECK(e->opp_volume_cubpts.dense, "CalcIntegralQuantities: hfx_eles_set_volume_cubpts was not called");
+  HFX_CHECK(e->ctx->have_params, "parameters not set");
+  for (int m = 0; m < n_q; m++)
+    HFX_CHECK(quantity_ids[m] >= 0 && quantity_ids[m] <= 4, "integral diagnostic quantity not recognized"); /* src/eles.cpp:5618 */
+  hfx_ctx *ctx = e->ctx;
+  hipStream_t st = ctx->stream;
+  const int nc = e->n_vol_cubpts;
+  const long pc = (long)nc * e->n_eles;
+  if (!e->iq_u) HFX_HIP(hipMalloc((void **)&e->iq_u, sizeof(double) * (size_t)pc * e->n_fields));
+  if (!e->iq_g) HFX_HIP(hipMalloc((void **)&e->iq_g, sizeof(double) * (size_t)pc * e->n_fields * e->n_dims));
+  // state and corrected gradient at the cubature points: dense contractions
+  {
+    const Operator *ops[1] = {&e->opp_volume_cubpts};
+    const double *in[1] = {e->arr[HFX_DISU_UPTS0]};
+    if (contract_multi_in(ctx, ops, 1, in, e->iq_u, (long)e->n_eles * e->n_fields, 0)) return 1;
+    in[0] = e->arr[HFX_GRAD_DISU_UPTS];
+    if (contract_multi_in(ctx, ops, 1, in, e->iq_g, (long)e->n_eles * e->n_fields * e->n_dims, 0)) return 1;
+  }
+  const int nblk = (int)std::min<long>(e->red_blocks / IQ_MAX, nblocks(pc, PT_BLOCK));
+  int *d_ids = nullptr;
+  HFX_HIP(hipMalloc((void **)&d_ids, sizeof(int) * IQ_MAX));
+  HFX_HIP(hipMemcpyAsync(d_ids, quantity_ids, sizeof(int) * n_q, hipMemcpyHostToDevice, st));
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(integral_quantities_kernel<2>, dim3(nblk), dim3(PT_BLOCK), 0, st, nc, (long)e->n_eles, e->iq_u, e->iq_g,
+                       e->weight_volume_cubpts, e->vol_detjac_vol_cubpts, ctx->params.gamma, n_q, d_ids, e->red_buf);
+  else
+    hipLaunchKernelGGL(integral_quantities_kernel<3>, dim3(nblk), dim3(PT_BLOCK), 0, st, nc, (long)e->n_eles, e->iq_u, e->iq_g,
+                       e->weight_volume_cubpts, e->vol_detjac_vol_cubpts, ctx->params.gamma, n_q, d_ids, e->red_buf);
+  HFX_HIP(hipGetLastError());
+  std::vector<double> part((size_t)nblk * n_q);
+  HFX_HIP(hipMemcpyAsync(part.data(), e->red_buf, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+  HFX_HIP(hipStreamSynchronize(st));
+  (void)hipFree(d_ids);
+  for (int m = 0; m < n_q; m++)
+  {
+    double s = 0.0;
+    for (int b = 0; b < nblk; b++) s += part[b + (size_t)nblk * m];
+    integral_quantities[m] += s; /* the reference accumulates over element classes (src/output.cpp:2023-2028) */
+  }
   return 0;
 }
 

@@ -91,6 +91,10 @@ struct hfx_eles
   int n_eles = 0, n_upts = 0, n_fpts = 0, n_fields = 0, n_dims = 0, ele_type = 0, order = 0;
   bool viscous_ops = false;
   double *h_ref = nullptr; // (n_eles) eles::h_ref for calc_dt_local
+  // integral diagnostics (hfx_eles_set_volume_cubpts)
+  int n_vol_cubpts = 0;
+  hfx::Operator opp_volume_cubpts;
+  double *weight_volume_cubpts = nullptr, *vol_detjac_vol_cubpts = nullptr, *iq_u = nullptr, *iq_g = nullptr;
   // over-integration (hfx_eles_set_over_int)
   bool over_int_ready = false;
   int n_cubpts = 0;

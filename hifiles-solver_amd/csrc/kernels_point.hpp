@@ -374,4 +374,97 @@ __global__ __launch_bounds__(64) void dt_local_kernel(int n_upts, long n_eles, c
   }
 }
 
+// ---- eles::CalcIntegralQuantities (src/eles.cpp:5485-5627) -----------------------------------
+// pointwise diagnostics at the volume cubature points (state and gradient already interpolated
+// there), weighted and reduced to one partial per workgroup per quantity (fixed tree; the host
+// adds the partials in block order)
+constexpr int IQ_MAX = 8;
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void integral_quantities_kernel(int n_cub, long n_eles, const double *__restrict__ Uc,
+                                                                       const double *__restrict__ Gc,
+                                                                       const double *__restrict__ wgt,
+                                                                       const double *__restrict__ vdj, double gamma, int nq,
+                                                                       const int *__restrict__ ids, double *partial)
+{
+  constexpr int NF = ND + 2;
+  __shared__ double sm[PT_BLOCK];
+  const long plane = (long)n_cub * n_eles;
+  double acc[IQ_MAX];
+#pragma unroll
+  for (int m = 0; m < IQ_MAX; m++) acc[m] = 0.0;
+  for (long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x; p < plane; p += (long)gridDim.x * PT_BLOCK)
+  {
+    double u[NF], g[NF * ND];
+#pragma unroll
+    for (int k = 0; k < NF; k++) u[k] = Uc[p + k * plane];
+#pragma unroll
+    for (int q = 0; q < NF * ND; q++) g[q] = Gc[p + q * plane];
+    const double irho = 1. / u[0];
+    double dv[ND][ND]; // dv[i][j] = d u_i / d x_j
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++) dv[i][j] = irho * (g[(i + 1) + NF * j] - u[i + 1] * irho * g[0 + NF * j]);
+    double tke = 0.0;
+#pragma unroll
+    for (int n = 1; n < ND + 1; n++) tke += 0.5 * u[n] * u[n];
+    const double w = wgt[p % n_cub] * vdj[p];
+    for (int m = 0; m < nq; m++)
+    {
+      double diagnostic = 0.0;
+      const int id = ids[m];
+      if (id == 0)
+        diagnostic = irho * tke;
+      else if (id == 1)
+      {
+        const double wz = dv[1][0] - dv[0][1];
+        diagnostic = wz * wz;
+        if (ND == 3)
+        {
+          const double wx = dv[ND - 1][1] - dv[1][ND - 1], wy = dv[0][ND - 1] - dv[ND - 1][0];
+          diagnostic += wx * wx + wy * wy;
+        }
+        diagnostic *= 0.5 / irho;
+      }
+      else if (id == 2)
+      {
+        const double pressure = (gamma - 1.0) * (u[ND + 1] - irho * tke);
+        double dil = dv[0][0] + dv[1][1];
+        if (ND == 3) dil = dil + dv[ND - 1][ND - 1];
+        diagnostic = pressure * dil;
+      }
+      else
+      {
+        double S[ND][ND];
+#pragma unroll
+        for (int a = 0; a < ND; a++)
+#pragma unroll
+          for (int b = 0; b < ND; b++) S[a][b] = (a == b) ? dv[a][a] : (dv[a][b] + dv[b][a]) / 2.0;
+        double diag = (S[0][0] + S[1][1]) / 3.0;
+        if (ND == 3) diag += S[ND - 1][ND - 1] / 3.0;
+        if (id == 4)
+#pragma unroll
+          for (int a = 0; a < ND; a++) S[a][a] -= diag;
+#pragma unroll
+        for (int a = 0; a < ND; a++)
+#pragma unroll
+          for (int b = 0; b < ND; b++) diagnostic += S[a][b] * S[a][b];
+      }
+      acc[m] += diagnostic * w;
+    }
+  }
+  for (int m = 0; m < nq; m++)
+  {
+    sm[threadIdx.x] = acc[m];
+    __syncthreads();
+    for (int s = PT_BLOCK / 2; s > 0; s >>= 1)
+    {
+      if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x + (long)gridDim.x * m] = sm[0];
+    __syncthreads();
+  }
+}
+
 } // namespace hfx

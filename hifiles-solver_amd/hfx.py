@@ -204,6 +204,18 @@ class Eles:
 
     def shock_capture(self): self._call("hfx_eles_shock_capture")
 
+    def set_volume_cubpts(self, opp_volume_cubpts, weight_volume_cubpts, vol_detjac_vol_cubpts):
+        a, d = _f(opp_volume_cubpts), _f(vol_detjac_vol_cubpts)
+        w = np.ascontiguousarray(np.ravel(weight_volume_cubpts).astype(np.float64))
+        check(lib().hfx_eles_set_volume_cubpts(self.h, C.c_int(a.shape[0]), a.ctypes.data_as(dp), w.ctypes.data_as(dp),
+                                               d.ctypes.data_as(dp)))
+
+    def CalcIntegralQuantities(self, ids):
+        ids = np.ascontiguousarray(np.array(ids, dtype=np.int32))
+        out = np.zeros(len(ids))
+        check(lib().hfx_eles_CalcIntegralQuantities(self.h, C.c_int(len(ids)), ids.ctypes.data_as(ip), out.ctypes.data_as(dp)))
+        return out
+
     def set_h_ref(self, h_ref):
         h = np.ascontiguousarray(np.ravel(h_ref).astype(np.float64))
         check(lib().hfx_eles_set_h_ref(self.h, h.ctypes.data_as(dp)))

@@ -172,6 +172,18 @@ int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
 
+/* ---- integral diagnostics (8f-1: the TGV monitors) ------------------------ */
+/* opp_volume_cubpts (n_cubpts,n_upts), weight_volume_cubpts (n_cubpts), vol_detjac_vol_cubpts (n_cubpts,n_eles):
+ * what eles::set_opp_volume_cubpts / set_transforms_vol_cubpts build when n_integral_quantities != 0
+ * (src/eles.cpp:3667,4027) */
+int hfx_eles_set_volume_cubpts(hfx_eles *e, int n_cubpts, const double *opp_volume_cubpts, const double *weight_volume_cubpts,
+                               const double *vol_detjac_vol_cubpts);
+/* eles::CalcIntegralQuantities (src/eles.cpp:5485-5627): integral_quantities[m] += this block's integral of
+ * quantity quantity_ids[m] (0 kineticenergy, 1 enstropy, 2 pressuredilatation, 3 straincolonproduct,
+ * 4 devstraincolonproduct) from disu_upts(0) and grad_disu_upts (the corrected gradient of the last
+ * per-method / fused-mode-2 stage).  The caller adds over blocks and ranks (src/output.cpp:2017-2050). */
+int hfx_eles_CalcIntegralQuantities(hfx_eles *e, int n_quantities, const int *quantity_ids, double *integral_quantities);
+
 /* ---- CFL time stepping (calc_time_step, src/solver.cpp:484-549) ---------- */
 int hfx_eles_set_h_ref(hfx_eles *e, const double *h_ref); /* eles::h_ref (n_eles), src/eles.cpp:3985 */
 /* dt_local(ic) = eles::calc_dt_local(ic) (src/eles.cpp:1267-1356) for every element -> HFX_DT_LOCAL, and the

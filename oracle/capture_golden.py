@@ -102,6 +102,11 @@ CASES = [
     case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
     case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
     case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+    # integral diagnostics of the TGV monitors (kinetic energy, enstrophy, ...)
+    case("hex_p2_integrals", amp=0.15, level=1, order=2, steps=1,
+         integral_quantities="5 kineticenergy enstropy pressuredilatation straincolonproduct devstraincolonproduct"),
+    case("quad_p3_integrals", dims=2, n=4, amp=0.1, level=1, order=3, steps=1,
+         integral_quantities="3 enstropy kineticenergy devstraincolonproduct"),
     # CFL time stepping: global minimum (dt_type 1) and local (dt_type 2)
     case("hex_p2_cfl_global", amp=0.15, level=1, order=2, steps=2, dt_type=1, CFL=0.4),
     case("hex_p2_cfl_local", amp=0.15, level=1, order=2, steps=2, dt_type=2, CFL=0.4, adv_type=0),

@@ -775,6 +775,103 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, con
 }
 
 /* ------------------------------------------------------------------------ */
+/* integral diagnostics                                                      */
+
+/* src/eles.cpp:5485-5627 ; vol_detjac (n_cub,n_eles) */
+void orc_CalcIntegralQuantities(const orc_eles *e, const orc_params *P, int nc, const double *opp, const double *wgt,
+                                const double *vdj, int nq, const int *ids, double *out)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields, nd = e->n_dims;
+  const long slab = (long)nu * ne;
+  const double *U = e->disu_upts[0], *G = e->grad_disu_upts;
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j < nc; j++)
+    {
+      const double detjac = vdj[j + (long)nc * i];
+      double u[MAXF], g[MAXF * MAXD];
+      for (int m = 0; m < nf; m++)
+      {
+        u[m] = 0.;
+        for (int k = 0; k < nu; k++) u[m] += opp[j + (long)nc * k] * U[k + (long)nu * i + m * slab];
+      }
+      for (int m = 0; m < nf; m++)
+        for (int n = 0; n < nd; n++)
+        {
+          double s = 0.;
+          for (int k = 0; k < nu; k++) s += opp[j + (long)nc * k] * G[k + (long)nu * i + (m + (long)nf * n) * slab];
+          g[m + nf * n] = s;
+        }
+#define GD(m, n) g[(m) + nf * (n)]
+      const double irho = 1. / u[0];
+      double dudx, dudy, dudz = 0, dvdx, dvdy, dvdz = 0, dwdx = 0, dwdy = 0, dwdz = 0;
+      dudx = irho * (GD(1, 0) - u[1] * irho * GD(0, 0));
+      dudy = irho * (GD(1, 1) - u[1] * irho * GD(0, 1));
+      dvdx = irho * (GD(2, 0) - u[2] * irho * GD(0, 0));
+      dvdy = irho * (GD(2, 1) - u[2] * irho * GD(0, 1));
+      if (nd == 3)
+      {
+        dudz = irho * (GD(1, 2) - u[1] * irho * GD(0, 2));
+        dvdz = irho * (GD(2, 2) - u[2] * irho * GD(0, 2));
+        dwdx = irho * (GD(3, 0) - u[3] * irho * GD(0, 0));
+        dwdy = irho * (GD(3, 1) - u[3] * irho * GD(0, 1));
+        dwdz = irho * (GD(3, 2) - u[3] * irho * GD(0, 2));
+      }
+#undef GD
+      for (int m = 0; m < nq; ++m)
+      {
+        double diagnostic = 0.0;
+        if (ids[m] == 0)
+        {
+          double tke = 0.0;
+          for (int n = 1; n < nd + 1; n++) tke += 0.5 * u[n] * u[n];
+          diagnostic = irho * tke;
+        }
+        else if (ids[m] == 1)
+        {
+          const double wz = dvdx - dudy;
+          diagnostic = wz * wz;
+          if (nd == 3)
+          {
+            const double wx = dwdy - dvdz, wy = dudz - dwdx;
+            diagnostic += wx * wx + wy * wy;
+          }
+          diagnostic *= 0.5 / irho;
+        }
+        else if (ids[m] == 2)
+        {
+          double tke = 0.0;
+          for (int n = 1; n < nd + 1; n++) tke += 0.5 * u[n] * u[n];
+          const double pressure = (P->gamma - 1.0) * (u[nd + 1] - irho * tke);
+          diagnostic = (nd == 2) ? pressure * (dudx + dvdy) : pressure * (dudx + dvdy + dwdz);
+        }
+        else
+        {
+          double S[3][3] = {{0}};
+          S[0][0] = dudx;
+          S[0][1] = (dudy + dvdx) / 2.0;
+          S[1][0] = S[0][1];
+          S[1][1] = dvdy;
+          double diag = (S[0][0] + S[1][1]) / 3.0;
+          if (nd == 3)
+          {
+            S[0][2] = (dudz + dwdx) / 2.0;
+            S[1][2] = (dvdz + dwdy) / 2.0;
+            S[2][0] = S[0][2];
+            S[2][1] = S[1][2];
+            S[2][2] = dwdz;
+            diag += S[2][2] / 3.0;
+          }
+          if (ids[m] == 4)
+            for (int a = 0; a < nd; a++) S[a][a] -= diag;
+          for (int a = 0; a < nd; a++)
+            for (int b = 0; b < nd; b++) diagnostic += S[a][b] * S[a][b];
+        }
+        out[m] += diagnostic * wgt[j] * detjac;
+      }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* over-integration                                                          */
 
 /* src/eles.cpp:1480-1545 (BLAS=NO branch) */

@@ -175,6 +175,11 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *f, orc_eles *e, con
 /* eles::evaluate_invFlux_over_int (src/eles.cpp:1480-1545): opp (n_cub,n_upts), filter (n_upts,n_cub), JGinv (nd,nd,n_cub,n_eles) */
 void orc_evaluate_invFlux_over_int(orc_eles *e, const orc_params *p, int n_cub, const double *opp_over_int_cubpts,
                                    const double *over_int_filter, const double *JGinv_over_int_cubpts);
+/* eles::CalcIntegralQuantities (src/eles.cpp:5485-5627); ids: 0 kineticenergy 1 enstropy 2 pressuredilatation
+ * 3 straincolonproduct 4 devstraincolonproduct; out[m] += contribution of this block; uses grad_disu_upts */
+void orc_CalcIntegralQuantities(const orc_eles *e, const orc_params *p, int n_cub, const double *opp_volume_cubpts,
+                                const double *weight_volume_cubpts, const double *vol_detjac_vol_cubpts, int n_q,
+                                const int *ids, double *out);
 void orc_shock_capture(orc_eles *e, const orc_shock *s); /* eles::shock_capture, shock_cap 1 + shock_det 0 */
 
 /* boundary faces, src/bdy_inters.cpp (wall model, LES inlet, RANS off) */

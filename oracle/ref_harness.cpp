@@ -292,6 +292,24 @@ int main(int argc, char *argv[])
       put_scalar("ramp_counter", run_input.ramp_counter);
     }
   }
+  // integral diagnostics (src/eles.cpp:5485-5627): volume cubature interpolation, weights, Jacobians
+  if (run_input.n_integral_quantities != 0)
+  {
+    put_arr("opp_volume_cubpts", E->opp_volume_cubpts);
+    put_arr("weight_volume_cubpts", E->weight_volume_cubpts);
+    const int nc = E->weight_volume_cubpts.get_dim(0);
+    vector<double> dj((size_t)nc * n_eles);
+    for (int j = 0; j < nc; j++)
+      for (int i = 0; i < n_eles; i++) dj[j + (size_t)nc * i] = E->vol_detjac_vol_cubpts(j)(i);
+    put_d("vol_detjac_vol_cubpts", dj.data(), {nc, n_eles});
+    vector<int32_t> ids(run_input.n_integral_quantities);
+    for (int m = 0; m < run_input.n_integral_quantities; m++)
+    {
+      const string &q = run_input.integral_quantities(m);
+      ids[m] = q == "kineticenergy" ? 0 : q == "enstropy" ? 1 : q == "pressuredilatation" ? 2 : q == "straincolonproduct" ? 3 : 4;
+    }
+    put_i("integral_quantity_ids", ids.data(), {run_input.n_integral_quantities});
+  }
   // over-integration (src/eles_hexas.cpp:1096-1129, src/eles.cpp:1480-1545)
   if (run_input.over_int)
   {
@@ -419,6 +437,14 @@ int main(int argc, char *argv[])
           res[n_fields + f] = E->compute_res_upts(2, f);
         }
         put_d("s0_res_sums", res.data(), {n_fields, 2});
+        if (run_input.n_integral_quantities != 0)
+        {
+          // state u_init, corrected gradients of this residual (output::CalcIntegralQuantities, src/output.cpp:2017)
+          hf_array<double> iq(run_input.n_integral_quantities);
+          iq.initialize_to_zero();
+          E->CalcIntegralQuantities(run_input.n_integral_quantities, iq);
+          put_arr("s0_integral_quantities", iq);
+        }
       }
       else
         CalcResidual(FlowSol.ini_iter + step, rk, &FlowSol);

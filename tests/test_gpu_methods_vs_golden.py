@@ -116,6 +116,21 @@ def test_over_integration_flux(ctx, name):
     e.close()
 
 
+@pytest.mark.parametrize("name", [n for n in ALL if "integrals" in n])
+def test_integral_quantities(ctx, name):
+    """eles::CalcIntegralQuantities on the device: kinetic energy, enstrophy, pressure dilatation, strain products."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e, faces = build(ctx, d)
+    e.set_volume_cubpts(d["opp_volume_cubpts"], d["weight_volume_cubpts"], d["vol_detjac_vol_cubpts"])
+    hfx.CalcResidual(e, faces)  # corrected gradients of u_init
+    got = e.CalcIntegralQuantities(np.ravel(d["integral_quantity_ids"]))
+    want = np.ravel(d["s0_integral_quantities"])
+    assert np.all(np.abs(got - want) <= 1e-11 * np.abs(want).max())
+    for f in faces:
+        f.close()
+    e.close()
+
+
 @pytest.mark.parametrize("name", BDY)
 def test_boundary_intermediates(ctx, name):
     """bdy_inters: the face arrays after the inviscid and the viscous sweep (interior + boundary blocks)."""

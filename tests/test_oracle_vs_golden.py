@@ -179,3 +179,22 @@ def test_over_integration_flux(oracle, name):
     oracle.orc_evaluate_invFlux_over_int(C.byref(e), C.byref(c.params), C.c_int(c.n_cub), e.opp_over_int_cubpts,
                                          e.over_int_filter, e.JGinv_over_int_cubpts)
     assert relerr(c.arr["tdisf_upts"], d["s0_tdisf_upts_inv"]) < RTOL
+
+
+@pytest.mark.parametrize("name", [n for n in ALL if "integrals" in n])
+def test_integral_quantities(oracle, name):
+    """eles::CalcIntegralQuantities: kinetic energy, enstrophy, pressure dilatation, strain products."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c = O.Case(d)
+    e = c.c_eles()
+    f, nfb = c.c_faces()
+    assert oracle.orc_CalcResidual(C.byref(e), f, nfb, C.byref(c.params)) == -1  # corrected gradients of u_init
+    opp = np.asfortranarray(d["opp_volume_cubpts"])
+    w = np.ascontiguousarray(np.ravel(d["weight_volume_cubpts"]))
+    dj = np.asfortranarray(d["vol_detjac_vol_cubpts"])
+    ids = np.ascontiguousarray(np.ravel(d["integral_quantity_ids"]).astype(np.int32))
+    out = np.zeros(len(ids))
+    oracle.orc_CalcIntegralQuantities(C.byref(e), C.byref(c.params), C.c_int(opp.shape[0]), O.fptr(opp), w.ctypes.data_as(O.dp),
+                                      O.fptr(dj), C.c_int(len(ids)), ids.ctypes.data_as(O.ip), out.ctypes.data_as(O.dp))
+    want = np.ravel(d["s0_integral_quantities"])
+    assert np.all(np.abs(out - want) <= 1e-12 * np.abs(want).max())
