@@ -2173,15 +2173,8 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     lds_barrier();
 
     // ---- A: transformed gradient, pencil-wise; flux-point solution, point-wise
-    double JF[ND * ND], nrm[ND], inv_df = 0.0;
     if (viscous)
     {
-      // flux-point metrics: issued here, used at the start of B
-#pragma unroll
-      for (int q = 0; q < ND * ND; q++) JF[q] = a.JGinv_fpts[o * (ND * ND) + q];
-      inv_df = 1.0 / a.detjac_fpts[o];
-#pragma unroll
-      for (int m = 0; m < ND; m++) nrm[m] = a.norm_fpts[o + m * plane_f];
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++)
       {
@@ -2219,39 +2212,8 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     }
     lds_barrier(); // sg complete; su / sd are dead: their region becomes st
 
+    __builtin_amdgcn_sched_barrier(0);
     // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
-    if (viscous && is_f)
-    {
-      double grf[NG], fq[NG];
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        double tg[ND], cg[ND];
-#pragma unroll
-        for (int d = 0; d < ND; d++)
-        {
-          double s = 0.0;
-#pragma unroll
-          for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&sg[(k + NF * d) * NU + am[m]]);
-          tg[d] = s;
-        }
-        to_physical<ND>(inv_df, JF, tg, cg);
-#pragma unroll
-        for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
-      }
-      if (a.grad_fpts && (a.meta == nullptr || (a.meta[o] & 4)))
-#pragma unroll
-        for (int q = 0; q < NG; q++) a.grad_fpts[o + q * plane_f] = grf[q];
-      calc_visf<ND, true>(a.P, uf, grf, fq);
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        double s = 0.0;
-#pragma unroll
-        for (int l = 0; l < ND; l++) s += fq[k + NF * l] * nrm[l];
-        a.fn_fpts[o + k * plane_f] = s;
-      }
-    }
     if (is_u)
     {
       // the transformed flux is accumulated in this thread's own st column (LDS) instead of 15 registers
@@ -2298,8 +2260,49 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
           }
       }
     }
+    __builtin_amdgcn_sched_barrier(0); // keep the two independent physics blocks apart: interleaving them doubles the live registers
+    if (viscous && is_f)
+    {
+      double grf[NG], fq[NG];
+      // flux-point metrics are fetched here, after the solution-point block has released its registers
+      double JF[ND * ND], nrm[ND];
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) JF[q] = a.JGinv_fpts[o * (ND * ND) + q];
+      const double inv_df = 1.0 / a.detjac_fpts[o];
+#pragma unroll
+      for (int m = 0; m < ND; m++) nrm[m] = a.norm_fpts[o + m * plane_f];
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double tg[ND], cg[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&sg[(k + NF * d) * NU + am[m]]);
+          tg[d] = s;
+        }
+        to_physical<ND>(inv_df, JF, tg, cg);
+#pragma unroll
+        for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
+      }
+      if (a.grad_fpts && (a.meta == nullptr || (a.meta[o] & 4)))
+#pragma unroll
+        for (int q = 0; q < NG; q++) a.grad_fpts[o + q * plane_f] = grf[q];
+      calc_visf<ND, true>(a.P, uf, grf, fq);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < ND; l++) s += fq[k + NF * l] * nrm[l];
+        a.fn_fpts[o + k * plane_f] = s;
+      }
+    }
     lds_barrier(); // st complete; sg is dead: its region takes the divergence parts
 
+    __builtin_amdgcn_sched_barrier(0);
     // ---- C: next element's inputs on their way; divergence parts pencil-wise, normal flux at the flux points
     if (e + gridDim.x < ne) fetch(e + gridDim.x);
 #pragma unroll
