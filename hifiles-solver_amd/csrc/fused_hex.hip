@@ -2091,6 +2091,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
   const double sgn1 = coef_g[T::C_L1 + dq * N]; // merged opp_1 row = sgn1 * Lrow (tnorm = +-1)
   // pencil role: ROUNDS work items (field, direction, pencil); a wave's items share the direction
   int it_d[ROUNDS], it_o[ROUNDS], it_fa[ROUNDS], it_fb[ROUNDS];
+  int it_dq[ROUNDS]; // the round's direction, wave-uniform (inactive lanes included)
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++)
   {
@@ -2106,6 +2107,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     else
       base = d == 0 ? N * line : (d == 1 ? (line % N) + N * N * (line / N) : line);
     it_d[r] = on ? d : -1;
+    it_dq[r] = __builtin_amdgcn_readfirstlane(d);
     it_o[r] = (k + NF * d) * NU + base;
     it_fa[r] = k * NFP + tidx[T::I_PF + (d * L + line) * 2 + 0];
     it_fb[r] = k * NFP + tidx[T::I_PF + (d * L + line) * 2 + 1];
@@ -2175,21 +2177,35 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     // ---- A: transformed gradient, pencil-wise; flux-point solution, point-wise
     if (viscous)
     {
+      // all rounds' pencils at once, branch-free (run-time stride): the LDS reads of every round are in flight
+      // together, then the N^2 FMAs per pencil against the wave-uniform 1-D matrix
+      double xa[ROUNDS][N], da[ROUNDS], db[ROUNDS];
+      int sr[ROUNDS];
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++)
       {
-        const int d = __builtin_amdgcn_readfirstlane(it_d[r] < 0 ? (int)((t + TB * r) / T::SP < ND ? (t + TB * r) / T::SP : ND - 1) : it_d[r]);
-        if (it_d[r] >= 0)
+        const int d = it_dq[r];
+        sr[r] = (d == 0) ? 1 : (d == 1 ? N : N * N);
+        const double *su_p = su + (it_o[r] - NF * d * NU);
+#pragma unroll
+        for (int m = 0; m < N; m++) xa[r][m] = ldsv(su_p + m * sr[r]);
+        da[r] = ldsv(sd + it_fa[r]);
+        db[r] = ldsv(sd + it_fb[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++)
+      {
+        const int d = it_dq[r];
+        double *sg_p = sg + it_o[r];
+#pragma unroll
+        for (int mp = 0; mp < N; mp++)
         {
-          const double *su_p = su + (it_o[r] - NF * d * NU);
-          const double *sda = sd + it_fa[r], *sdb = sd + it_fb[r];
-          double *sg_p = sg + it_o[r];
-          if (d == 0)
-            pencil_grad<ND, N, 0>(coef, su_p, sda, sdb, sg_p);
-          else if (d == 1)
-            pencil_grad<ND, N, 1>(coef, su_p, sda, sdb, sg_p);
-          else
-            pencil_grad<ND, N, ND - 1>(coef, su_p, sda, sdb, sg_p);
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < N; m++) acc += coef[T::C_D + mp * N + m] * xa[r][m];
+          acc += coef[T::C_5 + (d * 2 + 0) * N + mp] * da[r];
+          acc += coef[T::C_5 + (d * 2 + 1) * N + mp] * db[r];
+          if (it_d[r] >= 0) sg_p[mp * sr[r]] = acc;
         }
       }
     }
@@ -2201,13 +2217,18 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     }
     if (viscous && is_f)
     {
+      // pencil position outermost: NF independent accumulators per batch of LDS reads (one wait per batch
+      // instead of one per field); each output still sums over ascending m
 #pragma unroll
-      for (int k = 0; k < NF; k++)
+      for (int k = 0; k < NF; k++) uf[k] = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; m++)
       {
-        double s = 0.0;
+        double x[NF];
 #pragma unroll
-        for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&su[k * NU + am[m]]);
-        uf[k] = s;
+        for (int k = 0; k < NF; k++) x[k] = ldsv(&su[k * NU + am[m]]);
+#pragma unroll
+        for (int k = 0; k < NF; k++) uf[k] += Lrow[m] * x[k];
       }
     }
     lds_barrier(); // sg complete; su / sd are dead: their region becomes st
@@ -2272,17 +2293,22 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 #pragma unroll
       for (int m = 0; m < ND; m++) nrm[m] = a.norm_fpts[o + m * plane_f];
 #pragma unroll
+      for (int q = 0; q < NG; q++) grf[q] = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; m++)
+      {
+        double x[NG];
+#pragma unroll
+        for (int q = 0; q < NG; q++) x[q] = ldsv(&sg[q * NU + am[m]]);
+#pragma unroll
+        for (int q = 0; q < NG; q++) grf[q] += Lrow[m] * x[q];
+      }
+#pragma unroll
       for (int k = 0; k < NF; k++)
       {
         double tg[ND], cg[ND];
 #pragma unroll
-        for (int d = 0; d < ND; d++)
-        {
-          double s = 0.0;
-#pragma unroll
-          for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&sg[(k + NF * d) * NU + am[m]]);
-          tg[d] = s;
-        }
+        for (int d = 0; d < ND; d++) tg[d] = grf[k + NF * d];
         to_physical<ND>(inv_df, JF, tg, cg);
 #pragma unroll
         for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
@@ -2305,30 +2331,46 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     __builtin_amdgcn_sched_barrier(0);
     // ---- C: next element's inputs on their way; divergence parts pencil-wise, normal flux at the flux points
     if (e + gridDim.x < ne) fetch(e + gridDim.x);
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++)
     {
-      const int d = __builtin_amdgcn_readfirstlane(it_d[r] < 0 ? (int)((t + TB * r) / T::SP < ND ? (t + TB * r) / T::SP : ND - 1) : it_d[r]);
-      if (it_d[r] >= 0)
+      double xa[ROUNDS][N];
+      int sr[ROUNDS];
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++)
       {
-        if (d == 0)
-          pencil_div<ND, N, 0>(coef, st + it_o[r], sp + it_o[r]);
-        else if (d == 1)
-          pencil_div<ND, N, 1>(coef, st + it_o[r], sp + it_o[r]);
-        else
-          pencil_div<ND, N, ND - 1>(coef, st + it_o[r], sp + it_o[r]);
+        const int d = it_dq[r];
+        sr[r] = (d == 0) ? 1 : (d == 1 ? N : N * N);
+#pragma unroll
+        for (int m = 0; m < N; m++) xa[r][m] = ldsv(st + it_o[r] + m * sr[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++)
+      {
+#pragma unroll
+        for (int mp = 0; mp < N; mp++)
+        {
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < N; m++) acc += coef[T::C_D + mp * N + m] * xa[r][m];
+          if (it_d[r] >= 0) sp[it_o[r] + mp * sr[r]] = acc;
+        }
       }
     }
     if (is_f)
     {
+      double nt[NF];
 #pragma unroll
-      for (int k = 0; k < NF; k++)
+      for (int k = 0; k < NF; k++) nt[k] = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; m++)
       {
-        double s = 0.0;
+        double x[NF];
 #pragma unroll
-        for (int m = 0; m < N; m++) s += Lrow[m] * ldsv(&st[(k + NF * d_f) * NU + am[m]]);
-        a.ntd_fpts[o + k * plane_f] = sgn1 * s;
+        for (int k = 0; k < NF; k++) x[k] = ldsv(&st[(k + NF * d_f) * NU + am[m]]);
+#pragma unroll
+        for (int k = 0; k < NF; k++) nt[k] += Lrow[m] * x[k];
       }
+#pragma unroll
+      for (int k = 0; k < NF; k++) a.ntd_fpts[o + k * plane_f] = sgn1 * nt[k];
     }
     lds_barrier();
     if (is_u)
