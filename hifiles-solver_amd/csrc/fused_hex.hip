@@ -1797,6 +1797,10 @@ struct Split2Args
   double *disu_next;
   double *grad_upts, *grad_fpts; // optional outputs (NULL: not written)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
+  // update kernel: opp_3 and opp_0 in ELL form (values, columns, width), rows held in registers
+  const double *o3v, *o0v;
+  const int *o3i, *o0i;
+  int o3w, o0w;
   const double *src, *dt_local;
   unsigned long long *nan_flag;
   Phys P;
@@ -2445,25 +2449,33 @@ __global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
 
 // div_tdisf + opp_3 (norm_tconf - norm_tdisf) -> RK update -> disu_fpts of the new state: a streaming kernel
 template <int ND, int N>
-__global__ __launch_bounds__((SGeo<ND, N>::TB)) void split_update_kernel(const Split2Args a)
+__global__ __launch_bounds__((SGeo<ND, N>::TB), 3) void split_update_kernel(const Split2Args a)
 {
   using G = Geo<ND, N>;
-  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, WN = G::WN, TB = SGeo<ND, N>::TB;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TB = SGeo<ND, N>::TB;
   constexpr int N3 = 2 * ND;
-  constexpr int O3 = 0, O0 = words_of(N3), PW = O0 + WN;
-  __shared__ double tab[MAX_TAB];
   __shared__ double su[NF][NU];
   __shared__ double sc[NF][NFP];
   const int t = threadIdx.x;
   const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
   const bool is_u = t < NU, is_f = t < NFP;
   const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
-  for (int q = t; q < MAX_TAB; q += TB) tab[q] = a.tab_r[q];
-  unsigned pw[PW];
+  // this thread's rows of opp_3 (solution-point role) and opp_0 (flux-point role): the exact non-zeros in
+  // ascending column order, values and columns in registers (no dictionary, no table look-ups)
+  double c3[N3], c0[N];
+  int i3[N3], i0[N];
 #pragma unroll
-  for (int i = 0; i < words_of(N3); i++) pw[O3 + i] = a.pk_r[G::R_O3 + i * NU + tu];
+  for (int q = 0; q < N3; q++)
+  {
+    c3[q] = q < a.o3w ? a.o3v[tu + (long)NU * q] : 0.0;
+    i3[q] = q < a.o3w ? a.o3i[tu + (long)NU * q] : 0;
+  }
 #pragma unroll
-  for (int i = 0; i < WN; i++) pw[O0 + i] = a.pk_r[G::R_O0 + i * NFP + tf];
+  for (int q = 0; q < N; q++)
+  {
+    c0[q] = q < a.o0w ? a.o0v[tf + (long)NFP * q] : 0.0;
+    i0[q] = q < a.o0w ? a.o0i[tf + (long)NFP * q] : 0;
+  }
 
   for (long e = blockIdx.x; e < ne; e += gridDim.x)
   {
@@ -2486,10 +2498,23 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB)) void split_update_kernel(const S
     lds_barrier();
     if (is_u)
     {
+      // div_tconf = div_tdisf + opp_3 (norm_tconf - norm_tdisf): column outermost, NF accumulators per batch of reads
+      double dva[NF];
+#pragma unroll
+      for (int k = 0; k < NF; k++) dva[k] = dvin[k];
+#pragma unroll
+      for (int q = 0; q < N3; q++)
+      {
+        double x[NF];
+#pragma unroll
+        for (int k = 0; k < NF; k++) x[k] = ldsv(&sc[k][0] + i3[q]);
+#pragma unroll
+        for (int k = 0; k < NF; k++) dva[k] += c3[q] * x[k];
+      }
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
-        const double dv = row_dot<N3, O3, PW>(pw, tab, &sc[k][0], dvin[k]);
+        const double dv = dva[k];
         const long q = p + k * plane_u;
         if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)q);
         if (a.write_div) a.div[q] = dv;
@@ -2534,8 +2559,20 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB)) void split_update_kernel(const S
     lds_barrier();
     if (is_f)
     {
+      double un[NF];
 #pragma unroll
-      for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, O0, PW>(pw, tab, &su[k][0], 0.0);
+      for (int k = 0; k < NF; k++) un[k] = 0.0;
+#pragma unroll
+      for (int q = 0; q < N; q++)
+      {
+        double x[NF];
+#pragma unroll
+        for (int k = 0; k < NF; k++) x[k] = ldsv(&su[k][0] + i0[q]);
+#pragma unroll
+        for (int k = 0; k < NF; k++) un[k] += c0[q] * x[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = un[k];
     }
     lds_barrier();
   }
@@ -2575,6 +2612,8 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.grad_upts = nullptr;
     e2.grad_fpts = (any_bdy && P.viscous) ? e->arr[HFX_GRAD_DISU_FPTS] : nullptr; // boundary points only
     e2.meta = F->meta;
+    e2.o3v = e->opp_3.ell_val; e2.o3i = e->opp_3.ell_idx; e2.o3w = std::max(e->opp_3.nnz_max, 1);
+    e2.o0v = e->opp_0.ell_val; e2.o0i = e->opp_0.ell_idx; e2.o0w = std::max(e->opp_0.nnz_max, 1);
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;
     e2.adv_type = ea.adv_type; e2.in_step = ea.in_step; e2.dt_local_on = ea.dt_local_on; e2.write_div = ea.write_div;
     e2.need_u1 = ea.need_u1; e2.dt = ea.dt; e2.rk_a = ea.rk_a; e2.rk_b = ea.rk_b;
