@@ -252,6 +252,22 @@ extern "C" int hfxh_case_run(hfxh_case *c, int n_steps)
   return 0;
 }
 
+extern "C" int hfxh_case_write_restart(hfxh_case *c, const char *dir, int file_num)
+{
+  eles *E = the_eles(c);
+  if (c->S.ctx && E->cp_disu_upts_gpu_cpu()) { g_err = E->last_error(); return 1; }
+  if (write_restart_ascii(&c->S, dir ? dir : "", file_num)) { g_err = c->S.err; return 1; }
+  return 0;
+}
+
+extern "C" int hfxh_case_read_restart(hfxh_case *c, const char *dir, int file_num, int n_files)
+{
+  if (read_restart_ascii(&c->S, dir ? dir : "", file_num, n_files)) { g_err = c->S.err; return 1; }
+  eles *E = the_eles(c);
+  if (c->S.ctx && hfx_eles_upload(E->device(), HFX_DISU_UPTS0, E->disu_upts(0).get_ptr_cpu())) { g_err = hfx_last_error(); return 1; }
+  return 0;
+}
+
 extern "C" int hfxh_case_calc_time_step(hfxh_case *c, double *dt)
 {
   if (calc_time_step(&c->S)) { g_err = c->S.err; return 1; }

@@ -716,3 +716,147 @@ void eles_quads::eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double
     d(m, 1) = eval_lagrange(loc(0), i, x) * eval_d_lagrange(loc(1), j, x);
   }
 }
+
+// =========================================================================================
+// ASCII restart files: the on-disk state format of the reference (output::write_restart_ascii
+// src/output.cpp:1753-1818, read_restart_ascii src/solver.cpp:377-434)
+// =========================================================================================
+static const char *restart_ele_name(int ele_type) { return ele_type == 1 ? "QUADS" : (ele_type == 4 ? "HEXAS" : "?"); }
+
+void eles::write_restart_info_ascii(std::ostream &f)
+{
+  // src/eles_hexas.cpp:872-890, src/eles_quads.cpp write_restart_info_ascii
+  f << restart_ele_name(ele_type) << std::endl;
+  f << "Order" << std::endl;
+  f << order << std::endl;
+  f << (ele_type == 4 ? "Number of solution points per hexahedral element" : "Number of solution points per quadrilateral element")
+    << std::endl;
+  f << n_upts_per_ele << std::endl;
+  f << "Location of solution points in 1D" << std::endl;
+  for (int i = 0; i < order + 1; ++i) f << loc_1d_upts(i) << " ";
+  f << std::endl;
+}
+
+void eles::write_restart_data_ascii(std::ostream &f)
+{
+  // src/eles.cpp:845-870
+  f << "n_eles" << std::endl;
+  f << n_eles << std::endl;
+  f << "ele2global_ele hf_array" << std::endl;
+  for (int i = 0; i < n_eles; i++) f << ele2global_ele(i) << " ";
+  f << std::endl;
+  f << "data" << std::endl;
+  for (int i = 0; i < n_eles; i++)
+  {
+    f << ele2global_ele(i) << std::endl;
+    for (int j = 0; j < n_upts_per_ele; j++)
+    {
+      for (int k = 0; k < n_fields; k++) f << disu_upts(0)(j, i, k) << " ";
+      f << std::endl;
+    }
+  }
+  f << std::endl;
+}
+
+int eles::read_restart_info_ascii(std::istream &f)
+{
+  // src/eles_hexas.cpp:799-827
+  std::string str;
+  const std::string name = restart_ele_name(ele_type);
+  while (1)
+  {
+    std::getline(f, str);
+    if (str == name) break;
+    if (f.eof()) return 0;
+  }
+  std::getline(f, str);
+  f >> order_rest;
+  std::getline(f, str);
+  std::getline(f, str);
+  f >> n_upts_per_ele_rest;
+  std::getline(f, str);
+  std::getline(f, str);
+  loc_1d_upts_rest.setup(order_rest + 1);
+  for (int i = 0; i < order_rest + 1; ++i) f >> loc_1d_upts_rest(i);
+  set_opp_r();
+  return 1;
+}
+
+// opp_r(j,k) = restart basis k at solution point j (eval_nodal_basis_restart, src/eles_hexas.cpp:1149-1162)
+void eles::set_opp_r()
+{
+  const int n1 = order_rest + 1;
+  opp_r.setup(n_upts_per_ele, n_upts_per_ele_rest);
+  for (int j = 0; j < n_upts_per_ele; j++)
+    for (int idx = 0; idx < n_upts_per_ele_rest; idx++)
+    {
+      double v;
+      if (n_dims == 3)
+      {
+        const int i = idx / (n1 * n1), jj = (idx - n1 * n1 * i) / n1, k = idx - n1 * jj - n1 * n1 * i;
+        v = eval_lagrange(loc_upts(0, j), k, loc_1d_upts_rest) * eval_lagrange(loc_upts(1, j), jj, loc_1d_upts_rest) *
+            eval_lagrange(loc_upts(2, j), i, loc_1d_upts_rest);
+      }
+      else
+      {
+        const int i = idx / n1, jj = idx - n1 * i;
+        v = eval_lagrange(loc_upts(0, j), jj, loc_1d_upts_rest) * eval_lagrange(loc_upts(1, j), i, loc_1d_upts_rest);
+      }
+      opp_r(j, idx) = v;
+    }
+}
+
+int eles::read_restart_data_ascii(std::istream &f)
+{
+  // src/eles.cpp:655-728
+  std::string str;
+  const std::string name = restart_ele_name(ele_type);
+  f.clear();
+  f.seekg(0, f.beg);
+  while (1)
+  {
+    std::getline(f, str);
+    if (str == name) break;
+    if (f.eof()) return 0; // Restart file doesn't contain my elements
+  }
+  while (1)
+  {
+    std::getline(f, str);
+    if (str == "n_eles") break;
+    if (f.eof()) { fail("restart file: no n_eles block"); return 1; }
+  }
+  int num_eles_to_read = 0;
+  f >> num_eles_to_read;
+  std::getline(f, str);
+  std::getline(f, str);
+  std::getline(f, str);
+  std::getline(f, str);
+  hf_array<double> rest(n_upts_per_ele_rest, n_fields);
+  for (int i = 0; i < num_eles_to_read; i++)
+  {
+    int ele = -1;
+    f >> ele;
+    int index = -1;
+    for (int q = 0; q < n_eles; q++)
+      if (ele2global_ele(q) == ele) { index = q; break; }
+    if (index != -1)
+    {
+      for (int j = 0; j < n_upts_per_ele_rest; j++)
+        for (int k = 0; k < n_fields; k++) f >> rest(j, k);
+      for (int m = 0; m < n_fields; m++)
+        for (int j = 0; j < n_upts_per_ele; j++)
+        {
+          double value = 0.;
+          for (int k = 0; k < n_upts_per_ele_rest; k++) value += opp_r(j, k) * rest(k, m);
+          disu_upts(0)(j, index, m) = value;
+        }
+    }
+    else
+    {
+      std::getline(f, str);
+      for (int j = 0; j < n_upts_per_ele_rest; j++) std::getline(f, str);
+    }
+  }
+  if (!f) { fail("restart file: truncated data block"); return 1; }
+  return 0;
+}

@@ -7,6 +7,7 @@
 // they call the C ABI of libhfx (include/hfx.h), which owns the device copy of every array.
 // The setup methods (operators, metrics, initial condition) are host code, as in the reference.
 #pragma once
+#include <iostream>
 #include <string>
 
 #include "../../../include/hfx.h"
@@ -73,6 +74,15 @@ public:
   hf_array<hf_array<double>> div_tconf_upts;
   hf_array<double> grad_disu_upts;
   hf_array<double> h_ref, dt_local;
+  // ---- ASCII restart (src/eles.cpp:655-760,845-870; info blocks src/eles_hexas.cpp:799-890, eles_quads.cpp)
+  hf_array<int> ele2global_ele;
+  int order_rest = 0, n_upts_per_ele_rest = 0;
+  hf_array<double> loc_1d_upts_rest, opp_r;
+  void write_restart_info_ascii(std::ostream &restart_file);
+  void write_restart_data_ascii(std::ostream &restart_file);
+  int read_restart_info_ascii(std::istream &restart_file); // 1 found, 0 not in the file
+  int read_restart_data_ascii(std::istream &restart_file); // fills disu_upts(0); returns 0 or fails
+  void set_opp_r();
 
 protected:
   virtual int setup_ele_type_specific() = 0;

@@ -1,6 +1,8 @@
 #include "solver.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <fstream>
 #include <cmath>
 
 solution::~solution()
@@ -161,6 +163,15 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
             }
       }
   if (E->set_transforms()) { S->err = E->last_error(); return 1; }
+  // global element numbers (src/geometry.cpp: ele2global_ele): x-fastest over the GLOBAL box
+  E->ele2global_ele.setup(E->n_eles);
+  {
+    const int G[3] = {nx * mesh.pgrid[0], ny * mesh.pgrid[1], nz * (dims == 3 ? mesh.pgrid[2] : 1)};
+    for (int k = 0; k < nz; k++)
+      for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++)
+          E->ele2global_ele(i + nx * (j + ny * k)) = (i + mesh.pcoord[0] * nx) + G[0] * ((j + mesh.pcoord[1] * ny) + G[1] * (k + (dims == 3 ? mesh.pcoord[2] : 0) * nz));
+  }
   // reference length for CFL time stepping = the shortest edge of the (linear) element
   // (eles_hexas::calc_h_ref_specific src/eles_hexas.cpp:1551-1571, eles_quads:: src/eles_quads.cpp:1287-1301)
   {
@@ -316,6 +327,54 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
     for (int p = 0; p < S->nproc; p++) M.set_nout_proc(nout[p], p);
     if (M.failed()) { S->err = M.last_error(); return 1; }
   }
+  return 0;
+}
+
+// output::write_restart_ascii (src/output.cpp:1753-1818): "Rest_%09d_p%04d.dat" in `dir`
+int write_restart_ascii(solution *S, const std::string &dir, int in_file_num)
+{
+  char name[64];
+  snprintf(name, sizeof name, "Rest_%.09d_p%.04d.dat", in_file_num, S->rank);
+  std::ofstream f((dir.empty() ? std::string(".") : dir) + "/" + name);
+  if (!f) { S->err = "Unable to open restart file for writing"; return 1; }
+  f.precision(15);
+  f << S->time << std::endl;
+  for (int i = 0; i < S->n_ele_types; i++)
+    if (S->mesh_eles(i) && S->mesh_eles(i)->get_n_eles() != 0)
+    {
+      S->mesh_eles(i)->write_restart_info_ascii(f);
+      S->mesh_eles(i)->write_restart_data_ascii(f);
+    }
+  return f ? 0 : 1;
+}
+
+// read_restart_ascii (src/solver.cpp:377-434): time + every element class's data from the rank files
+int read_restart_ascii(solution *S, const std::string &dir, int in_file_num, int in_n_files)
+{
+  for (int i = 0; i < S->n_ele_types; i++)
+    if (S->mesh_eles(i) && S->mesh_eles(i)->get_n_eles() != 0)
+    {
+      bool info = false;
+      for (int j = 0; j < in_n_files && !info; j++)
+      {
+        char name[64];
+        snprintf(name, sizeof name, "Rest_%.09d_p%.04d.dat", in_file_num, j);
+        std::ifstream f((dir.empty() ? std::string(".") : dir) + "/" + name);
+        if (!f) { S->err = "Could not open restart file "; S->err += name; return 1; } /* src/solver.cpp:393 */
+        f >> S->time;
+        info = S->mesh_eles(i)->read_restart_info_ascii(f) != 0;
+      }
+      if (!info) { S->err = "Could not find restart info in the restart files"; return 1; }
+      for (int j = 0; j < in_n_files; j++)
+      {
+        char name[64];
+        snprintf(name, sizeof name, "Rest_%.09d_p%.04d.dat", in_file_num, j);
+        std::ifstream f((dir.empty() ? std::string(".") : dir) + "/" + name);
+        if (!f) { S->err = "Could not open restart file "; S->err += name; return 1; }
+        if (S->mesh_eles(i)->read_restart_data_ascii(f)) { S->err = S->mesh_eles(i)->last_error(); return 1; }
+      }
+    }
+  S->run_input.time = S->time;
   return 0;
 }
 

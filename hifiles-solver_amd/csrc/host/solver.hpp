@@ -69,6 +69,9 @@ int MoveToDevice(solution *FlowSol, int device);
 void CalcResidual(int in_file_num, int in_rk_stage, solution *FlowSol);
 // RK loop of src/HiFiLES.cpp:194-221 through the mirrored class methods
 int calc_time_step(solution *FlowSol); // src/solver.cpp:484-549
+// ASCII restart files "Rest_%09d_p%04d.dat" (host arrays; sync with the device before / after)
+int write_restart_ascii(solution *FlowSol, const std::string &dir, int in_file_num);             // src/output.cpp:1753
+int read_restart_ascii(solution *FlowSol, const std::string &dir, int in_file_num, int n_files); // src/solver.cpp:377
 int RunSteps(solution *FlowSol, int n_steps);
 // the same RK loop through the split fused kernels on a partitioned block, exchanging between the
 // phases of hfx_stage_partitioned

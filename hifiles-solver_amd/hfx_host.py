@@ -257,6 +257,12 @@ class Case:
         ctx, e, f, nb = self.handles()
         return hfx.lib().hfx_ctx_stream(ctx)
 
+    def write_restart(self, directory, file_num):
+        check(lib().hfxh_case_write_restart(self.h, str(directory).encode(), C.c_int(file_num)))
+
+    def read_restart(self, directory, file_num, n_files=1):
+        check(lib().hfxh_case_read_restart(self.h, str(directory).encode(), C.c_int(file_num), C.c_int(n_files)))
+
     def calc_time_step(self):
         v = C.c_double(0)
         check(lib().hfxh_case_calc_time_step(self.h, C.byref(v)))

@@ -100,6 +100,11 @@ int hfxh_case_run(hfxh_case *c, int n_steps); /* the mirrored RK loop (src/HiFiL
 int hfxh_case_mpi_handle(hfxh_case *c, hfx_inters **f);
 /* the RK loop through hfx_stage_partitioned (split fused kernels), exchanging between its phases */
 int hfxh_case_run_partitioned(hfxh_case *c, int n_steps);
+/* ASCII restart files of the reference, "Rest_%09d_p%04d.dat" in `dir` (output::write_restart_ascii
+ * src/output.cpp:1753-1818, read_restart_ascii src/solver.cpp:377-434): host state in / out; a case that is on
+ * the device downloads before writing and uploads after reading */
+int hfxh_case_write_restart(hfxh_case *c, const char *dir, int file_num);
+int hfxh_case_read_restart(hfxh_case *c, const char *dir, int file_num, int n_files);
 /* calc_time_step (src/solver.cpp:484-549) on the device; hfxh_case_run calls it before every step */
 int hfxh_case_calc_time_step(hfxh_case *c, double *dt);
 int hfxh_case_sync_host(hfxh_case *c);        /* cp_*_gpu_cpu of state, divergence, gradient */

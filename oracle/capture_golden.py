@@ -54,10 +54,10 @@ BASE = dict(
 BASE.update(TGV_FLUID)
 
 
-def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, **over):
+def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, **over):
     d = dict(BASE)
     d.update(over)
-    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs)
+    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs, restart=restart)
 
 
 # boundary groups for the bdy_inters fixtures: states near the TGV initial state (rho 8.42e-4, T 300, Mach 0.1)
@@ -102,6 +102,9 @@ CASES = [
     case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
     case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
     case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+    # the ASCII restart file of the final state (on-disk format either side of the path)
+    case("hex_p2_restart", amp=0.15, level=0, order=2, steps=1, restart=True),
+    case("quad_p3_restart", dims=2, n=4, amp=0.1, level=0, order=3, steps=1, restart=True),
     # integral diagnostics of the TGV monitors (kinetic energy, enstrophy, ...)
     case("hex_p2_integrals", amp=0.15, level=1, order=2, steps=1,
          integral_quantities="5 kineticenergy enstropy pressuredilatation straincolonproduct devstraincolonproduct"),
@@ -170,12 +173,16 @@ def run_case(c):
             for k, v in keys.items():
                 f.write("%s %s\n" % (k, repr(v) if isinstance(v, float) else v))
         env = dict(os.environ, HIFILES_HOME=REF_HOME)
+        if c.get("restart"):
+            env["HFX_DUMP_RESTART"] = "1"
         r = subprocess.run([HARNESS, "input", "dump.bin", str(c["steps"]), str(c["level"])],
                            cwd=td, env=env, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout[-3000:] + r.stderr[-3000:])
             raise SystemExit("harness failed for " + c["name"])
         arrs = read_dump(os.path.join(td, "dump.bin"))
+    if "restart_ascii" in arrs:
+        arrs["restart_ascii"] = arrs["restart_ascii"].astype(np.uint8)
     arrs["xv"] = xv
     meta = dict(name=c["name"], n=c["n"], dims=c["dims"], amp=c["amp"], steps=c["steps"],
                 level=c["level"], keys=c["keys"], bcs=c.get("bcs"),

@@ -468,6 +468,28 @@ int main(int argc, char *argv[])
     FlowSol.time += run_input.dt;
     run_input.time = FlowSol.time;
   }
+  if (getenv("HFX_DUMP_RESTART"))
+  {
+    // the ASCII restart of the final state, exactly as output::write_restart_ascii composes it
+    // (src/output.cpp:1753-1818): time, then per element class the info block and the data block
+    {
+      ofstream rf("restart_dump.dat");
+      rf.precision(15);
+      rf << FlowSol.time << endl;
+      for (int i = 0; i < FlowSol.n_ele_types; i++)
+        if (FlowSol.mesh_eles(i)->get_n_eles() != 0)
+        {
+          FlowSol.mesh_eles(i)->write_restart_info_ascii(rf);
+          FlowSol.mesh_eles(i)->write_restart_data_ascii(rf);
+        }
+    }
+    ifstream in("restart_dump.dat", ios::binary);
+    string txt((istreambuf_iterator<char>(in)), istreambuf_iterator<char>());
+    vector<int32_t> bytes(txt.size());
+    for (size_t i = 0; i < txt.size(); i++) bytes[i] = (unsigned char)txt[i];
+    put_i("restart_ascii", bytes.data(), {(int64_t)bytes.size()});
+    put_scalar("restart_time", FlowSol.time);
+  }
   fclose(g_out);
   return 0;
 }
