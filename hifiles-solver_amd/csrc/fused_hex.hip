@@ -1086,6 +1086,7 @@ static int tensor_build(hfx_eles *e, FusedData *F, int N, const std::vector<doub
 static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allow_unpaired = false)
 {
   HFX_CHECK(!e->over_int_ready, "fused path: over-integration is evaluated by the per-method path only");
+  HFX_CHECK(!e->les_ready, "fused path: the LES closure is evaluated by the per-method path only");
   HFX_CHECK(e->ele_type == 4 || e->ele_type == 1, "fused path: tensor-product elements only (hexes, quads)");
   const int N = tensor_n(e);
   HFX_CHECK(N >= 2 && N <= 6, "fused path: built for orders 1..5 (n_upts %d, n_fpts %d)", e->n_upts, e->n_fpts);

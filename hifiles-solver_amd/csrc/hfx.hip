@@ -412,10 +412,12 @@ int hfx_eles_create(hfx_ctx *ctx, const hfx_eles_desc *d, hfx_eles **out)
   len[HFX_DIV_TCONF_UPTS] = pu * nf; len[HFX_DELTA_DISU_FPTS] = pf * nf;
   len[HFX_GRAD_DISU_UPTS] = pu * nf * nd; len[HFX_GRAD_DISU_FPTS] = pf * nf * nd;
   len[HFX_SRC_UPTS] = pu * nf; len[HFX_DT_LOCAL] = ne; len[HFX_SENSOR] = ne;
+  len[HFX_SGSF_UPTS] = pu * nf * nd; len[HFX_SGSF_FPTS] = pf * nf * nd;
   for (int i = 0; i < HFX_N_ARRAYS; i++)
   {
     e->arr_len[i] = len[i];
-    if (i == HFX_SRC_UPTS || i == HFX_DT_LOCAL) continue; // allocated on first upload
+    if (i == HFX_SRC_UPTS || i == HFX_DT_LOCAL) continue;       // allocated on first upload
+    if (i == HFX_SGSF_UPTS || i == HFX_SGSF_FPTS) continue;     // allocated by hfx_eles_set_les
     HFX_HIP(hipMalloc((void **)&e->arr[i], sizeof(double) * (size_t)std::max<long>(len[i], 1)));
     // the reference zero-initialises its arrays (hf_array::setup + initialize_to_zero, src/eles.cpp:100-215)
     HFX_HIP(hipMemset(e->arr[i], 0, sizeof(double) * (size_t)std::max<long>(len[i], 1)));
@@ -451,6 +453,8 @@ int hfx_eles_destroy(hfx_eles *e)
   for (int i = 0; i < HFX_N_ARRAYS; i++)
     if (e->arr[i]) (void)hipFree(e->arr[i]);
   if (e->h_ref) (void)hipFree(e->h_ref);
+  if (e->wall_distance) (void)hipFree(e->wall_distance);
+  if (e->Jacobian_fpts) (void)hipFree(e->Jacobian_fpts);
   if (e->nan_flag) (void)hipFree(e->nan_flag);
   if (e->red_buf) (void)hipFree(e->red_buf);
   fused_destroy(e);
@@ -571,6 +575,19 @@ int hfx_eles_evaluate_viscFlux(hfx_eles *e)
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   const long plane = (long)e->n_upts * e->n_eles;
   const Phys P = e->ctx->phys();
+  if (e->les_ready)
+  {
+    if (e->n_dims == 2)
+      hipLaunchKernelGGL(viscflux_les_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane, P,
+                         e->les, e->arr[HFX_DISU_UPTS0], e->arr[HFX_GRAD_DISU_UPTS], e->JGinv_upts, e->detjac_upts,
+                         e->wall_distance, e->arr[HFX_TDISF_UPTS], e->arr[HFX_SGSF_UPTS]);
+    else
+      hipLaunchKernelGGL(viscflux_les_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane, P,
+                         e->les, e->arr[HFX_DISU_UPTS0], e->arr[HFX_GRAD_DISU_UPTS], e->JGinv_upts, e->detjac_upts,
+                         e->wall_distance, e->arr[HFX_TDISF_UPTS], e->arr[HFX_SGSF_UPTS]);
+    HFX_HIP(hipGetLastError());
+    return 0;
+  }
   if (e->n_dims == 2)
     hipLaunchKernelGGL(viscflux_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane, P,
                        e->arr[HFX_DISU_UPTS0], e->arr[HFX_GRAD_DISU_UPTS], e->JGinv_upts, e->arr[HFX_TDISF_UPTS]);
@@ -736,6 +753,53 @@ int hfx_inters_destroy(hfx_inters *f)
   return 0;
 }
 
+// ---- LES closure ----------------------------------------------------------------------------
+int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distance, const double *Jacobian_fpts)
+{
+  HFX_CHECK(e && les && Jacobian_fpts, "hfx_eles_set_les: NULL argument");
+  HFX_CHECK(les->sgs_model == 0 || les->sgs_model == 1, "SGS model not implemented"); /* src/eles.cpp:2461 (models 2-4: not built) */
+  HFX_CHECK(les->sgs_model != 0 || wall_distance, "hfx_eles_set_les: the Smagorinsky model needs wall_distance");
+  HFX_CHECK(e->viscous_ops, "LES not supported with inviscid flow"); /* src/input.cpp:570 */
+  e->les.sgs_model = les->sgs_model; e->les.order = e->order;
+  e->les.C_s = les->C_s; e->les.filter_ratio = les->filter_ratio; e->les.Kappa = les->Kappa; e->les.prandtl_t = les->prandtl_t;
+  for (double **p : {&e->wall_distance, &e->Jacobian_fpts})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (wall_distance && dev_alloc_copy(&e->wall_distance, wall_distance, (long)e->n_upts * e->n_eles * e->n_dims)) return 1;
+  if (dev_alloc_copy(&e->Jacobian_fpts, Jacobian_fpts, (long)e->n_dims * e->n_dims * e->n_fpts * e->n_eles)) return 1;
+  for (int id : {HFX_SGSF_UPTS, HFX_SGSF_FPTS})
+    if (!e->arr[id])
+    {
+      HFX_HIP(hipMalloc((void **)&e->arr[id], sizeof(double) * (size_t)std::max<long>(e->arr_len[id], 1)));
+      HFX_HIP(hipMemset(e->arr[id], 0, sizeof(double) * (size_t)std::max<long>(e->arr_len[id], 1)));
+    }
+  e->les_ready = true;
+  fused_invalidate(e);
+  return 0;
+}
+
+int hfx_eles_extrapolate_sgsFlux(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  HFX_CHECK(e->les_ready, "extrapolate_sgsFlux: hfx_eles_set_les was not called");
+  const long su = (long)e->n_upts * e->n_eles * e->n_fields, sf = (long)e->n_fpts * e->n_eles * e->n_fields;
+  for (int d = 0; d < e->n_dims; d++)
+  {
+    const Operator *ops[1] = {&e->opp_0};
+    const double *in[1] = {e->arr[HFX_SGSF_UPTS] + d * su};
+    if (contract_multi_in(e->ctx, ops, 1, in, e->arr[HFX_SGSF_FPTS] + d * sf, (long)e->n_eles * e->n_fields, 0)) return 1;
+  }
+  const long plane = (long)e->n_fpts * e->n_eles;
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(sgsf_to_physical_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane,
+                       e->detjac_fpts, e->Jacobian_fpts, e->arr[HFX_SGSF_FPTS]);
+  else
+    hipLaunchKernelGGL(sgsf_to_physical_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane,
+                       e->detjac_fpts, e->Jacobian_fpts, e->arr[HFX_SGSF_FPTS]);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- integral diagnostics -------------------------------------------------------------------
 int hfx_eles_set_volume_cubpts(hfx_eles *e, int n_cubpts, const double *opp_volume_cubpts, const double *weight_volume_cubpts,
                                const double *vol_detjac_vol_cubpts)
@@ -804,6 +868,8 @@ int hfx_eles_set_h_ref(hfx_eles *e, const double *h_ref)
 {
   HFX_CHECK(e && h_ref, "hfx_eles_set_h_ref: NULL argument");
   if (e->h_ref) (void)hipFree(e->h_ref);
+  if (e->wall_distance) (void)hipFree(e->wall_distance);
+  if (e->Jacobian_fpts) (void)hipFree(e->Jacobian_fpts);
   e->h_ref = nullptr;
   return dev_alloc_copy(&e->h_ref, h_ref, e->n_eles);
 }
@@ -1147,6 +1213,9 @@ static FaceArgs face_args(hfx_inters *f)
   a.tconf_l = l->arr[HFX_NORM_TCONF_FPTS]; a.tconf_r = r->arr[HFX_NORM_TCONF_FPTS];
   a.delta_l = l->arr[HFX_DELTA_DISU_FPTS]; a.delta_r = r->arr[HFX_DELTA_DISU_FPTS];
   a.grad_l = l->arr[HFX_GRAD_DISU_FPTS]; a.grad_r = r->arr[HFX_GRAD_DISU_FPTS];
+  const bool les = l->les_ready && r->les_ready;
+  a.sgsf_l = les ? l->arr[HFX_SGSF_FPTS] : nullptr;
+  a.sgsf_r = les ? r->arr[HFX_SGSF_FPTS] : nullptr;
   return a;
 }
 
@@ -1198,6 +1267,7 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
   {
     if (hfx_eles_correct_gradient(e)) return 1;
     if (hfx_eles_evaluate_viscFlux(e)) return 1;
+    if (e->les_ready && hfx_eles_extrapolate_sgsFlux(e)) return 1; /* src/solver.cpp:162-167 */
   }
   if (hfx_eles_extrapolate_totalFlux(e)) return 1;
   if (hfx_eles_calculate_divergence(e)) return 1;

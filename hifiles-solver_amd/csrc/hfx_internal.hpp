@@ -91,6 +91,10 @@ struct hfx_eles
   int n_eles = 0, n_upts = 0, n_fpts = 0, n_fields = 0, n_dims = 0, ele_type = 0, order = 0;
   bool viscous_ops = false;
   double *h_ref = nullptr; // (n_eles) eles::h_ref for calc_dt_local
+  // LES closure (hfx_eles_set_les)
+  bool les_ready = false;
+  hfx::LesParams les{};
+  double *wall_distance = nullptr, *Jacobian_fpts = nullptr;
   // integral diagnostics (hfx_eles_set_volume_cubpts)
   int n_vol_cubpts = 0;
   hfx::Operator opp_volume_cubpts;

@@ -109,6 +109,91 @@ __global__ __launch_bounds__(PT_BLOCK) void viscflux_kernel(long plane, const Ph
     }
 }
 
+// ---- eles::evaluate_viscFlux with LES (src/eles.cpp:2322-2348): F_v + F_sgs, and sgsf_upts = JGinv * F_sgs
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void viscflux_les_kernel(long plane, const Phys P, const LesParams Lp,
+                                                                const double *__restrict__ U, const double *__restrict__ G,
+                                                                const double *__restrict__ JGinv,
+                                                                const double *__restrict__ detjac,
+                                                                const double *__restrict__ wall_distance, double *tdisf,
+                                                                double *__restrict__ sgsf_upts)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double u[NF], g[NF * ND], f[NF * ND], sg[NF * ND], JG[ND * ND];
+#pragma unroll
+  for (int k = 0; k < NF; k++) u[k] = U[p + k * plane];
+#pragma unroll
+  for (int q = 0; q < NF * ND; q++) g[q] = G[p + q * plane];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) JG[q] = JGinv[p * (ND * ND) + q];
+  calc_visf<ND>(P, u, g, f);
+  double y = 0.0;
+  if (Lp.sgs_model == 0)
+  {
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+    {
+      const double w = wall_distance[p + i * plane];
+      y += w * w;
+    }
+    y = sqrt(y);
+  }
+  calc_sgsf<ND>(P, Lp, u, g, detjac[p], y, sg);
+#pragma unroll
+  for (int q = 0; q < NF * ND; q++) f[q] += 1.0 * sg[q];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      double ts = 0.0;
+#pragma unroll
+      for (int m = 0; m < ND; m++) ts += JG[l + ND * m] * sg[k + NF * m];
+      sgsf_upts[p + (k + NF * l) * plane] = ts;
+      double t = tdisf[p + (k + NF * l) * plane];
+#pragma unroll
+      for (int m = 0; m < ND; m++) t += JG[l + ND * m] * f[k + NF * m];
+      tdisf[p + (k + NF * l) * plane] = t;
+    }
+}
+
+// second half of eles::extrapolate_sgsFlux (src/eles.cpp:2862-2893): sgsf_fpts <- |J|^-1 J sgsf_fpts, in place
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void sgsf_to_physical_kernel(long plane, const double *__restrict__ detjac,
+                                                                    const double *__restrict__ Jac, double *S)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double J[ND * ND];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) J[q] = Jac[p * (ND * ND) + q];
+  const double inv_detjac = 1.0 / detjac[p];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    double ts[ND], ps[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++)
+    {
+      ts[d] = S[p + (k + NF * d) * plane];
+      ps[d] = 0.0;
+    }
+    // dgemm(alpha = inv_detjac): c(i) += (alpha * b(l)) * a(i,l), l outer (src/funcs.cpp:110-117)
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      const double temp = inv_detjac * ts[l];
+#pragma unroll
+      for (int i = 0; i < ND; i++) ps[i] += temp * J[i + ND * l];
+    }
+#pragma unroll
+    for (int d = 0; d < ND; d++) S[p + (k + NF * d) * plane] = ps[d];
+  }
+}
+
 // ---- int_inters::calculate_common_invFlux ------------------------------------
 struct FaceArgs
 {
@@ -121,6 +206,7 @@ struct FaceArgs
   double *tconf_l, *tconf_r;
   double *delta_l, *delta_r;
   const double *grad_l, *grad_r;
+  const double *sgsf_l, *sgsf_r; // LES: physical SGS flux at the flux points (NULL: off)
 };
 
 template <int ND>
@@ -185,6 +271,16 @@ __global__ __launch_bounds__(PT_BLOCK) void common_viscflux_kernel(const FaceArg
   for (int m = 0; m < ND; m++) n[m] = a.norm_l[il + m * a.plane_l];
   calc_visf<ND>(P, ul, gl, fl);
   calc_visf<ND>(P, ur, gr, fr);
+  if (a.sgsf_l != nullptr)
+  {
+    // src/int_inters.cpp:302-318
+#pragma unroll
+    for (int s = 0; s < NF * ND; s++)
+    {
+      fl[s] += a.sgsf_l[il + s * a.plane_l];
+      fr[s] += a.sgsf_r[ir + s * a.plane_r];
+    }
+  }
   const double beta = ldg_switch<ND>(P.ldg_beta, n);
   const double tl = a.tdA_l[il], tr = a.tdA_r[ir];
 #pragma unroll

@@ -371,4 +371,122 @@ __device__ __forceinline__ double ldg_switch(double beta, const double (&n)[ND])
   return beta;
 }
 
+// LES eddy-viscosity closure, eles::calc_sgsf_upts (src/eles.cpp:2395-2650): sgs_model 0 Smagorinsky with
+// near-wall damping (y = distance to the nearest no-slip wall), 1 WALE.  f(k,m) = f[k + NF*m].
+struct LesParams
+{
+  int sgs_model, order;
+  double C_s, filter_ratio, Kappa, prandtl_t;
+};
+
+template <int ND>
+__device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, const double (&tu)[ND + 2],
+                                          const double (&g)[(ND + 2) * ND], const double detjac, const double y,
+                                          double (&sg)[(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+  double u[ND], drho[ND], dene[ND], dke[ND], de[ND], dmom[ND][ND], du[ND][ND], S[ND][ND];
+  const double rho = tu[0];
+  double ke = 0.;
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+  {
+    u[i] = tu[i + 1] / rho;
+    ke += 0.5 * (u[i] * u[i]);
+  }
+  const double inte = tu[NF - 1] / rho - ke;
+  const double vol = detjac * (ND == 3 ? 8. : 4.); // calc_ele_vol of hexes / quads
+  const double delta = Lp.filter_ratio * pow(vol, 1. / ND) / (Lp.order + 1.);
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+  {
+    drho[i] = g[0 + NF * i];
+    dene[i] = g[(NF - 1) + NF * i];
+#pragma unroll
+    for (int j = 1; j < NF - 1; j++) dmom[i][j - 1] = g[j + NF * i];
+  }
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+  {
+    dke[i] = ke * drho[i];
+#pragma unroll
+    for (int j = 0; j < ND; j++)
+    {
+      du[i][j] = (dmom[i][j] - u[j] * drho[i]) / rho;
+      dke[i] += rho * u[j] * du[i][j];
+    }
+    de[i] = (dene[i] - dke[i] - drho[i] * inte) / rho;
+  }
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int j = 0; j < ND; j++) S[i][j] = (du[i][j] + du[j][i]) / 2.0;
+  double mu_t;
+  if (Lp.sgs_model == 0)
+  {
+    double Smod = 0.0;
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++) Smod += 2.0 * S[i][j] * S[i][j];
+    Smod = sqrt(Smod);
+    mu_t = rho * fmin(y * y * Lp.Kappa * Lp.Kappa, Lp.C_s * Lp.C_s * delta * delta) * Smod;
+  }
+  else
+  {
+    double num = 0.0, denom = 0.0, Sq[ND][ND], gT[ND][ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++)
+      {
+        double s = 0.;
+#pragma unroll
+        for (int l = 0; l < ND; l++) s += du[i][l] * du[l][j];
+        gT[i][j] = s;
+      }
+    double diag = 0.0;
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++)
+      {
+        Sq[i][j] = 0.;
+        Sq[i][j] += 0.5 * gT[j][i];
+        Sq[i][j] += 0.5 * gT[i][j];
+      }
+#pragma unroll
+    for (int i = 0; i < ND; i++) diag += gT[i][i] / 3.0;
+#pragma unroll
+    for (int i = 0; i < ND; i++) Sq[i][i] -= diag;
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++)
+      {
+        num += Sq[i][j] * Sq[i][j];
+        denom += S[i][j] * S[i][j];
+      }
+    denom = pow(denom, 2.5) + pow(num, 1.25);
+    num = pow(num, 1.5);
+    mu_t = rho * Lp.C_s * Lp.C_s * delta * delta * num / (denom + 1.e-12);
+  }
+  double diag = 0.;
+#pragma unroll
+  for (int i = 0; i < ND; i++) diag += S[i][i] / 3.0;
+#pragma unroll
+  for (int i = 0; i < ND; i++) S[i][i] -= diag;
+#pragma unroll
+  for (int j = 0; j < ND; j++)
+  {
+    sg[0 + NF * j] = 0.0;
+    double ef = -1.0 * P.gamma * mu_t / Lp.prandtl_t * de[j];
+#pragma unroll
+    for (int k = 0; k < ND; k++) ef -= u[k] * 2.0 * mu_t * S[k][j];
+    sg[(NF - 1) + NF * j] = ef;
+#pragma unroll
+    for (int i = 1; i < NF - 1; i++) sg[i + NF * j] = -2.0 * mu_t * S[i - 1][j];
+  }
+}
+
 } // namespace hfx

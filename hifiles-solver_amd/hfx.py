@@ -18,7 +18,12 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 
 (DISU_UPTS0, DISU_UPTS1, DISU_FPTS, TDISF_UPTS, NORM_TDISF_FPTS, NORM_TCONF_FPTS, DIV_TCONF_UPTS,
- DELTA_DISU_FPTS, GRAD_DISU_UPTS, GRAD_DISU_FPTS, SRC_UPTS, DT_LOCAL, SENSOR) = range(13)
+ DELTA_DISU_FPTS, GRAD_DISU_UPTS, GRAD_DISU_FPTS, SRC_UPTS, DT_LOCAL, SENSOR, SGSF_UPTS, SGSF_FPTS) = range(15)
+
+
+class Les(C.Structure):
+    _fields_ = [("sgs_model", C.c_int), ("pad", C.c_int), ("C_s", C.c_double), ("filter_ratio", C.c_double),
+                ("Kappa", C.c_double), ("prandtl_t", C.c_double)]
 CONTRACT_AUTO, CONTRACT_DENSE, CONTRACT_SPARSE = 0, 1, 2
 
 
@@ -163,7 +168,8 @@ class Eles:
             DISU_UPTS0: (nu, ne, nf), DISU_UPTS1: (nu, ne, nf), DISU_FPTS: (nfp, ne, nf),
             TDISF_UPTS: (nu, ne, nf, nd), NORM_TDISF_FPTS: (nfp, ne, nf), NORM_TCONF_FPTS: (nfp, ne, nf),
             DIV_TCONF_UPTS: (nu, ne, nf), DELTA_DISU_FPTS: (nfp, ne, nf), GRAD_DISU_UPTS: (nu, ne, nf, nd),
-            GRAD_DISU_FPTS: (nfp, ne, nf, nd), SRC_UPTS: (nu, ne, nf), DT_LOCAL: (ne,), SENSOR: (ne,)}
+            GRAD_DISU_FPTS: (nfp, ne, nf, nd), SRC_UPTS: (nu, ne, nf), DT_LOCAL: (ne,), SENSOR: (ne,),
+            SGSF_UPTS: (nu, ne, nf, nd), SGSF_FPTS: (nfp, ne, nf, nd)}
 
     def upload(self, array_id, a):
         a = _f(a)
@@ -203,6 +209,14 @@ class Eles:
                                                h.ctypes.data_as(ip), C.c_double(s0), C.c_int(shock_det_field)))
 
     def shock_capture(self): self._call("hfx_eles_shock_capture")
+
+    def set_les(self, sgs_model, C_s, filter_ratio, Kappa, prandtl_t, Jacobian_fpts, wall_distance=None):
+        les = Les(sgs_model, 0, C_s, filter_ratio, Kappa, prandtl_t)
+        J = _f(Jacobian_fpts)
+        w = _f(wall_distance) if wall_distance is not None else None
+        check(lib().hfx_eles_set_les(self.h, C.byref(les), w.ctypes.data_as(dp) if w is not None else None, J.ctypes.data_as(dp)))
+
+    def extrapolate_sgsFlux(self): self._call("hfx_eles_extrapolate_sgsFlux")
 
     def set_volume_cubpts(self, opp_volume_cubpts, weight_volume_cubpts, vol_detjac_vol_cubpts):
         a, d = _f(opp_volume_cubpts), _f(vol_detjac_vol_cubpts)

@@ -86,7 +86,9 @@ enum hfx_array_id
   HFX_SRC_UPTS = 10,      /* (n_upts,n_eles,n_fields); zero unless uploaded */
   HFX_DT_LOCAL = 11,      /* (n_eles) */
   HFX_SENSOR = 12,        /* (n_eles) eles::sensor, written by hfx_eles_shock_capture */
-  HFX_N_ARRAYS = 13
+  HFX_SGSF_UPTS = 13,     /* (n_upts,n_eles,n_fields,n_dims) LES: transformed SGS flux (allocated by hfx_eles_set_les) */
+  HFX_SGSF_FPTS = 14,     /* (n_fpts,n_eles,n_fields,n_dims) LES: physical SGS flux at the flux points */
+  HFX_N_ARRAYS = 15
 };
 
 /* which implementation the operator contractions use */
@@ -171,6 +173,22 @@ int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f);
 int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
+
+/* ---- LES sub-grid closure (8f-4) ----------------------------------------- */
+/* run_input.LES == 1 with an eddy-viscosity model (src/eles.cpp:2395-2650): sgs_model 0 Smagorinsky with near-wall
+ * damping (wall_distance (n_upts,n_eles,n_dims), eles::calc_wall_distance), 1 WALE.  Jacobian_fpts
+ * (n_dims,n_dims,n_fpts,n_eles) is what extrapolate_sgsFlux uses to take the flux back to physical space
+ * (src/eles.cpp:2862-2893).  Once set, evaluate_viscFlux adds the SGS flux, hfx_CalcResidual calls
+ * extrapolate_sgsFlux (src/solver.cpp:162-167) and interior faces add sgsf_fpts to both sides' viscous flux
+ * (src/int_inters.cpp:302-318).  Similarity / SVV models (2-4), the wall model and partition faces with LES are
+ * not built and are refused. */
+typedef struct hfx_les
+{
+  int sgs_model, pad;
+  double C_s, filter_ratio, Kappa, prandtl_t;
+} hfx_les;
+int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distance, const double *Jacobian_fpts);
+int hfx_eles_extrapolate_sgsFlux(hfx_eles *e); /* eles::extrapolate_sgsFlux, src/eles.cpp:2817 */
 
 /* ---- integral diagnostics (8f-1: the TGV monitors) ------------------------ */
 /* opp_volume_cubpts (n_cubpts,n_upts), weight_volume_cubpts (n_cubpts), vol_detjac_vol_cubpts (n_cubpts,n_eles):

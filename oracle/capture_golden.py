@@ -102,6 +102,11 @@ CASES = [
     case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
     case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
     case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+    # LES eddy-viscosity closures: WALE on a periodic box, Smagorinsky with wall damping between two walls
+    case("hex_p2_les_wale", amp=0.15, level=2, order=2, steps=1, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0),
+    case("hex_p2_les_smag", amp=0.1, level=2, order=2, steps=1, LES=1, SGS_model=0, C_s=0.17, filter_ratio=1.5,
+         bcs={"y-": "WallT", "y+": "WallQ"}, **BC_KEYS),
+    case("quad_p3_les_wale", dims=2, n=4, amp=0.1, level=2, order=3, steps=1, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0),
     # the ASCII restart file of the final state (on-disk format either side of the path)
     case("hex_p2_restart", amp=0.15, level=0, order=2, steps=1, restart=True),
     case("quad_p3_restart", dims=2, n=4, amp=0.1, level=0, order=3, steps=1, restart=True),

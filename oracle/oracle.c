@@ -535,12 +535,147 @@ void orc_evaluate_viscFlux(orc_eles *e, const orc_params *P)
       }
       orc_calc_visf(nd, P, u, g, f);
       const double *JG = e->JGinv_upts + (long)nd * nd * (j + (long)nu * i);
+      if (e->sgs_model >= 0 && e->sgsf_upts)
+      {
+        /* src/eles.cpp:2322-2348 */
+        double sg[MAXF * MAXD];
+        orc_calc_sgsf_upts(e, P, u, g, e->detjac_upts[j + (long)nu * i], i, j, sg);
+        for (int q = 0; q < nf * nd; q++) f[q] += 1.0 * sg[q]; /* daxpy */
+        for (int k = 0; k < nf; k++)
+          for (int l = 0; l < nd; l++)
+          {
+            double t = 0.0;
+            for (int m = 0; m < nd; m++) t += JG[l + nd * m] * sg[k + nf * m];
+            e->sgsf_upts[j + (long)nu * (i + (long)ne * (k + (long)nf * l))] = t;
+          }
+      }
       for (int k = 0; k < nf; k++)
         for (int l = 0; l < nd; l++)
         {
           double *t = &e->tdisf_upts[j + (long)nu * (i + (long)ne * (k + (long)nf * l))];
           for (int m = 0; m < nd; m++) *t += JG[l + nd * m] * f[k + nf * m];
         }
+    }
+}
+
+/* eles::calc_sgsf_upts, src/eles.cpp:2395-2650: sgs_model 0 (Smagorinsky, wall-damped) and 1 (WALE); f(k,m) = f[k + nf*m] */
+void orc_calc_sgsf_upts(const orc_eles *e, const orc_params *P, const double *temp_u, const double *temp_grad_u, double detjac,
+                        int ele, int upt, double *temp_sgsf)
+{
+  const int nd = e->n_dims, nf = e->n_fields, nu = e->n_upts, ne = e->n_eles;
+  double u[MAXD], drho[MAXD], dene[MAXD], dke[MAXD], de[MAXD], dmom[MAXD][MAXD], du[MAXD][MAXD], S[MAXD][MAXD];
+  double y = 0.0, mu_t = 0.0, diag;
+  const double rho = temp_u[0];
+  double ke = 0.;
+  for (int i = 0; i < nd; i++)
+  {
+    u[i] = temp_u[i + 1] / rho;
+    ke += 0.5 * pow(u[i], 2);
+  }
+  const double inte = temp_u[nf - 1] / rho - ke;
+  if (e->sgs_model == 0)
+  {
+    for (int i = 0; i < nd; i++)
+    {
+      const double w = e->wall_distance[upt + (long)nu * (ele + (long)ne * i)];
+      y += w * w;
+    }
+    y = sqrt(y);
+  }
+  for (int q = 0; q < nf * nd; q++) temp_sgsf[q] = 0.0;
+  const double vol = detjac * (nd == 3 ? 8. : 4.); /* calc_ele_vol of hexes / quads */
+  const double delta = e->filter_ratio * pow(vol, 1. / nd) / (e->order + 1.);
+  for (int i = 0; i < nd; i++)
+  {
+    drho[i] = temp_grad_u[0 + nf * i];
+    dene[i] = temp_grad_u[(nf - 1) + nf * i];
+    for (int j = 1; j < nf - 1; j++) dmom[i][j - 1] = temp_grad_u[j + nf * i];
+  }
+  for (int i = 0; i < nd; i++)
+  {
+    dke[i] = ke * drho[i];
+    for (int j = 0; j < nd; j++)
+    {
+      du[i][j] = (dmom[i][j] - u[j] * drho[i]) / rho;
+      dke[i] += rho * u[j] * du[i][j];
+    }
+    de[i] = (dene[i] - dke[i] - drho[i] * inte) / rho;
+  }
+  for (int i = 0; i < nd; i++)
+    for (int j = 0; j < nd; j++) S[i][j] = (du[i][j] + du[j][i]) / 2.0;
+  if (e->sgs_model == 0)
+  {
+    double Smod = 0.0;
+    for (int i = 0; i < nd; i++)
+      for (int j = 0; j < nd; j++) Smod += 2.0 * S[i][j] * S[i][j];
+    Smod = sqrt(Smod);
+    mu_t = rho * fmin(y * y * e->Kappa * e->Kappa, e->C_s * e->C_s * delta * delta) * Smod;
+  }
+  else
+  {
+    double num = 0.0, denom = 0.0;
+    const double eps = 1.e-12;
+    double Sq[MAXD][MAXD], gT[MAXD][MAXD]; /* gT = du*du (column-major dgemm of the (i,j)-stored arrays), g = gT^T */
+    for (int i = 0; i < nd; i++)
+      for (int j = 0; j < nd; j++)
+      {
+        /* hf_array du(i,j) is column-major: dgemm(A=du,B=du) gives C(i,j) = sum_l du(i,l) du(l,j) */
+        double s = 0.;
+        for (int l = 0; l < nd; l++) s += du[i][l] * du[l][j];
+        gT[i][j] = s;
+      }
+    for (int i = 0; i < nd; i++)
+      for (int j = 0; j < nd; j++)
+      {
+        Sq[i][j] = 0.;
+        Sq[i][j] += 0.5 * gT[j][i]; /* g_bar = transpose */
+        Sq[i][j] += 0.5 * gT[i][j];
+      }
+    diag = 0.0;
+    for (int i = 0; i < nd; i++) diag += gT[i][i] / 3.0;
+    for (int i = 0; i < nd; i++) Sq[i][i] -= diag;
+    for (int i = 0; i < nd; i++)
+      for (int j = 0; j < nd; j++)
+      {
+        num += Sq[i][j] * Sq[i][j];
+        denom += S[i][j] * S[i][j];
+      }
+    denom = pow(denom, 2.5) + pow(num, 1.25);
+    num = pow(num, 1.5);
+    mu_t = rho * e->C_s * e->C_s * delta * delta * num / (denom + eps);
+  }
+  diag = 0.;
+  for (int i = 0; i < nd; i++) diag += S[i][i] / 3.0;
+  for (int i = 0; i < nd; i++) S[i][i] -= diag;
+  for (int j = 0; j < nd; j++)
+  {
+    temp_sgsf[0 + nf * j] = 0.0;
+    temp_sgsf[(nf - 1) + nf * j] = -1.0 * P->gamma * mu_t / e->prandtl_t * de[j];
+    for (int k = 0; k < nd; k++) temp_sgsf[(nf - 1) + nf * j] -= u[k] * 2.0 * mu_t * S[k][j];
+    for (int i = 1; i < nf - 1; i++) temp_sgsf[i + nf * j] = -2.0 * mu_t * S[i - 1][j];
+  }
+}
+
+/* src/eles.cpp:2817-2910 : sgsf_fpts(:,:,:,d) = opp_0 * sgsf_upts(:,:,:,d) */
+void orc_extrapolate_sgsFlux(orc_eles *e)
+{
+  if (e->n_eles == 0) return;
+  const long su = (long)e->n_upts * e->n_eles * e->n_fields, sf = (long)e->n_fpts * e->n_eles * e->n_fields;
+  for (int d = 0; d < e->n_dims; d++)
+    orc_dgemm(e->n_fpts, e->n_fields * e->n_eles, e->n_upts, 1.0, 0.0, e->opp_0, e->sgsf_upts + d * su, e->sgsf_fpts + d * sf);
+  /* transform back to the physical domain: f = |J|^-1 * J * F (:2862-2893) */
+  const int nd = e->n_dims, nf = e->n_fields, nfp = e->n_fpts, ne = e->n_eles;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j < nfp; j++)
+    {
+      const double inv_detjac = 1.0 / e->detjac_fpts[j + (long)nfp * i];
+      double ts[MAXD * MAXF], ps[MAXD * MAXF];
+      for (int k = 0; k < nf; k++)
+        for (int d = 0; d < nd; d++) ts[d + nd * k] = e->sgsf_fpts[j + (long)nfp * (i + (long)ne * (k + (long)nf * d))];
+      orc_dgemm(nd, nf, nd, inv_detjac, 0.0, e->Jacobian_fpts + (long)nd * nd * (j + (long)nfp * i), ts, ps);
+      for (int k = 0; k < nf; k++)
+        for (int d = 0; d < nd; d++) e->sgsf_fpts[j + (long)nfp * (i + (long)ne * (k + (long)nf * d))] = ps[d + nd * k];
     }
 }
 
@@ -764,6 +899,13 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, con
         }
       orc_calc_visf(nd, P, ul, gl, fl);
       orc_calc_visf(nd, P, ur, gr, fr);
+      if (e->sgs_model >= 0 && e->sgsf_fpts) /* src/int_inters.cpp:302-318 */
+        for (int k = 0; k < nd; k++)
+          for (int l = 0; l < nf; l++)
+          {
+            fl[l + nf * k] += e->sgsf_fpts[il + (l + (long)nf * k) * plane];
+            fr[l + nf * k] += e->sgsf_fpts[ir + (l + (long)nf * k) * plane];
+          }
       for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
       orc_ldg_flux(0, nd, ul, ur, fl, fr, norm, fn, P->ldg_tau, P->ldg_beta);
       for (int k = 0; k < nf; k++)
@@ -1427,6 +1569,7 @@ long orc_CalcResidual_bdy(orc_eles *e, const orc_int_inters *faces, int n_face_b
   {
     orc_correct_gradient(e);
     orc_evaluate_viscFlux(e, P);
+    if (e->sgs_model >= 0 && e->sgsf_upts) orc_extrapolate_sgsFlux(e); /* src/solver.cpp:162-167 */
   }
   orc_extrapolate_totalFlux(e);
   orc_calculate_divergence(e);

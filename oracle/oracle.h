@@ -64,6 +64,14 @@ typedef struct orc_eles
   double *grad_disu_fpts;  /* (n_fpts,n_eles,n_fields,n_dims) */
   const double *src_upts;  /* (n_upts,n_eles,n_fields) or NULL (= 0) */
   const double *dt_local;  /* (n_eles) or NULL */
+  /* LES eddy-viscosity closure (run_input.LES): sgs_model < 0 = off; 0 Smagorinsky (wall_distance), 1 WALE */
+  int sgs_model;
+  double C_s, filter_ratio, Kappa, prandtl_t;
+  int order;                   /* run_input.order (filter width) */
+  const double *wall_distance; /* (n_upts,n_eles,n_dims), model 0 */
+  double *sgsf_upts;           /* (n_upts,n_eles,n_fields,n_dims) */
+  double *sgsf_fpts;           /* (n_fpts,n_eles,n_fields,n_dims) */
+  const double *Jacobian_fpts; /* (n_dims,n_dims,n_fpts,n_eles): extrapolate_sgsFlux takes the flux back to physical space */
   /* over-integration (run_input.over_int): n_cub 0 = off */
   int n_cub;
   const double *opp_over_int_cubpts;   /* (n_cub,n_upts) */
@@ -180,6 +188,10 @@ void orc_evaluate_invFlux_over_int(orc_eles *e, const orc_params *p, int n_cub, 
 void orc_CalcIntegralQuantities(const orc_eles *e, const orc_params *p, int n_cub, const double *opp_volume_cubpts,
                                 const double *weight_volume_cubpts, const double *vol_detjac_vol_cubpts, int n_q,
                                 const int *ids, double *out);
+/* LES: eles::calc_sgsf_upts (src/eles.cpp:2395-2650, eddy-viscosity models 0 and 1) and extrapolate_sgsFlux (:2817) */
+void orc_calc_sgsf_upts(const orc_eles *e, const orc_params *p, const double *u, const double *grad_u, double detjac, int ele,
+                        int upt, double *sgsf);
+void orc_extrapolate_sgsFlux(orc_eles *e);
 void orc_shock_capture(orc_eles *e, const orc_shock *s); /* eles::shock_capture, shock_cap 1 + shock_det 0 */
 
 /* boundary faces, src/bdy_inters.cpp (wall model, LES inlet, RANS off) */

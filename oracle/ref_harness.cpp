@@ -292,6 +292,18 @@ int main(int argc, char *argv[])
       put_scalar("ramp_counter", run_input.ramp_counter);
     }
   }
+  // LES closure (src/eles.cpp:2395-2650)
+  if (run_input.LES)
+  {
+    put_scalar("LES", run_input.LES);
+    put_scalar("SGS_model", run_input.SGS_model);
+    put_scalar("C_s", run_input.C_s);
+    put_scalar("filter_ratio", run_input.filter_ratio);
+    put_scalar("Kappa", run_input.Kappa);
+    put_scalar("prandtl_t", run_input.prandtl_t);
+    if (run_input.SGS_model == 0) put_arr("wall_distance", E->wall_distance);
+    put_arr("Jacobian_fpts", E->Jacobian_fpts); // used by extrapolate_sgsFlux to take the SGS flux back to physical space
+  }
   // integral diagnostics (src/eles.cpp:5485-5627): volume cubature interpolation, weights, Jacobians
   if (run_input.n_integral_quantities != 0)
   {
@@ -414,6 +426,16 @@ int main(int argc, char *argv[])
           }
           for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->evaluate_viscFlux();
           if (level >= 2) put_arr("s0_tdisf_upts", E->tdisf_upts);
+          if (run_input.LES)
+          {
+            // src/solver.cpp:162-167
+            for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->extrapolate_sgsFlux();
+            if (level >= 2)
+            {
+              put_arr("s0_sgsf_upts", E->sgsf_upts);
+              put_arr("s0_sgsf_fpts", E->sgsf_fpts);
+            }
+          }
         }
         for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->extrapolate_totalFlux();
         if (level >= 2) put_arr("s0_norm_tdisf_fpts", E->norm_tdisf_fpts);

@@ -29,6 +29,8 @@ class Eles(C.Structure):
         ("disu_upts", dp * 2), ("disu_fpts", dp), ("tdisf_upts", dp), ("norm_tdisf_fpts", dp),
         ("norm_tconf_fpts", dp), ("div_tconf_upts", dp), ("delta_disu_fpts", dp),
         ("grad_disu_upts", dp), ("grad_disu_fpts", dp), ("src_upts", dp), ("dt_local", dp),
+        ("sgs_model", C.c_int), ("C_s", C.c_double), ("filter_ratio", C.c_double), ("Kappa", C.c_double),
+        ("prandtl_t", C.c_double), ("order_les", C.c_int), ("wall_distance", dp), ("sgsf_upts", dp), ("sgsf_fpts", dp), ("Jacobian_fpts", dp),
         ("n_cub", C.c_int), ("opp_over_int_cubpts", dp), ("over_int_filter", dp), ("JGinv_over_int_cubpts", dp)]
 
 
@@ -144,6 +146,17 @@ class Case:
                 L = np.asfortranarray(np.array(data["int%d_L" % t], dtype=np.int32))
                 R = np.asfortranarray(np.array(data["int%d_R" % t], dtype=np.int32))
                 self.faces.append((L, R))
+        # LES closure
+        self.les = None
+        if "LES" in data and int(np.ravel(data["LES"])[0]):
+            sc = lambda k: float(np.ravel(data[k])[0])
+            self.les = dict(sgs_model=int(sc("SGS_model")), C_s=sc("C_s"), filter_ratio=sc("filter_ratio"), Kappa=sc("Kappa"),
+                            prandtl_t=sc("prandtl_t"))
+            self.arr["sgsf_upts"] = F((nu, ne, nf, nd))
+            self.arr["sgsf_fpts"] = F((nfp, ne, nf, nd))
+            if self.les["sgs_model"] == 0:
+                self.arr["wall_distance"] = g("wall_distance")
+            self.arr["Jacobian_fpts"] = g("Jacobian_fpts")
         # over-integration
         self.n_cub = 0
         if "over_int" in data and int(np.ravel(data["over_int"])[0]):
@@ -201,6 +214,15 @@ class Case:
                   "delta_disu_fpts", "grad_disu_upts", "grad_disu_fpts"):
             setattr(e, k, fptr(a[k]))
         e.disu_upts[0] = fptr(a["u0"]); e.disu_upts[1] = fptr(a["u1"])
+        e.sgs_model = -1
+        if self.les:
+            e.sgs_model = self.les["sgs_model"]
+            e.C_s, e.filter_ratio, e.Kappa, e.prandtl_t = (self.les[k] for k in ("C_s", "filter_ratio", "Kappa", "prandtl_t"))
+            e.order_les = self.order
+            e.sgsf_upts, e.sgsf_fpts = fptr(a["sgsf_upts"]), fptr(a["sgsf_fpts"])
+            e.Jacobian_fpts = fptr(a["Jacobian_fpts"])
+            if e.sgs_model == 0:
+                e.wall_distance = fptr(a["wall_distance"])
         e.n_cub = self.n_cub
         if self.n_cub:
             for k in ("opp_over_int_cubpts", "over_int_filter", "JGinv_over_int_cubpts"):

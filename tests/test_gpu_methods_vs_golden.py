@@ -19,7 +19,8 @@ import oracle_py as O
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+# the restart fixtures hold a state file only (tests/test_restart_io.py)
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "restart" not in p)
 BDY = [n for n in ALL if "bdy" in n]
 RTOL1 = 1e-12
 # div_tconf is a difference of terms ~1e3 times larger than itself (pressure-dominated energy
@@ -54,6 +55,10 @@ def build(ctx, d, mode=hfx.CONTRACT_AUTO):
             faces.append(hfx.BdyInters(ctx, e, d["bdy%d_L" % t], d["bdy%d_id" % t],
                                        hfx.bc_records(d["bc_flags"], d["bc_params"]),
                                        float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
+    if "LES" in d and int(np.ravel(d["LES"])[0]):
+        sc = lambda k: float(np.ravel(d[k])[0])
+        e.set_les(int(sc("SGS_model")), sc("C_s"), sc("filter_ratio"), sc("Kappa"), sc("prandtl_t"), d["Jacobian_fpts"],
+                  d["wall_distance"] if "wall_distance" in d else None)
     if "over_int" in d and int(np.ravel(d["over_int"])[0]):
         e.set_over_int(d["opp_over_int_cubpts"], d["over_int_filter"], d["JGinv_over_int_cubpts"])
     if "shock_cap" in d and int(np.ravel(d["shock_cap"])[0]):
@@ -111,6 +116,21 @@ def test_over_integration_flux(ctx, name):
     e, faces = build(ctx, d)
     e.evaluate_invFlux_over_int()
     assert relerr(e.download(hfx.TDISF_UPTS), d["s0_tdisf_upts_inv"]) < RTOL1
+    for f in faces:
+        f.close()
+    e.close()
+
+
+@pytest.mark.parametrize("name", [n for n in ALL if "_les_" in n])
+def test_les_intermediates(ctx, name):
+    """LES eddy-viscosity closure on the device: SGS flux at solution and flux points, total flux, residual."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e, faces = build(ctx, d)
+    hfx.CalcResidual(e, faces)
+    assert relerr(e.download(hfx.SGSF_UPTS), d["s0_sgsf_upts"]) < 1e-11
+    assert relerr(e.download(hfx.SGSF_FPTS), d["s0_sgsf_fpts"]) < 1e-11
+    assert relerr(e.download(hfx.TDISF_UPTS), d["s0_tdisf_upts"]) < RTOL1
+    assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOLD
     for f in faces:
         f.close()
     e.close()

@@ -198,3 +198,21 @@ def test_integral_quantities(oracle, name):
                                       O.fptr(dj), C.c_int(len(ids)), ids.ctypes.data_as(O.ip), out.ctypes.data_as(O.dp))
     want = np.ravel(d["s0_integral_quantities"])
     assert np.all(np.abs(out - want) <= 1e-12 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("name", [n for n in ALL if "_les_" in n])
+def test_les_intermediates(oracle, name):
+    """LES eddy-viscosity closure: SGS flux at the solution points (added to the viscous flux), its extrapolation,
+    and the common viscous flux that carries it across the faces."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c = O.Case(d)
+    assert c.les is not None
+    e = c.c_eles()
+    f, nfb = c.c_faces()
+    bd, nbd = c.c_bdy()
+    assert oracle.orc_CalcResidual_bdy(C.byref(e), f, nfb, bd, nbd, C.byref(c.params)) == -1
+    # pow() of two libm builds in the WALE formula: a few ulps
+    assert relerr(c.arr["sgsf_upts"], d["s0_sgsf_upts"]) < 1e-12
+    assert relerr(c.arr["sgsf_fpts"], d["s0_sgsf_fpts"]) < 1e-12
+    assert relerr(c.arr["tdisf_upts"], d["s0_tdisf_upts"]) < 1e-13
+    assert relerr(c.arr["div_tconf_upts"], d["s0_div_tconf_upts"]) < 1e-12
