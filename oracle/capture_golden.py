@@ -24,7 +24,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
-from gen_neu_mesh import write_neu  # noqa: E402
+from gen_neu_mesh import write_neu, write_neu_tets, write_neu_prisms  # noqa: E402
 
 REF_HOME = os.environ.get("HIFILES_HOME", "/root/reference")
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
@@ -54,10 +54,10 @@ BASE = dict(
 BASE.update(TGV_FLUID)
 
 
-def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, **over):
+def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, tets=False, **over):
     d = dict(BASE)
     d.update(over)
-    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs, restart=restart)
+    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs, restart=restart, tets=tets)
 
 
 # boundary groups for the bdy_inters fixtures: states near the TGV initial state (rho 8.42e-4, T 300, Mach 0.1)
@@ -102,6 +102,12 @@ CASES = [
     case("hex_p2_sd", amp=0.1, order=2, vcjh_scheme_hexa=2),
     case("hex_p2_lobatto", amp=0.1, order=2, upts_type_hexa=1),
     case("hex_p3_n3_deformed", amp=0.15, level=1, order=3, steps=1),
+    # tetrahedra (BASELINE.json configs[3]'s element family): non-tensor-product operators, triangular faces
+    case("tet_p2_n2_deformed", n=2, amp=0.1, level=2, order=2, steps=1, tets=True,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p2_n2_deformed", n=2, amp=0.1, level=2, order=2, steps=1, tets="prisms",
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
+         vcjh_scheme_tri=1, c_tri=0.0),
     # LES eddy-viscosity closures: WALE on a periodic box, Smagorinsky with wall damping between two walls
     case("hex_p2_les_wale", amp=0.15, level=2, order=2, steps=1, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0),
     case("hex_p2_les_smag", amp=0.1, level=2, order=2, steps=1, LES=1, SGS_model=0, C_s=0.17, filter_ratio=1.5,
@@ -169,7 +175,12 @@ def read_dump(path):
 
 def run_case(c):
     with tempfile.TemporaryDirectory() as td:
-        xv = write_neu(os.path.join(td, "mesh.neu"), c["n"], c["dims"], amp=c["amp"], bcs=c.get("bcs"))
+        if c.get("tets") == "prisms":
+            xv = write_neu_prisms(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])
+        elif c.get("tets"):
+            xv = write_neu_tets(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])
+        else:
+            xv = write_neu(os.path.join(td, "mesh.neu"), c["n"], c["dims"], amp=c["amp"], bcs=c.get("bcs"))
         keys = dict(c["keys"])
         keys["n_steps"] = c["steps"]
         if c["dims"] == 2:

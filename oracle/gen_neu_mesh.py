@@ -142,6 +142,139 @@ def write_neu(path, n, dims=3, length=2.0 * math.pi, amp=0.0, bcname="Cyclic", b
     return xv
 
 
+def write_neu_tets(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
+    """Periodic box of tetrahedra: every cube of the n^3 grid is cut into the 6 Kuhn tetrahedra (one per ordering
+    of the axes, all sharing the cube's main diagonal), which makes the triangulation conforming across cubes and
+    across the periodic images.  Gambit tets are element type 6 with 4 nodes; the reference's local faces are
+    f0 (1,2,3), f1 (0,3,2), f2 (0,1,3), f3 (0,2,1) (src/mesh.cpp get_corner_vlist_face) and its reader maps the
+    Gambit face number k to them as 1->3, 2->2, 3->0, 4->1 (src/mesh_reader.cpp:353-363)."""
+    import itertools
+    if isinstance(n, int):
+        n = [n] * 3
+    xv = box_vertices(n, 3, length, amp)
+    nx, ny, nz = n
+    nv = xv.shape[0]
+
+    def vid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    tets = []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                for perm in itertools.permutations(range(3)):
+                    p = [i, j, k]
+                    v = [vid(*p)]
+                    for a in perm:
+                        p[a] += 1
+                        v.append(vid(*p))
+                    # positive volume with the reference tet (-1,-1,-1),(1,-1,-1),(-1,1,-1),(-1,-1,1)
+                    x = xv[v]
+                    if np.linalg.det(np.stack([x[1] - x[0], x[2] - x[0], x[3] - x[0]])) < 0:
+                        v[1], v[2] = v[2], v[1]
+                    tets.append(v)
+    faces_loc = [(1, 2, 3), (0, 3, 2), (0, 1, 3), (0, 2, 1)]
+    to_k = {0: 3, 1: 4, 2: 2, 3: 1}
+    # lattice coordinates of every vertex to spot faces on the box boundary
+    lat = np.zeros((nv, 3), dtype=int)
+    for k in range(nz + 1):
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                lat[vid(i, j, k)] = (i, j, k)
+    bfaces = []
+    for e, v in enumerate(tets):
+        for f, fl in enumerate(faces_loc):
+            c = lat[[v[q] for q in fl]]
+            for d in range(3):
+                if (c[:, d] == 0).all() or (c[:, d] == n[d]).all():
+                    bfaces.append((e + 1, 6, to_k[f]))
+    ne = len(tets)
+    with open(path, "w") as f:
+        f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\nperiodic_box_tets\n")
+        f.write("PROGRAM:                Gambit     VERSION:  2.3.16\n\n")
+        f.write("     NUMNP     NELEM     NGRPS    NBSETS     NDFCD     NDFVL\n")
+        f.write("%10d%10d%10d%10d%10d%10d\n" % (nv, ne, 1, 1, 3, 3))
+        f.write("ENDOFSECTION\n   NODAL COORDINATES 2.3.16\n")
+        for i in range(nv):
+            f.write("%10d" % (i + 1) + "".join(" %.17e" % c for c in xv[i]) + "\n")
+        f.write("ENDOFSECTION\n      ELEMENTS/CELLS 2.3.16\n")
+        for e, v in enumerate(tets):
+            f.write("%8d %2d %2d " % (e + 1, 6, 4) + "".join("%8d" % (q + 1) for q in v) + "\n")
+        f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
+        f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n" % (1, ne, 2, 1))
+        f.write("                           fluid\n       0\n")
+        ids = list(range(1, ne + 1))
+        for s0 in range(0, ne, 10):
+            f.write("".join("%8d" % q for q in ids[s0:s0 + 10]) + "\n")
+        f.write("ENDOFSECTION\n BOUNDARY CONDITIONS 2.3.16\n")
+        f.write("%32s%8d%8d%8d%8d\n" % (bcname, 1, len(bfaces), 0, 6))
+        for (el, ty, fc) in bfaces:
+            f.write("%10d%5d%5d\n" % (el, ty, fc))
+        f.write("ENDOFSECTION\n")
+    return xv
+
+
+def write_neu_prisms(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
+    """Periodic box of triangular prisms: every cube is cut along the (x,y) diagonal into two prisms extruded in z.
+    Gambit prisms are element type 5 with 6 nodes (0,1,2 bottom triangle, 3,4,5 above them); local faces f0 (0,2,1),
+    f1 (3,4,5), f2 (0,1,4,3), f3 (1,2,5,4), f4 (2,0,3,5) (src/mesh.cpp get_corner_vlist_face); Gambit face k maps to
+    them as 1->2, 2->3, 3->4, 4->0, 5->1 (src/mesh_reader.cpp:364-375)."""
+    if isinstance(n, int):
+        n = [n] * 3
+    xv = box_vertices(n, 3, length, amp)
+    nx, ny, nz = n
+    nv = xv.shape[0]
+
+    def vid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    pris = []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                for tri in (((0, 0), (1, 0), (1, 1)), ((0, 0), (1, 1), (0, 1))):  # counter-clockwise seen from +z
+                    v = [vid(i + a, j + b, k) for a, b in tri] + [vid(i + a, j + b, k + 1) for a, b in tri]
+                    pris.append(v)
+    faces_loc = [(0, 2, 1), (3, 4, 5), (0, 1, 4, 3), (1, 2, 5, 4), (2, 0, 3, 5)]
+    to_k = {2: 1, 3: 2, 4: 3, 0: 4, 1: 5}
+    lat = np.zeros((nv, 3), dtype=int)
+    for k in range(nz + 1):
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                lat[vid(i, j, k)] = (i, j, k)
+    bfaces = []
+    for e, v in enumerate(pris):
+        for f, fl in enumerate(faces_loc):
+            c = lat[[v[q] for q in fl]]
+            for d in range(3):
+                if (c[:, d] == 0).all() or (c[:, d] == n[d]).all():
+                    bfaces.append((e + 1, 5, to_k[f]))
+    ne = len(pris)
+    with open(path, "w") as f:
+        f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\nperiodic_box_prisms\n")
+        f.write("PROGRAM:                Gambit     VERSION:  2.3.16\n\n")
+        f.write("     NUMNP     NELEM     NGRPS    NBSETS     NDFCD     NDFVL\n")
+        f.write("%10d%10d%10d%10d%10d%10d\n" % (nv, ne, 1, 1, 3, 3))
+        f.write("ENDOFSECTION\n   NODAL COORDINATES 2.3.16\n")
+        for i in range(nv):
+            f.write("%10d" % (i + 1) + "".join(" %.17e" % c for c in xv[i]) + "\n")
+        f.write("ENDOFSECTION\n      ELEMENTS/CELLS 2.3.16\n")
+        for e, v in enumerate(pris):
+            f.write("%8d %2d %2d " % (e + 1, 5, 6) + "".join("%8d" % (q + 1) for q in v) + "\n")
+        f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
+        f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n" % (1, ne, 2, 1))
+        f.write("                           fluid\n       0\n")
+        ids = list(range(1, ne + 1))
+        for s0 in range(0, ne, 10):
+            f.write("".join("%8d" % q for q in ids[s0:s0 + 10]) + "\n")
+        f.write("ENDOFSECTION\n BOUNDARY CONDITIONS 2.3.16\n")
+        f.write("%32s%8d%8d%8d%8d\n" % (bcname, 1, len(bfaces), 0, 6))
+        for (el, ty, fc) in bfaces:
+            f.write("%10d%5d%5d\n" % (el, ty, fc))
+        f.write("ENDOFSECTION\n")
+    return xv
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
