@@ -140,7 +140,27 @@ def main():
         import exchange
         if args.mode not in ("auto", "split", "split3", "methods"):
             raise SystemExit("N>1 runs the split fused path or the per-method path")
-        ex = exchange.for_case(case, device=torch.device("cuda", local_rank), projected_flux=args.mode in ("auto", "split3"))
+        pf = args.mode in ("auto", "split3")
+        dev = torch.device("cuda", local_rank)
+        transport = dist.get_backend()
+        ex = exchange.for_case(case, device=dev, projected_flux=pf)
+        if transport == "nccl":
+            # one trial exchange on RCCL; if any rank fails, every rank falls back to the host-staged gloo exchange
+            # (slower, still correct) instead of losing the run
+            gloo = dist.new_group(backend="gloo")
+            ok = 1
+            try:
+                ex(0, 0); ex(0, 1)
+                torch.cuda.synchronize()
+            except Exception as err:  # noqa: BLE001
+                sys.stderr.write("rank %d: RCCL partition-face exchange failed (%s); falling back to gloo\n" % (rank, err))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
+            if int(flag.item()) == 0:
+                ex.close()
+                ex = exchange.for_case(case, group=gloo, device=dev, projected_flux=pf)
+                transport = "gloo (fallback, host staged)"
         case.set_exchange(ex)
 
     mode = args.mode
@@ -271,7 +291,7 @@ def main():
                        "n_eles_per_gpu": case.n_eles, "dof_per_gpu": dof_per_rank, "path": mode,
                        "multi_gpu": "none" if world == 1 else
                        "one periodic box split into %s blocks, partition-face exchange over %s p2p" %
-                       ("x".join(map(str, pgrid)), "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")},
+                       ("x".join(map(str, pgrid)), "RCCL" if transport == "nccl" else transport + (" (rehearsal)" if "fallback" not in transport else ""))},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
