@@ -222,15 +222,30 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
         acc[s][rg] = (a.beta && row_ok && ocol < ncl) ? a.C[(c0 + ocol) * m + row] : 0.0;
       }
     }
-    for (int kb = 0; kb < kpad; kb += 4)
+    // the operator fragments of UK k-steps are fetched together (L2-resident A, one latency per UK MFMA groups)
+    constexpr int UK = 8;
+    for (int kb = 0; kb < kpad; kb += 4 * UK)
     {
-      const int kk = kb + lk;
-      const double av = (row_ok && kk < k) ? a.A[row + (long)m * kk] : 0.0;
+      double av[UK];
 #pragma unroll
-      for (int s = 0; s < NS; s++)
+      for (int u = 0; u < UK; u++)
       {
-        const double bv = btile[kk * LDB + s * 16 + li];
-        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[s], 0, 0, 0);
+        const int kk = kb + 4 * u + lk;
+        av[u] = (row_ok && kk < k) ? a.A[row + (long)m * kk] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < UK; u++)
+      {
+        const int kk = kb + 4 * u + lk;
+        if (kb + 4 * u < kpad)
+        {
+#pragma unroll
+          for (int s = 0; s < NS; s++)
+          {
+            const double bv = btile[kk * LDB + s * 16 + li];
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av[u], acc[s], 0, 0, 0);
+          }
+        }
       }
     }
 #pragma unroll
