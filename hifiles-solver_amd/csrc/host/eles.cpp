@@ -293,7 +293,27 @@ int eles::set_ics(double &time)
     for (int j = 0; j < n_upts_per_ele; j++)
     {
       for (int k = 0; k < n_dims; k++) pos(k) = pos_upts(j, i, k);
-      if (run_input->ic_form == 1) // uniform flow, src/eles.cpp:284-316
+      if (run_input->ic_form == 0) // isentropic vortex (BASELINE.json configs[0]), src/eles.cpp:261-280 + src/funcs.cpp:1724-1739
+      {
+        const double pi = 3.141592653589793, ev_eps_ic = 5.0;
+        const double x = pos(0) - time, y = pos(1) - time;
+        const double f = 1.0 - (x * x + y * y);
+        const double rho = std::pow(1.0 - ev_eps_ic * ev_eps_ic * (gamma - 1.0) / (8.0 * gamma * pi * pi) * std::exp(f), 1.0 / (gamma - 1.0));
+        const double vx = 1. - ev_eps_ic * y / (2.0 * pi) * std::exp(f / 2.0);
+        const double vy = 1. + ev_eps_ic * x / (2.0 * pi) * std::exp(f / 2.0);
+        const double vz = 0., p = std::pow(rho, gamma);
+        ics(0) = rho;
+        ics(1) = rho * vx;
+        ics(2) = rho * vy;
+        if (n_dims == 2)
+          ics(3) = (p / (gamma - 1.0)) + (0.5 * rho * ((vx * vx) + (vy * vy)));
+        else
+        {
+          ics(3) = rho * vz;
+          ics(4) = (p / (gamma - 1.0)) + (0.5 * rho * ((vx * vx) + (vy * vy) + (vz * vz)));
+        }
+      }
+      else if (run_input->ic_form == 1) // uniform flow, src/eles.cpp:284-316
       {
         const double rho = run_input->rho_c_ic, vx = run_input->u_c_ic, vy = run_input->v_c_ic, vz = run_input->w_c_ic;
         const double p = run_input->p_c_ic;
@@ -334,7 +354,7 @@ int eles::set_ics(double &time)
       }
       else
       {
-        fail("ERROR: Invalid form of initial condition ... (this build: ic_form 1 and 7)");
+        fail("ERROR: Invalid form of initial condition ... (this build: ic_form 0, 1 and 7)");
         return 1;
       }
       for (int k = 0; k < n_fields; k++) disu_upts(0)(j, i, k) = ics(k);

@@ -186,3 +186,20 @@ def test_cfl_time_stepping_through_the_mirror(name, dt_type):
     last = int(d["sizes"][7]) - 1
     assert rel(c.array("disu_upts0"), d["u_step1_stage%d" % last]) < 1e-11
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["methods", 3])
+def test_isentropic_vortex_through_the_mirror(mode):
+    """BASELINE.json configs[0] (reduced mesh): inviscid vortex on quads, Rusanov, RK45, through the mirror."""
+    d = dict(np.load(os.path.join(GOLDEN, "quad_p3_vortex.npz")))
+    c = H.Case([6, 6, 1], xv=d["xv"], dims=2, order=3, viscous=0, ic_form=0, riemann_solve_type=0, dt=0.001,
+               rho_c_ic=1.0, u_c_ic=1.0, v_c_ic=1.0, p_c_ic=1.0)
+    c.to_device(0)
+    if mode == "methods":
+        c.run(2)
+    else:
+        c.run_steps_lib(2, fused=mode)
+    c.sync_host()
+    last = int(d["sizes"][7]) - 1
+    assert rel(c.array("disu_upts0"), d["u_step1_stage%d" % last]) < 1e-11
+    c.close()

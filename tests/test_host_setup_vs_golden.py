@@ -131,3 +131,14 @@ def test_h_ref_vs_reference():
     c = H.Case(3, xv=d["xv"], order=2, dt_type=1, CFL=0.4)
     assert rel(c.array("h_ref"), np.ravel(d["h_ref"])) < 1e-15
     c.close()
+
+
+def test_isentropic_vortex_initial_state():
+    """BASELINE.json configs[0]: the Euler isentropic vortex on quads (ic_form 0) as the reference initialises it."""
+    d = dict(np.load(os.path.join(GOLDEN, "quad_p3_vortex.npz")))
+    c = H.Case([6, 6, 1], xv=d["xv"], dims=2, order=3, viscous=0, ic_form=0, riemann_solve_type=0, dt=0.001,
+               rho_c_ic=1.0, u_c_ic=1.0, v_c_ic=1.0, p_c_ic=1.0)
+    assert rel(c.array("disu_upts0"), d["u_init"]) < 1e-14
+    L, R = c.faces()
+    assert np.array_equal(L, d["int0_L"]) and np.array_equal(R, d["int0_R"])
+    c.close()
