@@ -70,6 +70,7 @@ struct FusedData
   double *disu_alt = nullptr;    // second disu_fpts buffer
   double *fn_fpts = nullptr;     // split variant 3: projected viscous flux per flux point (n_fpts,n_eles,n_fields)
   // tensor-product tables of the sum-factorised flux kernel (valid when tensor_ok)
+  long long *stamps = nullptr; // diagnostics buffer (HFX_FLUX_STAMPS=1)
   bool tensor_ok = false;
   double *t_coef = nullptr; // Dm[N][N] | c5[ND][2][N] | Lf[ND][2][N] | L1[ND][2][N]
   int *t_idx = nullptr;     // pf[ND][L][2] | fdq[NFP] | fbase[NFP]
@@ -1798,6 +1799,7 @@ struct Split2Args
   double *disu_next;
   double *grad_upts, *grad_fpts; // optional outputs (NULL: not written)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
+  long long *stamps; // diagnostics (tools/flux_phase_stamps.py): cycle counter of wave w of workgroup 0 at the phase boundaries
   // update kernel: opp_3 and opp_0 in ELL form (values, columns, width), rows held in registers
   const double *o3v, *o0v;
   const int *o3i, *o0i;
@@ -2123,8 +2125,8 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
   // top of the next iteration.  All barriers order LDS traffic only, so these loads and the result
   // stores stay in flight across them.
   constexpr int UNP = (NF * NU + TB - 1) / TB, DNP = (NF * NFP + TB - 1) / TB;
-  double pf_u[UNP], pf_d[DNP], JG[ND * ND], inv_detjac = 0.0;
-  auto fetch = [&](long e) {
+  double pf_u[UNP], pf_d[DNP], JG[ND * ND], detjac_raw = 1.0;
+  auto fetch_state = [&](long e) {
 #pragma unroll
     for (int i = 0; i < UNP; i++)
     {
@@ -2148,16 +2150,30 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         }
       }
     }
+  };
+  auto fetch_metrics = [&](long e) {
     const long p = tu + NU * e;
 #pragma unroll
     for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
-    inv_detjac = viscous ? 1.0 / a.detjac_upts[p] : 0.0;
+    // only the load here: the reciprocal is taken at the top of the next iteration, so that nothing in phase C
+    // waits for this (last issued) load and with it for the whole prefetch
+    detjac_raw = a.detjac_upts[p];
   };
-  if ((long)blockIdx.x < ne) fetch(blockIdx.x);
+  if ((long)blockIdx.x < ne)
+  {
+    fetch_state(blockIdx.x);
+    fetch_metrics(blockIdx.x);
+  }
 
-  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  int it_no = 0;
+  auto stamp = [&](int slot) {
+    if (a.stamps != nullptr && blockIdx.x == 0 && it_no == 2 && (t & 63) == 0) a.stamps[(t >> 6) * 16 + slot] = clock64();
+  };
+  for (long e = blockIdx.x; e < ne; e += gridDim.x, it_no++)
   {
     const long p = tu + NU * e, o = tf + NFP * e;
+    stamp(0);
+    const double inv_detjac = viscous ? 1.0 / detjac_raw : 0.0;
     // the pencil addresses of the flux-point role are loop invariant; left alone the compiler hoists
     // one address register per (plane, m) out of the element loop.  Rebuild the N of them here from an
     // opaque copy and let the plane offsets be immediates.
@@ -2177,7 +2193,9 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
       for (int i = 0; i < DNP; i++)
         if (t + TB * i < NF * NFP) sd[t + TB * i] = pf_d[i];
     }
+    stamp(1);
     lds_barrier();
+    stamp(2);
 
     // ---- A: transformed gradient, pencil-wise; flux-point solution, point-wise
     if (viscous)
@@ -2236,7 +2254,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         for (int k = 0; k < NF; k++) uf[k] += Lrow[m] * x[k];
       }
     }
+    stamp(3);
     lds_barrier(); // sg complete; su / sd are dead: their region becomes st
+    stamp(4);
+
+
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
@@ -2331,11 +2353,17 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         a.fn_fpts[o + k * plane_f] = s;
       }
     }
+    stamp(5);
     lds_barrier(); // st complete; sg is dead: its region takes the divergence parts
+    stamp(6);
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- C: next element's inputs on their way; divergence parts pencil-wise, normal flux at the flux points
-    if (e + gridDim.x < ne) fetch(e + gridDim.x);
+    if (e + gridDim.x < ne)
+    {
+      fetch_state(e + gridDim.x);
+      fetch_metrics(e + gridDim.x);
+    }
     {
       double xa[ROUNDS][N];
       int sr[ROUNDS];
@@ -2377,7 +2405,9 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 #pragma unroll
       for (int k = 0; k < NF; k++) a.ntd_fpts[o + k * plane_f] = sgn1 * nt[k];
     }
+    stamp(7);
     lds_barrier();
+    stamp(8);
     if (is_u)
     {
 #pragma unroll
@@ -2389,6 +2419,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         a.div[p + k * plane_u] = s;
       }
     }
+    stamp(9);
     // no barrier: the next iteration's writes to sA (dead since the last barrier) do not touch sB, and
     // its writes to sB come after its first barrier
   }
@@ -2600,6 +2631,11 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   Split2Args e2{};
   if (variant == 3)
   {
+    if (getenv("HFX_FLUX_STAMPS") && !F->stamps)
+    {
+      HFX_HIP(hipMalloc((void **)&F->stamps, sizeof(long long) * 64));
+      HFX_HIP(hipMemset(F->stamps, 0, sizeof(long long) * 64));
+    }
     if (!F->fn_fpts) HFX_HIP(hipMalloc((void **)&F->fn_fpts, sizeof(double) * (size_t)plane_f * e->n_fields));
     e2.n_eles = ea.n_eles;
     e2.pk_g = F->pk_g; e2.pk_r = F->pk_r; e2.tab_g = F->tab_g; e2.tab_r = F->tab_r; e2.o1m_dim = F->o1m_dim;
@@ -2613,6 +2649,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.grad_upts = nullptr;
     e2.grad_fpts = (any_bdy && P.viscous) ? e->arr[HFX_GRAD_DISU_FPTS] : nullptr; // boundary points only
     e2.meta = F->meta;
+    e2.stamps = F->stamps;
     e2.o3v = e->opp_3.ell_val; e2.o3i = e->opp_3.ell_idx; e2.o3w = std::max(e->opp_3.nnz_max, 1);
     e2.o0v = e->opp_0.ell_val; e2.o0i = e->opp_0.ell_idx; e2.o0w = std::max(e->opp_0.nnz_max, 1);
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;
@@ -2793,6 +2830,17 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
   for (auto &x : ev) (void)hipEventDestroy(x);
   for (int i = 0; i < 8; i++) ms[i] = 0.0;
   for (int w = 0; w < 4; w++) ms[w] = acc[w] / reps;
+  if (e->fused->stamps)
+  {
+    long long h[64];
+    HFX_HIP(hipMemcpy(h, e->fused->stamps, sizeof h, hipMemcpyDeviceToHost));
+    for (int w = 0; w < 3; w++)
+    {
+      fprintf(stderr, "flux kernel wave %d cycles: ", w);
+      for (int q = 1; q <= 9; q++) fprintf(stderr, "%s%lld", q > 1 ? " " : "", h[w * 16 + q] - h[w * 16 + q - 1]);
+      fprintf(stderr, "   (fill | bar1 | A | bar2 | B | bar3 | C | bar4 | D)  total %lld\n", h[w * 16 + 9] - h[w * 16]);
+    }
+  }
   const bool tensor = e->fused->tensor_ok && getenv("HFX_SPLIT_DICT") == nullptr;
   snprintf(names, names_len, "%s",
            variant == 3 ? (tensor ? "face_delta_kernel,split_flux_tensor_kernel,face_flux2_kernel,split_update_kernel"
