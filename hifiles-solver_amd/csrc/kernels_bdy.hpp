@@ -14,245 +14,251 @@
 namespace hfx
 {
 
-// ghost state; sol_spec 0: state for the inviscid Riemann problem, 1: state for the viscous (LDG) terms
+// ---- ghost state -----------------------------------------------------------------------------
+// sol_spec 0: the state the inviscid Riemann problem sees, 1: the state the viscous (LDG) terms see.
+// Every boundary type is a function of the left primitives (rho, v, e, p, T, v.n, c), computed once, the
+// unit normal and the group's record; the arithmetic of each type follows the cited lines operation by
+// operation (the parity tests hold the boundary sweeps to 1e-12 of the reference).
+template <int ND>
+struct LeftPrim
+{
+  double rho, v[ND], e, p, T, vn;
+};
+
+template <int ND>
+__device__ __forceinline__ double sum_sq(const double (&w)[ND])
+{
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < ND; i++) s += (w[i] * w[i]);
+  return s;
+}
+
 template <int ND>
 __device__ __forceinline__ void bc_state(const int sol_spec, const hfx_bc &bc, const double (&u_l)[ND + 2],
                                          const double (&norm)[ND], const double gamma, const double R_ref,
                                          const int ramp_counter, double (&u_r)[ND + 2])
 {
-  double rho_l, rho_r = 0., v_l[ND], v_r[ND], e_l, e_r = 0., p_l, p_r, T_l, T_r, vn_l, v_sq, machn_l;
-  const int bc_flag = bc.flag;
+  const double gm1 = gamma - 1.0;
+  LeftPrim<ND> L;
+  L.rho = u_l[0];
 #pragma unroll
-  for (int i = 0; i < ND; i++) v_r[i] = 0.;
-  rho_l = u_l[0];
+  for (int i = 0; i < ND; i++) L.v[i] = u_l[i + 1] / u_l[0];
+  L.e = u_l[ND + 1];
+  L.p = gm1 * (L.e - 0.5 * L.rho * sum_sq<ND>(L.v));
+  L.T = L.p / (L.rho * R_ref);
+  L.vn = 0.;
 #pragma unroll
-  for (int i = 0; i < ND; i++) v_l[i] = u_l[i + 1] / u_l[0];
-  e_l = u_l[ND + 1];
-  v_sq = 0.;
-#pragma unroll
-  for (int i = 0; i < ND; i++) v_sq += (v_l[i] * v_l[i]);
-  p_l = (gamma - 1.0) * (e_l - 0.5 * rho_l * v_sq);
-  T_l = p_l / (rho_l * R_ref);
-  vn_l = 0.;
-#pragma unroll
-  for (int i = 0; i < ND; i++) vn_l += v_l[i] * norm[i];
+  for (int i = 0; i < ND; i++) L.vn += L.v[i] * norm[i];
 
-  if (bc_flag == HFX_BC_SUB_IN_SIMP)
+  double rho_g = 0., e_g = 0., w[ND]; // ghost density, total energy, velocity
+#pragma unroll
+  for (int i = 0; i < ND; i++) w[i] = 0.;
+  // total energy of a ghost state given by pressure, density and its velocity w
+  auto energy = [&](double p, double rho) { return (p / gm1) + 0.5 * rho * sum_sq<ND>(w); };
+  auto copy_left_velocity = [&]() {
+#pragma unroll
+    for (int i = 0; i < ND; i++) w[i] = L.v[i];
+  };
+  auto prescribed_velocity = [&]() {
+#pragma unroll
+    for (int i = 0; i < ND; i++) w[i] = bc.velocity[i];
+  };
+  // reflect (factor 2) or remove (factor 1) the wall-normal velocity
+  auto wall_normal = [&](double factor) {
+#pragma unroll
+    for (int i = 0; i < ND; i++) w[i] = L.v[i] - factor * L.vn * norm[i];
+  };
+
+  switch (bc.flag)
   {
-    rho_r = bc.rho;
-    for (int i = 0; i < ND; i++) v_r[i] = bc.velocity[i];
-    v_sq = 0.;
-    for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-    e_r = p_l / (gamma - 1.0) + 0.5 * rho_r * v_sq;
-  }
-  else if (bc_flag == HFX_BC_SUB_OUT_SIMP)
+  case HFX_BC_SUB_IN_SIMP: // :378-400 density and velocity fixed, pressure from inside
+    rho_g = bc.rho;
+    prescribed_velocity();
+    e_g = L.p / gm1 + 0.5 * rho_g * sum_sq<ND>(w);
+    break;
+
+  case HFX_BC_SUB_OUT_SIMP: // :404-468 back pressure; reverse flow and supersonic outflow handled apart
   {
-    machn_l = fabs(vn_l) / sqrt(gamma * p_l / rho_l);
-    if (vn_l < 0)
+    const double machn = fabs(L.vn) / sqrt(gamma * L.p / L.rho);
+    if (L.vn < 0)
     {
-      for (int i = 0; i < ND; i++) v_r[i] = vn_l * norm[i];
-      v_sq = 0.;
-      for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-      T_r = bc.T_total - 0.5 * v_sq * (gamma - 1.0) / (R_ref * gamma);
-      p_r = bc.p_static * pow((1.0 + 0.5 * (gamma - 1.0) * (v_sq / (gamma * R_ref * T_r))), -gamma / (gamma - 1.0));
-      rho_r = p_r / (R_ref * T_r);
-      e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+#pragma unroll
+      for (int i = 0; i < ND; i++) w[i] = L.vn * norm[i];
+      const double q2 = sum_sq<ND>(w);
+      const double T_g = bc.T_total - 0.5 * q2 * gm1 / (R_ref * gamma);
+      const double p_g = bc.p_static * pow((1.0 + 0.5 * gm1 * (q2 / (gamma * R_ref * T_g))), -gamma / gm1);
+      rho_g = p_g / (R_ref * T_g);
+      e_g = (p_g / gm1) + 0.5 * rho_g * q2;
     }
-    else if (vn_l >= 0 && machn_l >= 1)
+    else if (machn >= 1)
     {
-      rho_r = rho_l;
-      for (int i = 0; i < ND; i++) v_r[i] = v_l[i];
-      e_r = e_l;
+      rho_g = L.rho;
+      copy_left_velocity();
+      e_g = L.e;
     }
     else
     {
-      for (int i = 0; i < ND; i++) v_r[i] = v_l[i];
-      rho_r = rho_l;
-      p_r = bc.p_static;
-      v_sq = 0.;
-      for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-      e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+      copy_left_velocity();
+      rho_g = L.rho;
+      e_g = energy(bc.p_static, rho_g);
     }
+    break;
   }
-  else if (bc_flag == HFX_BC_SUB_IN_CHAR)
+
+  case HFX_BC_SUB_IN_CHAR: // :475-590 total conditions + outgoing Riemann invariant (with the optional ramps)
   {
-    double V_r, c_l, c_r_sq, c_total_sq, R_plus, aa, bb, cc, dd, Mach_sq, alpha, p_total_temp, T_total_temp;
+    double p0 = bc.p_total, T0 = bc.T_total;
     if (bc.pressure_ramp)
     {
       if (bc.p_ramp_coeff != 0.0)
       {
-        p_total_temp = bc.p_total_old + (bc.p_total - bc.p_total_old) * bc.p_ramp_coeff * ramp_counter;
-        if (p_total_temp >= bc.p_total) p_total_temp = bc.p_total;
+        p0 = bc.p_total_old + (bc.p_total - bc.p_total_old) * bc.p_ramp_coeff * ramp_counter;
+        if (p0 >= bc.p_total) p0 = bc.p_total;
       }
-      else
-        p_total_temp = bc.p_total;
       if (bc.T_ramp_coeff > 0)
       {
-        T_total_temp = bc.T_total_old + (bc.T_total - bc.T_total_old) * bc.T_ramp_coeff * ramp_counter;
-        if (T_total_temp >= bc.T_total) T_total_temp = bc.T_total;
+        T0 = bc.T_total_old + (bc.T_total - bc.T_total_old) * bc.T_ramp_coeff * ramp_counter;
+        if (T0 >= bc.T_total) T0 = bc.T_total;
       }
       else if (bc.T_ramp_coeff < 0)
-        T_total_temp = T_l * pow(p_total_temp / p_l, (gamma - 1.0) / gamma);
-      else
-        T_total_temp = bc.T_total;
+        T0 = L.T * pow(p0 / L.p, gm1 / gamma);
     }
-    else
-    {
-      p_total_temp = bc.p_total;
-      T_total_temp = bc.T_total;
-    }
-    const double n_free_stream[3] = {bc.nx, bc.ny, bc.nz};
-    c_l = sqrt(gamma * p_l / rho_l);
-    R_plus = vn_l + 2.0 * c_l / (gamma - 1.0);
-    c_total_sq = gamma * R_ref * T_total_temp;
-    alpha = 0.;
-    for (int i = 0; i < ND; i++) alpha += norm[i] * n_free_stream[i];
-    aa = 1.0 + 0.5 * (gamma - 1.0) * alpha * alpha;
-    bb = -(gamma - 1.0) * alpha * R_plus;
-    cc = 0.5 * (gamma - 1.0) * R_plus * R_plus - 2.0 * c_total_sq / (gamma - 1.0);
-    dd = bb * bb - 4.0 * aa * cc;
-    dd = sqrt(dd > 0.0 ? dd : 0.0);
-    V_r = (-bb + dd) / (2.0 * aa);
-    V_r = V_r > 0.0 ? V_r : 0.0;
-    v_sq = V_r * V_r;
-    c_r_sq = c_total_sq - 0.5 * (gamma - 1.0) * v_sq;
-    Mach_sq = v_sq / (c_r_sq);
-    Mach_sq = Mach_sq < 1.0 ? Mach_sq : 1.0;
-    v_sq = Mach_sq * c_r_sq;
-    V_r = sqrt(v_sq);
-    c_r_sq = c_total_sq - 0.5 * (gamma - 1.0) * v_sq;
-    for (int i = 0; i < ND; i++) v_r[i] = V_r * n_free_stream[i];
-    T_r = c_r_sq / (gamma * R_ref);
-    p_r = p_total_temp * pow(T_r / T_total_temp, gamma / (gamma - 1.0));
-    rho_r = p_r / (R_ref * T_r);
-    e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+    const double dir[3] = {bc.nx, bc.ny, bc.nz};
+    const double c_l = sqrt(gamma * L.p / L.rho);
+    const double R_plus = L.vn + 2.0 * c_l / gm1;
+    const double c0sq = gamma * R_ref * T0;
+    double alpha = 0.;
+#pragma unroll
+    for (int i = 0; i < ND; i++) alpha += norm[i] * dir[i];
+    const double qa = 1.0 + 0.5 * gm1 * alpha * alpha;
+    const double qb = -gm1 * alpha * R_plus;
+    const double qc = 0.5 * gm1 * R_plus * R_plus - 2.0 * c0sq / gm1;
+    double disc = qb * qb - 4.0 * qa * qc;
+    disc = sqrt(disc > 0.0 ? disc : 0.0);
+    double speed = (-qb + disc) / (2.0 * qa);
+    speed = speed > 0.0 ? speed : 0.0;
+    double q2 = speed * speed;
+    double csq = c0sq - 0.5 * gm1 * q2;
+    double M2 = q2 / (csq);
+    M2 = M2 < 1.0 ? M2 : 1.0;
+    q2 = M2 * csq;
+    speed = sqrt(q2);
+    csq = c0sq - 0.5 * gm1 * q2;
+#pragma unroll
+    for (int i = 0; i < ND; i++) w[i] = speed * dir[i];
+    const double T_g = csq / (gamma * R_ref);
+    const double p_g = p0 * pow(T_g / T0, gamma / gm1);
+    rho_g = p_g / (R_ref * T_g);
+    e_g = (p_g / gm1) + 0.5 * rho_g * q2;
+    break;
   }
-  else if (bc_flag == HFX_BC_SUB_OUT_CHAR)
+
+  case HFX_BC_SUB_OUT_CHAR: // :598-640 entropy and the outgoing invariant extrapolated, pressure fixed
   {
-    double c_l, c_r, R_plus, s, vn_r;
-    c_l = sqrt(gamma * p_l / rho_l);
-    R_plus = vn_l + 2.0 * c_l / (gamma - 1.0);
-    s = p_l / pow(rho_l, gamma);
-    p_r = bc.p_static;
-    rho_r = pow(p_r / s, 1.0 / gamma);
-    c_r = sqrt(gamma * p_r / rho_r);
-    vn_r = R_plus - 2.0 * c_r / (gamma - 1.0);
-    v_sq = 0.;
+    const double c_l = sqrt(gamma * L.p / L.rho);
+    const double R_plus = L.vn + 2.0 * c_l / gm1;
+    const double entropy = L.p / pow(L.rho, gamma);
+    const double p_g = bc.p_static;
+    rho_g = pow(p_g / entropy, 1.0 / gamma);
+    const double c_g = sqrt(gamma * p_g / rho_g);
+    const double vn_g = R_plus - 2.0 * c_g / gm1;
+    double q2 = 0.;
+#pragma unroll
     for (int i = 0; i < ND; i++)
     {
-      v_r[i] = v_l[i] + (vn_r - vn_l) * norm[i];
-      v_sq += (v_r[i] * v_r[i]);
+      w[i] = L.v[i] + (vn_g - L.vn) * norm[i];
+      q2 += (w[i] * w[i]);
     }
-    e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
+    e_g = (p_g / gm1) + 0.5 * rho_g * q2;
+    break;
   }
-  else if (bc_flag == HFX_BC_SUP_IN)
-  {
-    rho_r = bc.rho;
-    for (int i = 0; i < ND; i++) v_r[i] = bc.velocity[i];
-    p_r = bc.p_static;
-    v_sq = 0.;
-    for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-    e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
-  }
-  else if (bc_flag == HFX_BC_SUP_OUT)
-  {
-    rho_r = rho_l;
-    for (int i = 0; i < ND; i++) v_r[i] = v_l[i];
-    e_r = e_l;
-  }
-  else if (bc_flag == HFX_BC_SLIP_WALL)
-  {
-    rho_r = rho_l;
+
+  case HFX_BC_SUP_IN: // :643-659 everything prescribed
+    rho_g = bc.rho;
+    prescribed_velocity();
+    e_g = energy(bc.p_static, rho_g);
+    break;
+
+  case HFX_BC_SUP_OUT: // :662-669 everything extrapolated
+    rho_g = L.rho;
+    copy_left_velocity();
+    e_g = L.e;
+    break;
+
+  case HFX_BC_SLIP_WALL: // :672-701
+    rho_g = L.rho;
+    wall_normal(sol_spec == 0 ? 2.0 : 1.0);
+    e_g = L.p / gm1 + 0.5 * rho_g * sum_sq<ND>(w);
+    break;
+
+  case HFX_BC_ISOTHERM_WALL: // :704-792 (wall model off): wall velocity, wall temperature
+  case HFX_BC_ADIABAT_WALL:  // :795-860 (wall model off): wall velocity, interior pressure
+    rho_g = L.rho;
     if (sol_spec == 0)
-      for (int i = 0; i < ND; i++) v_r[i] = v_l[i] - 2 * vn_l * norm[i];
-    else
-      for (int i = 0; i < ND; i++) v_r[i] = v_l[i] - vn_l * norm[i];
-    v_sq = 0.;
-    for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-    e_r = p_l / (gamma - 1.0) + 0.5 * rho_r * v_sq;
-  }
-  else if (bc_flag == HFX_BC_ISOTHERM_WALL)
-  {
-    T_r = bc.T_static;
-    rho_r = rho_l;
-    if (sol_spec == 0)
-      for (int i = 0; i < ND; i++) v_r[i] = 2 * bc.velocity[i] - v_l[i];
-    else
-      for (int i = 0; i < ND; i++) v_r[i] = bc.velocity[i];
-    v_sq = 0.;
-    for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-    e_r = rho_r * (R_ref / (gamma - 1.0) * T_r) + 0.5 * rho_r * v_sq;
-  }
-  else if (bc_flag == HFX_BC_ADIABAT_WALL)
-  {
-    rho_r = rho_l;
-    if (sol_spec == 0)
-      for (int i = 0; i < ND; i++) v_r[i] = 2 * bc.velocity[i] - v_l[i];
-    else
-      for (int i = 0; i < ND; i++) v_r[i] = bc.velocity[i];
-    v_sq = 0.;
-    for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-    e_r = p_l / (gamma - 1.0) + 0.5 * rho_r * v_sq;
-  }
-  else if (bc_flag == HFX_BC_CHAR)
-  {
-    double c_star, vn_star, vn_r, r_plus, r_minus, c_l, c_r, one_over_s, mach;
-    vn_r = 0;
-    for (int i = 0; i < ND; i++) vn_r += bc.velocity[i] * norm[i];
-    c_l = sqrt(gamma * p_l / rho_l);
-    c_r = sqrt(gamma * bc.p_static / bc.rho);
-    mach = fabs(vn_l) / c_l;
-    if (vn_l < 0)
     {
-      if (mach >= 1)
-      {
-        r_minus = vn_r - 2. / (gamma - 1.) * c_r;
-        r_plus = vn_r + 2. / (gamma - 1.) * c_r;
-      }
-      else
-      {
-        r_plus = vn_l + 2. / (gamma - 1.) * c_l;
-        r_minus = vn_r - 2. / (gamma - 1.) * c_r;
-      }
-      c_star = 0.25 * (gamma - 1.) * (r_plus - r_minus);
-      vn_star = 0.5 * (r_plus + r_minus);
-      one_over_s = pow(bc.rho, gamma) / bc.p_static;
-      rho_r = pow(1. / gamma * (one_over_s * c_star * c_star), 1. / (gamma - 1.));
-      for (int i = 0; i < ND; i++) v_r[i] = vn_star * norm[i] + (bc.velocity[i] - vn_r * norm[i]);
-    }
-    else
-    {
-      if (mach >= 1)
-      {
-        r_minus = vn_l - 2. / (gamma - 1.) * c_l;
-        r_plus = vn_l + 2. / (gamma - 1.) * c_l;
-      }
-      else
-      {
-        r_plus = vn_l + 2. / (gamma - 1.) * c_l;
-        r_minus = vn_r - 2. / (gamma - 1.) * c_r;
-      }
-      c_star = 0.25 * (gamma - 1.) * (r_plus - r_minus);
-      vn_star = 0.5 * (r_plus + r_minus);
-      one_over_s = pow(rho_l, gamma) / p_l;
-      rho_r = pow(1. / gamma * (one_over_s * c_star * c_star), 1. / (gamma - 1.));
-      for (int i = 0; i < ND; i++) v_r[i] = vn_star * norm[i] + (v_l[i] - vn_l * norm[i]);
-    }
-    v_sq = 0.;
-    for (int i = 0; i < ND; i++) v_sq += (v_r[i] * v_r[i]);
-    p_r = rho_r / gamma * c_star * c_star;
-    e_r = (p_r / (gamma - 1.0)) + 0.5 * rho_r * v_sq;
-  }
-  else if (bc_flag == HFX_BC_SLIP_WALL_DUAL)
-  {
-    rho_r = rho_l;
-    for (int i = 0; i < ND; i++) v_r[i] = v_l[i] - 2 * vn_l * norm[i];
-    e_r = e_l;
-  }
-  u_r[0] = rho_r;
 #pragma unroll
-  for (int i = 0; i < ND; i++) u_r[i + 1] = rho_r * v_r[i];
-  u_r[ND + 1] = e_r;
+      for (int i = 0; i < ND; i++) w[i] = 2 * bc.velocity[i] - L.v[i];
+    }
+    else
+      prescribed_velocity();
+    if (bc.flag == HFX_BC_ISOTHERM_WALL)
+      e_g = rho_g * (R_ref / gm1 * bc.T_static) + 0.5 * rho_g * sum_sq<ND>(w);
+    else
+      e_g = L.p / gm1 + 0.5 * rho_g * sum_sq<ND>(w);
+    break;
+
+  case HFX_BC_CHAR: // :863-960 Riemann invariants against the far-field state
+  {
+    double vn_far = 0;
+#pragma unroll
+    for (int i = 0; i < ND; i++) vn_far += bc.velocity[i] * norm[i];
+    const double c_l = sqrt(gamma * L.p / L.rho);
+    const double c_far = sqrt(gamma * bc.p_static / bc.rho);
+    const bool supersonic = fabs(L.vn) / c_l >= 1;
+    const bool inflow = L.vn < 0;
+    double r_plus, r_minus;
+    if (supersonic && inflow)
+    {
+      r_minus = vn_far - 2. / gm1 * c_far;
+      r_plus = vn_far + 2. / gm1 * c_far;
+    }
+    else if (supersonic)
+    {
+      r_minus = L.vn - 2. / gm1 * c_l;
+      r_plus = L.vn + 2. / gm1 * c_l;
+    }
+    else
+    {
+      r_plus = L.vn + 2. / gm1 * c_l;
+      r_minus = vn_far - 2. / gm1 * c_far;
+    }
+    const double c_star = 0.25 * gm1 * (r_plus - r_minus);
+    const double vn_star = 0.5 * (r_plus + r_minus);
+    // entropy from the far field on inflow, from the interior on outflow; the tangential velocity likewise
+    const double inv_entropy = inflow ? pow(bc.rho, gamma) / bc.p_static : pow(L.rho, gamma) / L.p;
+    rho_g = pow(1. / gamma * (inv_entropy * c_star * c_star), 1. / gm1);
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+      w[i] = inflow ? vn_star * norm[i] + (bc.velocity[i] - vn_far * norm[i]) : vn_star * norm[i] + (L.v[i] - L.vn * norm[i]);
+    const double p_g = rho_g / gamma * c_star * c_star;
+    e_g = energy(p_g, rho_g);
+    break;
+  }
+
+  case HFX_BC_SLIP_WALL_DUAL: // :963-980
+    rho_g = L.rho;
+    wall_normal(2.0);
+    e_g = L.e;
+    break;
+
+  default:
+    break;
+  }
+  u_r[0] = rho_g;
+#pragma unroll
+  for (int i = 0; i < ND; i++) u_r[i + 1] = rho_g * w[i];
+  u_r[ND + 1] = e_g;
 }
 
 // set_boundary_gradients (src/bdy_inters.cpp:1138-1189); g(field, dim) = g[field + NF*dim]
