@@ -1086,7 +1086,6 @@ static int tensor_build(hfx_eles *e, FusedData *F, int N, const std::vector<doub
 
 static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allow_unpaired = false)
 {
-  HFX_CHECK(!e->over_int_ready, "fused path: over-integration is evaluated by the per-method path only");
   HFX_CHECK(!e->les_ready, "fused path: the LES closure is evaluated by the per-method path only");
   HFX_CHECK(e->ele_type == 4 || e->ele_type == 1, "fused path: tensor-product elements only (hexes, quads)");
   const int N = tensor_n(e);
@@ -1309,6 +1308,7 @@ int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
   for (int b = 0; b < nfb; b++)
     HFX_CHECK(!faces[b]->is_bdy, "the gather-style fused path (fused=1) has no boundary faces: use fused=2 or 3");
   HFX_CHECK(!e->shock_ready, "the gather-style fused path (fused=1) has no shock capturing: use fused=2 or 3");
+  HFX_CHECK(!e->over_int_ready, "the gather-style fused path (fused=1) has no over-integration: use fused=3");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
   if (n_steps <= 0) return 0;
@@ -1798,6 +1798,8 @@ struct Split2Args
   double *div;      // div_tdisf (flux kernel) -> read by the update kernel, which may overwrite it with div_tconf
   double *disu_next;
   double *grad_upts, *grad_fpts; // optional outputs (NULL: not written)
+  int xcd_order;                 // EleOrder: contiguous element ranges per XCD
+  const double *tdisf_in;        // over-integration: the transformed inviscid flux, already evaluated (NULL: computed here)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
   long long *stamps; // diagnostics (tools/flux_phase_stamps.py): cycle counter of wave w of workgroup 0 at the phase boundaries
   // update kernel: opp_3 and opp_0 in ELL form (values, columns, width), rows held in registers
@@ -1882,17 +1884,25 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flu
       double u[NF], f[NG];
 #pragma unroll
       for (int k = 0; k < NF; k++) u[k] = su[k * NU + tu];
-      calc_invf<ND, true>(a.P.gamma, u, f);
+      if (a.tdisf_in)
+      {
 #pragma unroll
-      for (int k = 0; k < NF; k++)
+        for (int q = 0; q < NG; q++) tfl[q] = a.tdisf_in[p + q * plane_u];
+      }
+      else
+      {
+        calc_invf<ND, true>(a.P.gamma, u, f);
 #pragma unroll
-        for (int l = 0; l < ND; l++)
-        {
-          double s = 0.0;
+        for (int k = 0; k < NF; k++)
 #pragma unroll
-          for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-          tfl[k + NF * l] = s;
-        }
+          for (int l = 0; l < ND; l++)
+          {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+            tfl[k + NF * l] = s;
+          }
+      }
       if (viscous)
       {
         double gr[NG];
@@ -2005,6 +2015,9 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flu
 #ifndef HFX_SPLIT2T_WAVES
 #define HFX_SPLIT2T_WAVES 2
 #endif
+#ifndef HFX_FLUX_FMETRICS
+#define HFX_FLUX_FMETRICS 0
+#endif
 
 // constant address space: loads with a wave-uniform address are selected as scalar loads
 typedef const double __attribute__((address_space(4))) *cdptr;
@@ -2028,6 +2041,69 @@ __device__ __forceinline__ double ldsv(const double *p)
 {
   return *(const volatile __attribute__((address_space(3))) double *)p;
 }
+
+// Element order of a persistent workgroup.  Workgroups whose ids are equal modulo 8 share an XCD and its L2
+// (MI355X_MICROARCH.md, workgroup dispatch): each such group walks ONE contiguous eighth of the elements, so that the
+// 128-byte lines two neighbouring elements share (an element's run per field is 1000 / 1200 bytes, not a multiple of
+// a line) are fetched into one L2 once instead of into two.  HFX_NO_XCD_ORDER=1 (or a grid that is no multiple of 8):
+// element = workgroup id + k * grid.
+struct EleOrder
+{
+  long ne, chunk;
+  int per, slot, xcd;
+  bool remap;
+  __device__ __forceinline__ EleOrder(long n_eles, bool want) : ne(n_eles)
+  {
+    remap = want && (gridDim.x % 8 == 0);
+    per = gridDim.x / 8;
+    slot = blockIdx.x / 8;
+    xcd = blockIdx.x % 8;
+    chunk = (ne + 7) / 8;
+  }
+  // k-th element of this workgroup, -1 past the end
+  __device__ __forceinline__ long at(long k) const
+  {
+    if (!remap)
+    {
+      const long e = blockIdx.x + k * gridDim.x;
+      return e < ne ? e : -1;
+    }
+    const long l = slot + k * per, e = xcd * chunk + l;
+    return (l < chunk && e < ne) ? e : -1;
+  }
+};
+
+// A global array of doubles addressed as [wave-uniform offset + lane offset].  BUF: through a buffer descriptor
+// (4 SGPRs per array), the uniform part in the instruction's scalar offset and the lane part in ONE 32-bit VGPR that
+// is loop invariant -- instead of a 64-bit VGPR address per (array, field), which the compiler otherwise keeps live
+// across the element loop (a third of the registers of these kernels) and recomputes with 64-bit VALU adds.
+// Offsets are 32-bit byte counts: the launcher selects BUF only when every array is smaller than 4 GiB.
+typedef unsigned hfx_v2u __attribute__((ext_vector_type(2)));
+template <bool BUF>
+struct GArr
+{
+  double *p;
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ GArr(const double *q, long n) : p(const_cast<double *>(q))
+  {
+    if constexpr (BUF) r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, q ? (int)(unsigned)(n * 8) : 0, 0x00020000);
+  }
+  // uni: element offset common to the wave, lane: this lane's element offset (small, loop invariant)
+  __device__ __forceinline__ double ld(long uni, unsigned lane) const
+  {
+    if constexpr (BUF)
+      return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8u, (unsigned)uni * 8u, 0));
+    else
+      return p[uni + lane];
+  }
+  __device__ __forceinline__ void st(long uni, unsigned lane, double v) const
+  {
+    if constexpr (BUF)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(hfx_v2u, v), r, lane * 8u, (unsigned)uni * 8u, 0);
+    else
+      p[uni + lane] = v;
+  }
+};
 
 // transformed gradient along direction D on one pencil: sg = Dm x + c5[.][0] delta_a + c5[.][1] delta_b
 template <int ND, int N, int D>
@@ -2070,7 +2146,7 @@ __device__ __forceinline__ void pencil_div(cdptr coef, const double *st_p, doubl
   }
 }
 
-template <int ND, int N, int WV>
+template <int ND, int N, int WV, bool BUF>
 __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kernel(const Split2Args a,
                                                                                                const double *coef_g,
                                                                                                const int *tidx)
@@ -2126,52 +2202,73 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
   // stores stay in flight across them.
   constexpr int UNP = (NF * NU + TB - 1) / TB, DNP = (NF * NFP + TB - 1) / TB;
   double pf_u[UNP], pf_d[DNP], JG[ND * ND], detjac_raw = 1.0;
+  // global arrays as [wave-uniform element offset + loop-invariant lane offset] (GArr)
+  const long tot_u = plane_u * NF, tot_f = plane_f * NF;
+  const GArr<BUF> g_u0(a.u0, tot_u), g_delta(a.delta, tot_f), g_JGu(a.JGinv_upts, plane_u * (ND * ND)), g_dju(a.detjac_upts, plane_u);
+  const GArr<BUF> g_JGf(a.JGinv_fpts, plane_f * (ND * ND)), g_djf(a.detjac_fpts, plane_f), g_nrm(a.norm_fpts, plane_f * ND);
+  const GArr<BUF> g_gu(a.grad_upts, plane_u * NG), g_gf(a.grad_fpts, plane_f * NG), g_fn(a.fn_fpts, tot_f), g_ntd(a.ntd_fpts, tot_f),
+      g_div(a.div, tot_u), g_td(a.tdisf_in, plane_u * NG);
+  const unsigned lu = tu, lf = tf;
+  unsigned lo_u[UNP], lo_d[DNP]; // lane offsets of the state / delta prefetch: (field plane + point)
+#pragma unroll
+  for (int i = 0; i < UNP; i++)
+  {
+    const int q = t + TB * i, f = q / NU;
+    lo_u[i] = (unsigned)(q - f * NU) + (unsigned)f * (unsigned)plane_u;
+  }
+#pragma unroll
+  for (int i = 0; i < DNP; i++)
+  {
+    const int q = t + TB * i, f = q / NFP;
+    lo_d[i] = (unsigned)(q - f * NFP) + (unsigned)f * (unsigned)plane_f;
+  }
   auto fetch_state = [&](long e) {
 #pragma unroll
     for (int i = 0; i < UNP; i++)
-    {
-      const int q = t + TB * i;
-      if (q < NF * NU)
-      {
-        const int f = q / NU, p2 = q - f * NU;
-        pf_u[i] = a.u0[p2 + NU * e + f * plane_u];
-      }
-    }
+      if (t + TB * i < NF * NU) pf_u[i] = g_u0.ld((long)NU * e, lo_u[i]);
     if (viscous)
     {
 #pragma unroll
       for (int i = 0; i < DNP; i++)
-      {
-        const int q = t + TB * i;
-        if (q < NF * NFP)
-        {
-          const int f = q / NFP, p2 = q - f * NFP;
-          pf_d[i] = a.delta[p2 + NFP * e + f * plane_f];
-        }
-      }
+        if (t + TB * i < NF * NFP) pf_d[i] = g_delta.ld((long)NFP * e, lo_d[i]);
     }
   };
   auto fetch_metrics = [&](long e) {
-    const long p = tu + NU * e;
 #pragma unroll
-    for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
+    for (int q = 0; q < ND * ND; q++) JG[q] = g_JGu.ld((long)NU * e * (ND * ND), lu * (ND * ND) + q);
     // only the load here: the reciprocal is taken at the top of the next iteration, so that nothing in phase C
     // waits for this (last issued) load and with it for the whole prefetch
-    detjac_raw = a.detjac_upts[p];
+    detjac_raw = g_dju.ld((long)NU * e, lu);
   };
-  if ((long)blockIdx.x < ne)
+  // flux-point metrics of the current element (HFX_FLUX_FMETRICS: where they are requested -- 0: at their use in
+  // phase B, behind the solution-point block; 1: at the top of phase B; 2: at the top of phase A)
+  double JF[ND * ND], nrm[ND], djf_raw = 1.0;
+  long ef_cur = 0;
+  auto fetch_fmetrics = [&]() {
+    if (viscous && is_f)
+    {
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) JF[q] = g_JGf.ld(ef_cur * (ND * ND), lf * (ND * ND) + q);
+      djf_raw = g_djf.ld(ef_cur, lf);
+#pragma unroll
+      for (int m = 0; m < ND; m++) nrm[m] = g_nrm.ld(ef_cur + m * plane_f, lf);
+    }
+  };
+  const EleOrder order(ne, a.xcd_order != 0);
+  if (order.at(0) >= 0)
   {
-    fetch_state(blockIdx.x);
-    fetch_metrics(blockIdx.x);
+    fetch_state(order.at(0));
+    fetch_metrics(order.at(0));
   }
 
   int it_no = 0;
   auto stamp = [&](int slot) {
     if (a.stamps != nullptr && blockIdx.x == 0 && it_no == 2 && (t & 63) == 0) a.stamps[(t >> 6) * 16 + slot] = clock64();
   };
-  for (long e = blockIdx.x; e < ne; e += gridDim.x, it_no++)
+  for (long kk = 0, e = order.at(0), e_next; e >= 0; kk++, e = e_next, it_no++)
   {
-    const long p = tu + NU * e, o = tf + NFP * e;
+    e_next = order.at(kk + 1);
+    const long eu = (long)NU * e, ef = (long)NFP * e;
     stamp(0);
     const double inv_detjac = viscous ? 1.0 / detjac_raw : 0.0;
     // the pencil addresses of the flux-point role are loop invariant; left alone the compiler hoists
@@ -2196,6 +2293,10 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     stamp(1);
     lds_barrier();
     stamp(2);
+    ef_cur = ef;
+#if HFX_FLUX_FMETRICS == 2
+    fetch_fmetrics();
+#endif
 
     // ---- A: transformed gradient, pencil-wise; flux-point solution, point-wise
     if (viscous)
@@ -2261,10 +2362,21 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 
 
     __builtin_amdgcn_sched_barrier(0);
+#if HFX_FLUX_FMETRICS == 1
+    fetch_fmetrics();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
     if (is_u)
     {
       // the transformed flux is accumulated in this thread's own st column (LDS) instead of 15 registers
+      if (a.tdisf_in)
+      {
+        // over-integration: the de-aliased inviscid flux was evaluated at the cubature points and projected back
+#pragma unroll
+        for (int q = 0; q < NG; q++) st[q * NU + tu] = g_td.ld(eu + q * plane_u, lu);
+      }
+      else
       {
         double f[NG];
         calc_invf<ND, true>(a.P.gamma, u, f);
@@ -2294,7 +2406,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         }
         if (a.grad_upts)
 #pragma unroll
-          for (int q = 0; q < NG; q++) a.grad_upts[p + q * plane_u] = gr[q];
+          for (int q = 0; q < NG; q++) g_gu.st(eu + q * plane_u, lu, gr[q]);
         calc_visf<ND, true>(a.P, u, gr, f);
 #pragma unroll
         for (int k = 0; k < NF; k++)
@@ -2312,13 +2424,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     if (viscous && is_f)
     {
       double grf[NG], fq[NG];
+#if HFX_FLUX_FMETRICS == 0
       // flux-point metrics are fetched here, after the solution-point block has released its registers
-      double JF[ND * ND], nrm[ND];
-#pragma unroll
-      for (int q = 0; q < ND * ND; q++) JF[q] = a.JGinv_fpts[o * (ND * ND) + q];
-      const double inv_df = 1.0 / a.detjac_fpts[o];
-#pragma unroll
-      for (int m = 0; m < ND; m++) nrm[m] = a.norm_fpts[o + m * plane_f];
+      fetch_fmetrics();
+#endif
+      const double inv_df = 1.0 / djf_raw;
 #pragma unroll
       for (int q = 0; q < NG; q++) grf[q] = 0.0;
 #pragma unroll
@@ -2340,9 +2450,9 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 #pragma unroll
         for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
       }
-      if (a.grad_fpts && (a.meta == nullptr || (a.meta[o] & 4)))
+      if (a.grad_fpts && (a.meta == nullptr || (a.meta[ef + tf] & 4)))
 #pragma unroll
-        for (int q = 0; q < NG; q++) a.grad_fpts[o + q * plane_f] = grf[q];
+        for (int q = 0; q < NG; q++) g_gf.st(ef + q * plane_f, lf, grf[q]);
       calc_visf<ND, true>(a.P, uf, grf, fq);
 #pragma unroll
       for (int k = 0; k < NF; k++)
@@ -2350,7 +2460,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         double s = 0.0;
 #pragma unroll
         for (int l = 0; l < ND; l++) s += fq[k + NF * l] * nrm[l];
-        a.fn_fpts[o + k * plane_f] = s;
+        g_fn.st(ef + k * plane_f, lf, s);
       }
     }
     stamp(5);
@@ -2359,10 +2469,10 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- C: next element's inputs on their way; divergence parts pencil-wise, normal flux at the flux points
-    if (e + gridDim.x < ne)
+    if (e_next >= 0)
     {
-      fetch_state(e + gridDim.x);
-      fetch_metrics(e + gridDim.x);
+      fetch_state(e_next);
+      fetch_metrics(e_next);
     }
     {
       double xa[ROUNDS][N];
@@ -2403,7 +2513,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         for (int k = 0; k < NF; k++) nt[k] += Lrow[m] * x[k];
       }
 #pragma unroll
-      for (int k = 0; k < NF; k++) a.ntd_fpts[o + k * plane_f] = sgn1 * nt[k];
+      for (int k = 0; k < NF; k++) g_ntd.st(ef + k * plane_f, lf, sgn1 * nt[k]);
     }
     stamp(7);
     lds_barrier();
@@ -2416,7 +2526,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
         double s = ldsv(&sp[k * NU + tu]);
         s += ldsv(&sp[(k + NF) * NU + tu]);
         if (ND == 3) s += ldsv(&sp[(k + NF * (ND - 1)) * NU + tu]);
-        a.div[p + k * plane_u] = s;
+        g_div.st(eu + k * plane_u, lu, s);
       }
     }
     stamp(9);
@@ -2480,8 +2590,11 @@ __global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
 }
 
 // div_tdisf + opp_3 (norm_tconf - norm_tdisf) -> RK update -> disu_fpts of the new state: a streaming kernel
-template <int ND, int N>
-__global__ __launch_bounds__((SGeo<ND, N>::TB), 3) void split_update_kernel(const Split2Args a)
+#ifndef HFX_UPD_WAVES
+#define HFX_UPD_WAVES 3
+#endif
+template <int ND, int N, bool BUF>
+__global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update_kernel(const Split2Args a)
 {
   using G = Geo<ND, N>;
   constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TB = SGeo<ND, N>::TB;
@@ -2509,23 +2622,29 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), 3) void split_update_kernel(cons
     i0[q] = q < a.o0w ? a.o0i[tf + (long)NFP * q] : 0;
   }
 
-  for (long e = blockIdx.x; e < ne; e += gridDim.x)
+  const unsigned lu = tu, lf = tf;
+  const long tot_u = plane_u * NF, tot_f = plane_f * NF;
+  const GArr<BUF> g_u0(a.u0, tot_u), g_u1(a.u1, tot_u), g_div(a.div, tot_u), g_src(a.src, tot_u), g_dj(a.detjac_upts, plane_u);
+  const GArr<BUF> g_tc(a.tconf, tot_f), g_nt(a.ntd_fpts, tot_f), g_dn(a.disu_next, tot_f);
+  const EleOrder order(ne, a.xcd_order != 0);
+  for (long kk = 0, e = order.at(0); e >= 0; kk++, e = order.at(kk))
   {
-    const long p = tu + NU * e, o = tf + NFP * e;
+    const long eu = (long)NU * e, ef = (long)NFP * e;
     double u[NF], dvin[NF], u1v[NF];
     if (is_f)
     {
 #pragma unroll
-      for (int k = 0; k < NF; k++) sc[k][tf] = a.tconf[o + k * plane_f] + -1.0 * a.ntd_fpts[o + k * plane_f];
+      for (int k = 0; k < NF; k++) sc[k][tf] = g_tc.ld(ef + k * plane_f, lf) + -1.0 * g_nt.ld(ef + k * plane_f, lf);
     }
     const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
-    const double dj = a.detjac_upts[p];
+    const double dj = g_dj.ld(eu, lu);
 #pragma unroll
     for (int k = 0; k < NF; k++)
     {
-      u[k] = a.u0[p + k * plane_u];
-      dvin[k] = a.div[p + k * plane_u];
-      u1v[k] = a.need_u1 ? a.u1[p + k * plane_u] : 0.0;
+      const long ok = eu + k * plane_u;
+      u[k] = g_u0.ld(ok, lu);
+      dvin[k] = g_div.ld(ok, lu);
+      u1v[k] = a.need_u1 ? g_u1.ld(ok, lu) : 0.0;
     }
     lds_barrier();
     if (is_u)
@@ -2547,17 +2666,17 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), 3) void split_update_kernel(cons
       for (int k = 0; k < NF; k++)
       {
         const double dv = dva[k];
-        const long q = p + k * plane_u;
-        if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)q);
-        if (a.write_div) a.div[q] = dv;
-        const double s = a.src ? a.src[q] : 0.0;
+        const long ok = eu + k * plane_u;
+        if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)(ok + tu));
+        if (a.write_div) g_div.st(ok, lu, dv);
+        const double s = a.src ? g_src.ld(ok, lu) : 0.0;
         const double dd = dv / dj;
         double un = u[k];
         if (a.adv_type == 0)
           un -= dt * (dd - s);
         else if (a.adv_type == 1)
         {
-          if (a.in_step == 0) a.u1[q] = un;
+          if (a.in_step == 0) g_u1.st(ok, lu, un);
           if (a.in_step < 3)
             un -= dt / 3.0 * (dd - s);
           else
@@ -2568,7 +2687,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), 3) void split_update_kernel(cons
         }
         else if (a.adv_type == 2)
         {
-          if (a.in_step == 0) a.u1[q] = un;
+          if (a.in_step == 0) g_u1.st(ok, lu, un);
           if (a.in_step < 2 || a.in_step == 3)
             un -= dt / 2.0 * (dd - s);
           else if (a.in_step == 2)
@@ -2581,10 +2700,10 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), 3) void split_update_kernel(cons
         {
           const double rhs = -dd + s;
           const double r1 = a.rk_a * u1v[k] + dt * rhs;
-          a.u1[q] = r1;
+          g_u1.st(ok, lu, r1);
           un += a.rk_b * r1;
         }
-        a.u0[q] = un;
+        g_u0.st(ok, lu, un);
         su[k][tu] = un;
       }
     }
@@ -2604,7 +2723,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), 3) void split_update_kernel(cons
         for (int k = 0; k < NF; k++) un[k] += c0[q] * x[k];
       }
 #pragma unroll
-      for (int k = 0; k < NF; k++) a.disu_next[o + k * plane_f] = un[k];
+      for (int k = 0; k < NF; k++) g_dn.st(ef + k * plane_f, lf, un[k]);
     }
     lds_barrier();
   }
@@ -2638,6 +2757,8 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     }
     if (!F->fn_fpts) HFX_HIP(hipMalloc((void **)&F->fn_fpts, sizeof(double) * (size_t)plane_f * e->n_fields));
     e2.n_eles = ea.n_eles;
+    static const bool no_xcd = getenv("HFX_NO_XCD_ORDER") != nullptr;
+    e2.xcd_order = no_xcd ? 0 : 1;
     e2.pk_g = F->pk_g; e2.pk_r = F->pk_r; e2.tab_g = F->tab_g; e2.tab_r = F->tab_r; e2.o1m_dim = F->o1m_dim;
     e2.detjac_upts = ea.detjac_upts; e2.JGinv_upts = ea.JGinv_upts; e2.detjac_fpts = ea.detjac_fpts;
     e2.JGinv_fpts = ea.JGinv_fpts; e2.norm_fpts = e->norm_fpts;
@@ -2675,12 +2796,24 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   {
     if (which == 0 || which == 2)
     {
+      e2.tdisf_in = nullptr;
+      if (e->over_int_ready)
+      {
+        // polynomial de-aliasing (src/solver.cpp:82-91): tdisf_upts = over_int_filter . F(opp_over_int_cubpts . u)
+        if (hfx_eles_evaluate_invFlux_over_int(e)) return 1;
+        e2.tdisf_in = e->arr[HFX_TDISF_UPTS];
+      }
       static const bool dict_only = getenv("HFX_SPLIT_DICT") != nullptr; // A/B switch for measurements
       static const int waves = getenv("HFX_SPLIT2T_WAVES") ? atoi(getenv("HFX_SPLIT2T_WAVES")) : HFX_SPLIT2T_WAVES;
-      if (F->tensor_ok && !dict_only && waves == 2)
-        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+      // buffer-descriptor addressing needs 32-bit byte offsets into the largest array the kernel touches
+      static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
+      const bool buf = !nobuf && (double)plane_f * e->n_fields * e->n_dims * 8.0 < 4294967296.0;
+      if (F->tensor_ok && !dict_only && waves == 2 && buf)
+        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+      else if (F->tensor_ok && !dict_only && buf)
+        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 3, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
       else if (F->tensor_ok && !dict_only)
-        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 3>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, false>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
       else
         hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
     }
@@ -2726,7 +2859,15 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   if (which == 0 || which == 4)
   {
     if (variant == 3)
-      hipLaunchKernelGGL((split_update_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+    {
+      // buffer-descriptor addressing needs 32-bit byte offsets
+      static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
+      const bool small = (double)plane_f * e->n_fields * 8.0 < 4294967296.0;
+      if (small && !nobuf)
+        hipLaunchKernelGGL((split_update_kernel<ND, N, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+      else
+        hipLaunchKernelGGL((split_update_kernel<ND, N, false>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+    }
     else
     {
       ea.pk = F->pk_r;
@@ -2777,6 +2918,7 @@ static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_st
 int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int variant)
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
+  HFX_CHECK(!e->over_int_ready || variant == 3, "fused=2 has no over-integration: use fused=3");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
   if (n_steps <= 0) return 0;
@@ -2921,6 +3063,7 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
   };
   const bool last = in_step == nst - 1;
   const int variant = (e->ctx->fused_mode == 2) ? 2 : 3; // 3: fluxes in the gradient kernel, Fn on the wire
+  HFX_CHECK(!e->over_int_ready || variant == 3, "fused=2 has no over-integration: use fused=3");
   switch (phase)
   {
   case 0:

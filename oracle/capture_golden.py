@@ -82,6 +82,8 @@ BC_KEYS = dict(
     bc_InR_pressure_ramp=1, bc_InR_p_ramp_coeff=0.01, bc_InR_T_ramp_coeff=-1.0, bc_InR_p_total_old=P_TGV * 1.002,
 )
 
+# threshold inside the widest gap of hex_p4_jet's first-stage sensor values (so that rounding cannot flip an element)
+HEX_P4_JET_S0 = 7.0e-7
 
 CASES = [
     # full dump of every intermediate of one residual on a deformed mesh
@@ -138,6 +140,11 @@ CASES = [
          expf_order=4, expf_cutoff=0, shock_det_field=1),
     case("quad_p3_shock", dims=2, n=4, amp=0.1, level=1, order=3, steps=1, shock_cap=1, shock_det=0, s0=1.8616e-7,
          expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0),
+    # BASELINE.json configs[4] in small: P4 hexes, HLLC, shock capturing AND polynomial de-aliasing together, supersonic
+    # in- and outflow, a characteristic far field and slip walls around a box (the pieces of the supersonic-jet case)
+    case("hex_p4_jet", n=2, amp=0.12, level=1, order=4, steps=1, riemann_solve_type=3, over_int=1, over_int_order=6,
+         shock_cap=1, shock_det=0, s0=HEX_P4_JET_S0, expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0,
+         bcs={"z-": "SupI", "z+": "SupO", "x-": "Far", "x+": "Far", "y-": "Slip", "y+": "Slip"}, **BC_KEYS),
     # boundary faces (bdy_inters): every ghost-state branch that the shipped cases use
     case("hex_p2_bdy_walls", amp=0.1, level=2, order=2, steps=1,
          bcs={"z-": "In", "z+": "Out", "y-": "WallT", "y+": "WallQ", "x-": "Far", "x+": "Slip"}, **BC_KEYS),
