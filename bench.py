@@ -76,7 +76,8 @@ def cpu_baseline(order, threads):
     import oracle_py as O
     orc = O.load()
     out = {}
-    for label, n_cells, nthr, nsteps in (("1core", 8, 1, 1), ("allcores", 16, threads, 2)):
+    # bounded sample, about 10-20 s of CPU work in all: 8^3 for one step on one core, 16^3 for 12 steps on all cores
+    for label, n_cells, nthr, nsteps in (("1core", 8, 1, 2), ("allcores", 16, threads, 12)):
         case = H.Case(n_cells, order=order)
         reg = case.registration()
         oc = O.Case(reg)

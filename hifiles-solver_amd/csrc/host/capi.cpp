@@ -43,6 +43,12 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
   in.Mach_c_ic = d->Mach_c_ic; in.T_c_ic = d->T_c_ic; in.rho_c_ic = d->rho_c_ic;
   in.u_c_ic = d->u_c_ic; in.v_c_ic = d->v_c_ic; in.w_c_ic = d->w_c_ic; in.p_c_ic = d->p_c_ic;
   in.dx_cyclic = in.dy_cyclic = in.dz_cyclic = d->length;
+  in.over_int = d->over_int; in.over_int_order = d->over_int_order;
+  in.shock_cap = d->shock_cap; in.shock_det_field = d->shock_det_field; in.s0 = d->s0;
+  if (d->shock_cap)
+  {
+    in.expf_fac = d->expf_fac; in.expf_order = d->expf_order; in.expf_cutoff = d->expf_cutoff;
+  }
   if (d->loc_1d_upts)
   {
     in.loc_1d_upts_override.setup(d->order + 1);
@@ -126,6 +132,14 @@ extern "C" int hfxh_case_get_array(hfxh_case *c, const char *name, const double 
     else if (which == 4 && E->viscous) a = &E->opp_4(d);
     else if (which == 5 && E->viscous) a = &E->opp_5(d);
   }
+  else if (n == "inv_vandermonde") a = &E->inv_vandermonde;
+  else if (n == "vandermonde") a = &E->vandermonde;
+  else if (n == "exp_filter") a = &E->exp_filter;
+  else if (n == "norm_basis_persson") a = &E->norm_basis_persson;
+  else if (n == "opp_over_int_cubpts") a = &E->opp_over_int_cubpts;
+  else if (n == "over_int_filter") a = &E->over_int_filter;
+  else if (n == "JGinv_over_int_cubpts") a = &E->JGinv_over_int_cubpts;
+  else if (n == "loc_over_int_cubpts") a = &E->loc_over_int_cubpts;
   else if (n == "detjac_upts") a = &E->detjac_upts;
   else if (n == "JGinv_upts") a = &E->JGinv_upts;
   else if (n == "detjac_fpts") a = &E->detjac_fpts;

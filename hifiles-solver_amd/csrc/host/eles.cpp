@@ -36,6 +36,9 @@ int eles::setup(int in_n_eles, int in_max_n_spts_per_ele, input *in_run_input)
   order = run_input->order;
   viscous = run_input->viscous;
   if (setup_ele_type_specific()) return 1;
+  // src/eles_hexas.cpp:74-92, src/eles_quads.cpp:77-102
+  if (run_input->shock_cap && set_shock_capture_operators()) return 1;
+  if (run_input->over_int && set_over_int()) return 1;
   shape.setup(n_dims, max_n_spts_per_ele, n_eles);
   n_spts_per_ele.setup(n_eles);
   n_spts_per_ele.initialize_to_value(max_n_spts_per_ele);
@@ -174,13 +177,16 @@ void eles::calc_d_pos(const hf_array<double> &in_loc, int in_ele, hf_array<doubl
     }
 }
 
-int eles::set_transforms_pts(bool at_fpts)
+int eles::set_transforms_pts(int which)
 {
-  const int npts = at_fpts ? n_fpts_per_ele : n_upts_per_ele;
-  hf_array<double> &detjac = at_fpts ? detjac_fpts : detjac_upts;
-  hf_array<double> &JGinv = at_fpts ? JGinv_fpts : JGinv_upts;
-  hf_array<double> &posa = at_fpts ? pos_fpts : pos_upts;
-  const hf_array<double> &locs = at_fpts ? tloc_fpts : loc_upts;
+  // which 2: the over-integration cubature points (src/eles.cpp:4155-4210): JGinv only
+  const bool at_fpts = which == 1, at_cub = which == 2;
+  const int npts = at_cub ? loc_over_int_cubpts.get_dim(1) : (at_fpts ? n_fpts_per_ele : n_upts_per_ele);
+  hf_array<double> detjac_cub, pos_cub;
+  hf_array<double> &detjac = at_cub ? detjac_cub : (at_fpts ? detjac_fpts : detjac_upts);
+  hf_array<double> &JGinv = at_cub ? JGinv_over_int_cubpts : (at_fpts ? JGinv_fpts : JGinv_upts);
+  hf_array<double> &posa = at_cub ? pos_cub : (at_fpts ? pos_fpts : pos_upts);
+  const hf_array<double> &locs = at_cub ? loc_over_int_cubpts : (at_fpts ? tloc_fpts : loc_upts);
   detjac.setup(npts, n_eles);
   JGinv.setup(n_dims, n_dims, npts, n_eles);
   posa.setup(npts, n_eles, n_dims);
@@ -226,7 +232,7 @@ int eles::set_transforms_pts(bool at_fpts)
       {
         const double xr = d_pos(0, 0), xs = d_pos(0, 1), yr = d_pos(1, 0), ys = d_pos(1, 1);
         detjac(j, i) = xr * ys - xs * yr;
-        if (detjac(j, i) < 0)
+        if (detjac(j, i) < 0 && !at_cub)
         {
           fail(at_fpts ? "Negative Jacobian at flux points" : "Negative Jacobian at solution points");
           return 1;
@@ -278,8 +284,9 @@ int eles::set_transforms_pts(bool at_fpts)
 int eles::set_transforms()
 {
   if (n_eles == 0) return 0;
-  if (set_transforms_pts(false)) return 1;
-  if (set_transforms_pts(true)) return 1;
+  if (set_transforms_pts(0)) return 1;
+  if (set_transforms_pts(1)) return 1;
+  if (run_input->over_int && set_transforms_pts(2)) return 1;
   return 0;
 }
 
@@ -391,6 +398,20 @@ int eles::mv_all_cpu_gpu(hfx_ctx *ctx)
       return 1;
     }
   if (hfx_eles_set_h_ref(dev, h_ref.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
+  if (run_input->over_int &&
+      hfx_eles_set_over_int(dev, loc_over_int_cubpts.get_dim(1), opp_over_int_cubpts.get_ptr_cpu(), over_int_filter.get_ptr_cpu(),
+                            JGinv_over_int_cubpts.get_ptr_cpu()))
+  {
+    fail(hfx_last_error());
+    return 1;
+  }
+  if (run_input->shock_cap &&
+      hfx_eles_set_shock_capture(dev, inv_vandermonde.get_ptr_cpu(), exp_filter.get_ptr_cpu(), norm_basis_persson.get_ptr_cpu(),
+                                 persson_high_modes.get_ptr_cpu(), run_input->s0, run_input->shock_det_field))
+  {
+    fail(hfx_last_error());
+    return 1;
+  }
   return 0;
 }
 
@@ -425,6 +446,8 @@ int eles::cp_disu_upts_cpu_gpu()
 void eles::extrapolate_solution() { HFX_CALL(hfx_eles_extrapolate_solution(dev)); }
 void eles::calculate_gradient() { HFX_CALL(hfx_eles_calculate_gradient(dev)); }
 void eles::evaluate_invFlux() { HFX_CALL(hfx_eles_evaluate_invFlux(dev)); }
+void eles::evaluate_invFlux_over_int() { HFX_CALL(hfx_eles_evaluate_invFlux_over_int(dev)); }
+void eles::shock_capture() { HFX_CALL(hfx_eles_shock_capture(dev)); }
 void eles::correct_gradient() { HFX_CALL(hfx_eles_correct_gradient(dev)); }
 void eles::evaluate_viscFlux() { HFX_CALL(hfx_eles_evaluate_viscFlux(dev)); }
 void eles::extrapolate_totalFlux() { HFX_CALL(hfx_eles_extrapolate_totalFlux(dev)); }

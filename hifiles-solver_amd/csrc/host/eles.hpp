@@ -40,6 +40,8 @@ public:
   void extrapolate_solution();
   void calculate_gradient();
   void evaluate_invFlux();
+  void evaluate_invFlux_over_int(); // src/eles.cpp:1480 (run_input.over_int)
+  void shock_capture();             // src/eles.cpp:2918 (run_input.shock_cap), after AdvanceSolution
   void correct_gradient();
   void evaluate_viscFlux();
   void extrapolate_totalFlux();
@@ -74,6 +76,14 @@ public:
   hf_array<hf_array<double>> div_tconf_upts;
   hf_array<double> grad_disu_upts;
   hf_array<double> h_ref, dt_local;
+  // ---- modal operators of the tensor-product classes (eles_modal.cpp): shock capturing and over-integration
+  // (include/eles.h:926-935; eles_hexas.h / eles_quads.h: vandermonde, inv_vandermonde, norm_basis_persson)
+  hf_array<double> vandermonde, inv_vandermonde, exp_filter, norm_basis_persson;
+  hf_array<int> persson_high_modes; // 1: a mode with a degree == order in some direction
+  hf_array<double> loc_over_int_cubpts, weight_over_int_cubpts, opp_over_int_cubpts, over_int_filter, JGinv_over_int_cubpts;
+  int set_shock_capture_operators(); // set_vandermonde1D/3D, calc_norm_basis, set_exp_filter
+  int set_over_int();                // set_over_int (cubature points, interpolation, L2-projection filter)
+  void tensor_modes(hf_array<int> &deg) const;
   // ---- ASCII restart (src/eles.cpp:655-760,845-870; info blocks src/eles_hexas.cpp:799-890, eles_quads.cpp)
   hf_array<int> ele2global_ele;
   int order_rest = 0, n_upts_per_ele_rest = 0;
@@ -101,7 +111,7 @@ protected:
   void set_opp_6();
   void calc_pos(const hf_array<double> &in_loc, int in_ele, hf_array<double> &out_pos);
   void calc_d_pos(const hf_array<double> &in_loc, int in_ele, hf_array<double> &out_d_pos);
-  int set_transforms_pts(bool at_fpts);
+  int set_transforms_pts(int which); // 0 solution points, 1 flux points, 2 over-integration cubature points
   void fail(const std::string &msg);
 
   hfx_eles *dev = nullptr;

@@ -1,0 +1,236 @@
+// eles_modal.cpp -- the modal-basis operators of the tensor-product element classes (hexes, quads): what the
+// reference builds in eles_hexas / eles_quads ::set_vandermonde1D/3D (src/eles_hexas.cpp:926-951), set_exp_filter
+// (:953-989), calc_norm_basis (:991-1004), set_over_int (:1096-1129) and their eles_quads twins
+// (src/eles_quads.cpp:759-959), i.e. the matrices behind shock capturing and over-integration
+// (row a5).
+//
+// The reference assembles the n_upts x n_upts Vandermonde matrix of the hierarchical tensor Legendre basis, inverts it
+// by full-pivot Gaussian elimination (src/funcs.cpp:2751) and multiplies dense matrices.  Here every operator is
+// assembled from its 1-D factor: the basis is a tensor product, so
+//     vandermonde      = P (V1 x V1 x V1),        inv_vandermonde = (W1 x W1 x W1) P^T,      W1 = V1^-1,
+//     exp_filter       = E1 x E1 x E1,            E1 = V1 diag(sigma) W1,
+//     over_int_filter  = F1 x F1 x F1,            F1 = V1 diag((2m+1)/2) [P_m(c) w_c],
+//     opp_over_int_cubpts = I1 x I1 x I1,         I1 = l_i(c)
+// (P: the reference's "hierarchical" mode order, modes sorted by the sum of their 1-D degrees).  Same matrices to
+// rounding (tests/test_host_setup_vs_golden.py holds them to 1e-12 of the reference's), O(N^2) work per factor and
+// a 1-D inverse of an (order+1)^2 matrix instead of a 125 x 125 one.
+#include <cmath>
+#include <vector>
+
+#include "basis.hpp"
+#include "eles.hpp"
+
+namespace
+{
+// inverse of a small dense matrix (n x n, column-major a(i,j) = a[i + n*j]), Gauss-Jordan with row pivoting
+bool invert_small(int n, std::vector<double> a, std::vector<double> &inv)
+{
+  inv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) inv[i + (size_t)n * i] = 1.0;
+  for (int c = 0; c < n; c++)
+  {
+    int piv = c;
+    for (int r = c + 1; r < n; r++)
+      if (std::fabs(a[r + (size_t)n * c]) > std::fabs(a[piv + (size_t)n * c])) piv = r;
+    if (a[piv + (size_t)n * c] == 0.0) return false;
+    if (piv != c)
+      for (int j = 0; j < n; j++)
+      {
+        std::swap(a[c + (size_t)n * j], a[piv + (size_t)n * j]);
+        std::swap(inv[c + (size_t)n * j], inv[piv + (size_t)n * j]);
+      }
+    const double d = 1.0 / a[c + (size_t)n * c];
+    for (int j = 0; j < n; j++)
+    {
+      a[c + (size_t)n * j] *= d;
+      inv[c + (size_t)n * j] *= d;
+    }
+    for (int r = 0; r < n; r++)
+    {
+      if (r == c) continue;
+      const double f = a[r + (size_t)n * c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; j++)
+      {
+        a[r + (size_t)n * j] -= f * a[c + (size_t)n * j];
+        inv[r + (size_t)n * j] -= f * inv[c + (size_t)n * j];
+      }
+    }
+  }
+  return true;
+}
+} // namespace
+
+// degrees (i, j[, k]) of every mode in the reference's hierarchical order: sorted by the sum of the degrees, the
+// last direction's degree ascending inside a sum, then the second's (eval_legendre_basis_3D_hierarchical,
+// src/eles_hexas.cpp:1364-1403; 2-D: src/eles_quads.cpp:1116-1150)
+void eles::tensor_modes(hf_array<int> &deg) const
+{
+  const int p = order;
+  deg.setup(n_dims, n_upts_per_ele);
+  int mode = 0;
+  if (n_dims == 3)
+  {
+    for (int l = 0; l < 3 * p + 1; l++)
+      for (int k = 0; k < l + 1; k++)
+        for (int j = 0; j < l - k + 1; j++)
+        {
+          const int i = l - k - j;
+          if (i <= p && j <= p && k <= p)
+          {
+            deg(0, mode) = i;
+            deg(1, mode) = j;
+            deg(2, mode) = k;
+            mode++;
+          }
+        }
+  }
+  else
+  {
+    for (int k = 0; k < 2 * p + 1; k++)
+      for (int j = 0; j < k + 1; j++)
+      {
+        const int i = k - j;
+        if (i <= p && j <= p)
+        {
+          deg(0, mode) = i;
+          deg(1, mode) = j;
+          mode++;
+        }
+      }
+  }
+}
+
+// out(row, col) = prod_d f(r_d, c_d): rows / columns are tensor indices with the first direction fastest
+// (solution points upt = k + N j + N^2 i <-> (x_k, y_j, z_i), cubature points likewise), f is nr1 x nc1 column-major
+static void kron_fill(int nd, int nr1, int nc1, const std::vector<double> &f, hf_array<double> &out)
+{
+  int nr = 1, nc = 1;
+  for (int d = 0; d < nd; d++)
+  {
+    nr *= nr1;
+    nc *= nc1;
+  }
+  out.setup(nr, nc);
+  for (int c = 0; c < nc; c++)
+    for (int r = 0; r < nr; r++)
+    {
+      double v = 1.0;
+      int rr = r, cc = c;
+      for (int d = 0; d < nd; d++)
+      {
+        v *= f[(rr % nr1) + (size_t)nr1 * (cc % nc1)];
+        rr /= nr1;
+        cc /= nc1;
+      }
+      out(r, c) = v;
+    }
+}
+
+int eles::set_shock_capture_operators()
+{
+  const int N = order + 1, nu = n_upts_per_ele;
+  // 1-D Vandermonde V1(point, degree) = P_degree(x_point) and its inverse (set_vandermonde1D)
+  std::vector<double> V1((size_t)N * N), W1;
+  for (int i = 0; i < N; i++)
+    for (int m = 0; m < N; m++) V1[i + (size_t)N * m] = eval_legendre(loc_1d_upts(i), m);
+  if (!invert_small(N, V1, W1))
+  {
+    fail("singular 1-D Vandermonde matrix");
+    return 1;
+  }
+  hf_array<int> deg;
+  tensor_modes(deg);
+  // set_vandermonde3D / 2D and its inverse
+  vandermonde.setup(nu, nu);
+  inv_vandermonde.setup(nu, nu);
+  for (int pt = 0; pt < nu; pt++)
+    for (int mode = 0; mode < nu; mode++)
+    {
+      double v = 1.0, w = 1.0;
+      int r = pt;
+      for (int d = 0; d < n_dims; d++)
+      {
+        v *= V1[(r % N) + (size_t)N * deg(d, mode)];
+        w *= W1[deg(d, mode) + (size_t)N * (r % N)];
+        r /= N;
+      }
+      vandermonde(pt, mode) = v;
+      inv_vandermonde(mode, pt) = w;
+    }
+  // calc_norm_basis and the highest modes of the Persson sensor (shock_det_persson: any degree == order)
+  norm_basis_persson.setup(nu);
+  persson_high_modes.setup(nu);
+  for (int mode = 0; mode < nu; mode++)
+  {
+    double nrm = 1.0;
+    int high = 0;
+    for (int d = 0; d < n_dims; d++)
+    {
+      nrm *= 2.0 / (2.0 * deg(d, mode) + 1.0);
+      if (deg(d, mode) == order) high = 1;
+    }
+    norm_basis_persson(mode) = nrm;
+    persson_high_modes(mode) = high;
+  }
+  // set_exp_filter: sigma(degree) per direction, E1 = V1 diag(sigma) W1
+  if (run_input->shock_cap == 1)
+  {
+    const double eta_c = (double)run_input->expf_cutoff / (double)order;
+    std::vector<double> E1((size_t)N * N, 0.0);
+    for (int m = 0; m < N; m++)
+    {
+      const double eta = (double)m / (double)order;
+      double sigma = 1.0;
+      if (eta > eta_c) sigma = std::exp(-run_input->expf_fac * std::pow((eta - eta_c) / (1. - eta_c), run_input->expf_order));
+      for (int a = 0; a < N; a++)
+        for (int b = 0; b < N; b++) E1[a + (size_t)N * b] += V1[a + (size_t)N * m] * sigma * W1[m + (size_t)N * b];
+    }
+    kron_fill(n_dims, N, N, E1, exp_filter);
+  }
+  return 0;
+}
+
+int eles::set_over_int()
+{
+  const int N = order + 1, Nc = run_input->over_int_order + 1;
+  if (Nc < 1 || Nc > 16)
+  {
+    fail("cubature order not implemented."); // src/cubature_1d.cpp:84
+    return 1;
+  }
+  // set_volume_cubpts: tensor Gauss points, first direction fastest (src/cubature_hexa.cpp:49-74)
+  hf_array<double> c1, w1;
+  cubature_1d_nodes(0, Nc, c1, w1);
+  int n_cub = 1;
+  for (int d = 0; d < n_dims; d++) n_cub *= Nc;
+  loc_over_int_cubpts.setup(n_dims, n_cub);
+  weight_over_int_cubpts.setup(n_cub);
+  for (int q = 0; q < n_cub; q++)
+  {
+    int r = q;
+    double w = 1.0;
+    for (int d = 0; d < n_dims; d++)
+    {
+      loc_over_int_cubpts(d, q) = c1(r % Nc);
+      w *= w1(r % Nc);
+      r /= Nc;
+    }
+    weight_over_int_cubpts(q) = w;
+  }
+  // set_opp_volume_cubpts: nodal basis at the cubature points, I1(c, i) = l_i(x_c)
+  std::vector<double> I1((size_t)Nc * N), F1((size_t)N * Nc, 0.0);
+  for (int c = 0; c < Nc; c++)
+    for (int i = 0; i < N; i++) I1[c + (size_t)Nc * i] = eval_lagrange(c1(c), i, loc_1d_upts);
+  kron_fill(n_dims, Nc, N, I1, opp_over_int_cubpts);
+  // L2 projection on the modal basis, then back to the solution points: F1(a, c) = sum_m P_m(x_a) (2m+1)/2 P_m(x_c) w_c
+  for (int a = 0; a < N; a++)
+    for (int c = 0; c < Nc; c++)
+    {
+      double s = 0.0;
+      for (int m = 0; m < N; m++) s += eval_legendre(loc_1d_upts(a), m) * (eval_legendre(c1(c), m) / (2.0 / (2.0 * m + 1.0)) * w1(c));
+      F1[a + (size_t)N * c] = s;
+    }
+  kron_fill(n_dims, N, Nc, F1, over_int_filter);
+  return 0;
+}

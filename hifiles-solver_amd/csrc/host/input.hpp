@@ -29,6 +29,11 @@ struct input
   int ic_form = 7, adv_type = 3, dt_type = 0, n_steps = 1;
   double dt = 0.0, CFL = 0.0;
   double ldg_tau = 0.0, ldg_beta = 0.5;
+  // ---- polynomial de-aliasing and shock capturing (src/input.cpp:248-263)
+  int over_int = 0, over_int_order = 0;
+  int shock_cap = 0, shock_det = 0, shock_det_field = 0;
+  double s0 = 0.0, expf_fac = 36.0;
+  int expf_order = 4, expf_cutoff = 0;
   // ---- element parameters
   int upts_type_hexa = 0, vcjh_scheme_hexa = 1;
   double eta_hexa = 0.0;

@@ -422,7 +422,10 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
     /*! Compute the uncorrected transformed gradient of the solution at the solution points. */
     each_ele(&eles::calculate_gradient);
   /*! Compute the transformed inviscid flux at the solution points. */
-  each_ele(&eles::evaluate_invFlux);
+  if (FlowSol->run_input.over_int) /* src/solver.cpp:82-91 */
+    each_ele(&eles::evaluate_invFlux_over_int);
+  else
+    each_ele(&eles::evaluate_invFlux);
   /*! Compute the transformed normal inviscid numerical fluxes, common solution and corrections. */
   for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_invFlux();
   for (i = 0; i < FlowSol->n_bdy_inter_types; i++)
@@ -494,6 +497,9 @@ int RunSteps(solution *FlowSol, int n_steps)
       CalcResidual(FlowSol->ini_iter + i_steps, i, FlowSol);
       for (int j = 0; j < FlowSol->n_ele_types; j++)
         if (FlowSol->mesh_eles(j)) FlowSol->mesh_eles(j)->AdvanceSolution(i, FlowSol->run_input.adv_type);
+      if (FlowSol->run_input.shock_cap) /* src/HiFiLES.cpp:214-216 */
+        for (int j = 0; j < FlowSol->n_ele_types; j++)
+          if (FlowSol->mesh_eles(j)) FlowSol->mesh_eles(j)->shock_capture();
     }
     FlowSol->time += FlowSol->run_input.dt;
     FlowSol->run_input.time = FlowSol->time;

@@ -25,7 +25,9 @@ class CaseDesc(C.Structure):
                                           "rho_c_ic", "Mach_c_ic", "T_c_ic", "u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic")] + \
                [("rank", C.c_int), ("nproc", C.c_int), ("pgrid", C.c_int * 3),
                 ("n_bcs", C.c_int), ("bcs", C.c_void_p), ("side_bc", C.c_int * 6),
-                ("dt_type", C.c_int), ("CFL", C.c_double)]
+                ("dt_type", C.c_int), ("CFL", C.c_double),
+                ("over_int", C.c_int), ("over_int_order", C.c_int), ("shock_cap", C.c_int), ("shock_det_field", C.c_int),
+                ("s0", C.c_double), ("expf_fac", C.c_double), ("expf_order", C.c_int), ("expf_cutoff", C.c_int)]
 
 
 class BcDesc(C.Structure):

@@ -64,6 +64,14 @@ typedef struct hfxh_case_desc
   /* time step: dt_type 0 fixed `dt`, 1 global CFL minimum, 2 local CFL steps (src/input.cpp:141-158) */
   int dt_type;
   double CFL;
+  /* polynomial de-aliasing and shock capturing, the reference's keys (src/input.cpp:248-263): over_int,
+   * over_int_order; shock_cap (1: exponential modal filter), shock_det_field (0 density, 1 total energy), s0,
+   * expf_fac, expf_order, expf_cutoff.  The matrices (opp_over_int_cubpts, over_int_filter, JGinv_over_int_cubpts,
+   * inv_vandermonde, exp_filter, norm_basis_persson) are built by the host mirror (csrc/host/eles_modal.cpp). */
+  int over_int, over_int_order;
+  int shock_cap, shock_det_field;
+  double s0, expf_fac;
+  int expf_order, expf_cutoff;
 } hfxh_case_desc;
 
 const char *hfxh_last_error(void);

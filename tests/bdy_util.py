@@ -35,8 +35,11 @@ def case_from_fixture(d, **over):
     kw = dict(dims=meta["dims"], order=kk["order"], adv_type=kk["adv_type"], riemann_solve_type=kk["riemann_solve_type"],
               viscous=kk["viscous"], ic_form=kk["ic_form"], fix_vis=kk["fix_vis"], T_c_ic=kk["T_c_ic"], rho_c_ic=kk["rho_c_ic"],
               upts_type=kk["upts_type_hexa"], vcjh_scheme=kk["vcjh_scheme_hexa"])
-    for k in ("u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic"):
+    for k in ("u_c_ic", "v_c_ic", "w_c_ic", "p_c_ic", "over_int", "over_int_order", "shock_cap", "shock_det_field", "s0",
+              "expf_fac", "expf_order", "expf_cutoff", "dt"):
         if k in kk:
             kw[k] = kk[k]
+    if meta["dims"] == 2:
+        kw["upts_type"], kw["vcjh_scheme"] = kk["upts_type_quad"], kk["vcjh_scheme_quad"]
     kw.update(over)
     return H.Case(n + [1] * (3 - len(n)), xv=d["xv"], bcs=bcs, sides=sides, **kw), meta

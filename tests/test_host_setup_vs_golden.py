@@ -142,3 +142,27 @@ def test_isentropic_vortex_initial_state():
     L, R = c.faces()
     assert np.array_equal(L, d["int0_L"]) and np.array_equal(R, d["int0_R"])
     c.close()
+
+
+MODAL = ["hex_p2_overint", "quad_p3_overint", "hex_p3_shock", "hex_p2_shock_energy", "quad_p3_shock", "hex_p4_jet"]
+
+
+@pytest.mark.parametrize("name", MODAL)
+def test_modal_operators_vs_reference(name):
+    """The producers of the shock-capturing and over-integration matrices (csrc/host/eles_modal.cpp: 1-D factors and
+    Kronecker products) against the matrices the genuine reference built by dense inversion / multiplication
+    (set_vandermonde3D, set_exp_filter, calc_norm_basis, set_over_int; JGinv at the cubature points)."""
+    import bdy_util
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    c, meta = bdy_util.case_from_fixture(d)
+    keys = []
+    if "over_int" in d:
+        keys += ["opp_over_int_cubpts", "over_int_filter", "JGinv_over_int_cubpts"]
+    if "shock_cap" in d:
+        keys += ["inv_vandermonde", "exp_filter", "norm_basis_persson"]
+    assert keys
+    for k in keys:
+        got, want = c.array(k), d[k]
+        assert got.shape == want.shape, k
+        assert rel(got, want) < 5e-14, (k, rel(got, want))
+    c.close()
