@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--order", type=int, default=4)
     ap.add_argument("--mode", default="auto", choices=["auto", "fused", "split", "split3", "methods", "dense"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    # BASELINE.json configs[4]'s ingredients on the same mesh (not the default workload): polynomial de-aliasing of the
+    # inviscid flux and shock capturing after every stage
+    ap.add_argument("--over-int-order", type=int, default=-1, help="over_int 1 with this over_int_order (cubature points per direction - 1)")
+    ap.add_argument("--shock-s0", type=float, default=-1.0, help="shock_cap 1 with this sensor threshold s0")
     args = ap.parse_args()
 
     import torch
@@ -132,7 +136,12 @@ def main():
     import hfx_host as H
 
     pgrid = {1: None, 2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}.get(world, [world, 1, 1])
-    case = H.Case(args.n, order=args.order, rank=rank, pgrid=pgrid)
+    extra = {}
+    if args.over_int_order >= 0:
+        extra.update(over_int=1, over_int_order=args.over_int_order)
+    if args.shock_s0 >= 0:
+        extra.update(shock_cap=1, s0=args.shock_s0, expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0)
+    case = H.Case(args.n, order=args.order, rank=rank, pgrid=pgrid, **extra)
     case.to_device(local_rank)
     ctx, e, faces, nb = case.handles()
     lib = hfx.lib()
@@ -169,7 +178,8 @@ def main():
     if world > 1:
         mode = "split3" if mode == "auto" else mode
     elif mode in ("auto", "fused", "split", "split3"):
-        rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(1))
+        probe = {"fused": 1, "split": 2, "split3": 3}[DEFAULT_FUSED if mode == "auto" else mode]
+        rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(probe))
         fused_ok = (rc == 0)
         if mode != "auto" and not fused_ok:
             raise SystemExit("fused path unavailable: " + lib.hfx_last_error().decode())
@@ -288,7 +298,9 @@ def main():
             "ms_per_rk_stage": ms_per_stage, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Taylor-Green vortex, %d^3 hexa per GPU, P%d, Navier-Stokes, HLLC+LDG, RK45, "
-                                   "1 step = %d RK stages" % (args.n, args.order, n_stages),
+                                   "1 step = %d RK stages" % (args.n, args.order, n_stages) +
+                                   (", over-integration order %d" % args.over_int_order if args.over_int_order >= 0 else "") +
+                                   (", shock capturing s0 %g" % args.shock_s0 if args.shock_s0 >= 0 else ""),
                        "n_eles_per_gpu": case.n_eles, "dof_per_gpu": dof_per_rank, "path": mode,
                        "multi_gpu": "none" if world == 1 else
                        "one periodic box split into %s blocks, partition-face exchange over %s p2p" %

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "fused_hex.hpp"
+#include "tensor_ops.hpp"
 #include "hfx_internal.hpp"
 #include "kernels_ops.hpp"
 #include "kernels_bdy.hpp"
@@ -443,6 +444,7 @@ int hfx_eles_destroy(hfx_eles *e)
     if (p) (void)hipFree(p);
   if (e->persson_num) (void)hipFree(e->persson_num);
   if (e->persson_den) (void)hipFree(e->persson_den);
+  tensor_ops_destroy(e);
   for (int i = 0; i < 3; i++)
   {
     free_operator(e->opp_1[i]); free_operator(e->opp_2[i]); free_operator(e->opp_4[i]); free_operator(e->opp_5[i]);
@@ -917,7 +919,8 @@ int hfx_eles_set_over_int(hfx_eles *e, int n_cubpts, const double *opp_over_int_
   if (dev_alloc_copy(&e->t_cub, nullptr, pc * e->n_fields * e->n_dims)) return 1;
   e->over_int_ready = true;
   fused_invalidate(e);
-  return 0;
+  // tensor-product elements: 1-D factors of the two matrices for the sum-factorised kernel (tensor_ops.hip)
+  return tensor_over_int_setup(e, n_cubpts, opp_over_int_cubpts, over_int_filter);
 }
 
 int hfx_eles_evaluate_invFlux_over_int(hfx_eles *e)
@@ -927,6 +930,7 @@ int hfx_eles_evaluate_invFlux_over_int(hfx_eles *e)
   HFX_CHECK(e->over_int_ready, "evaluate_invFlux_over_int: hfx_eles_set_over_int was not called");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   hfx_ctx *ctx = e->ctx;
+  if (tensor_over_int_available(e) && ctx->contract_mode != HFX_CONTRACT_DENSE) return tensor_over_int_launch(e);
   // interpolate the solution to the over-integration cubature points
   {
     const Operator *ops[1] = {&e->opp_over_int_cubpts};
@@ -975,7 +979,7 @@ int hfx_eles_set_shock_capture(hfx_eles *e, const double *inv_vandermonde, const
   e->s0 = s0;
   e->shock_det_field = shock_det_field;
   e->shock_ready = true;
-  return 0;
+  return tensor_shock_setup(e, inv_vandermonde, exp_filter, norm_basis_persson, high_modes);
 }
 
 int hfx_eles_shock_capture(hfx_eles *e)
@@ -984,6 +988,7 @@ int hfx_eles_shock_capture(hfx_eles *e)
   if (e->n_eles == 0) return 0; /* src/eles.cpp:2920 */
   HFX_CHECK(e->shock_ready, "shock_capture: hfx_eles_set_shock_capture was not called");
   hfx_ctx *ctx = e->ctx;
+  if (tensor_shock_available(e) && ctx->contract_mode != HFX_CONTRACT_DENSE) return tensor_shock_launch(e);
   const long plane = (long)e->n_upts * e->n_eles;
   double *scratch = e->arr[HFX_TDISF_UPTS]; // free between AdvanceSolution and the next stage's evaluate_invFlux
   double *u = e->arr[HFX_DISU_UPTS0];

@@ -121,6 +121,7 @@ struct hfx_eles
   unsigned long long *nan_flag = nullptr; // device: smallest flat index of a NaN in div_tconf, or ~0
   double *red_buf = nullptr;              // device partial sums for reductions
   int red_blocks = 0;
+  void *tensor_ops = nullptr; // hfx::TensorOps: 1-D factors of the over-integration / shock-capturing matrices
   // fused-path private data (built lazily)
   hfx::FusedData *fused = nullptr;
   std::vector<hfx_inters *> faces_attached;

@@ -109,11 +109,14 @@ def test_every_intermediate(ctx, mode):
     e.close()
 
 
+@pytest.mark.parametrize("mode", [hfx.CONTRACT_AUTO, hfx.CONTRACT_DENSE])
 @pytest.mark.parametrize("name", [n for n in ALL if "overint" in n])
-def test_over_integration_flux(ctx, name):
-    """eles::evaluate_invFlux_over_int through two dense FP64 MFMA contractions (n_cub = 343 / 100 columns)."""
+def test_over_integration_flux(ctx, name, mode):
+    """eles::evaluate_invFlux_over_int: sum-factorised (one kernel: interpolation, flux at the cubature points,
+    projection, all in LDS; 1-D factors recovered from the registered matrices) and as two dense FP64 MFMA
+    contractions (n_cub = 343 / 100 columns) around the pointwise flux kernel."""
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
-    e, faces = build(ctx, d)
+    e, faces = build(ctx, d, mode)
     e.evaluate_invFlux_over_int()
     assert relerr(e.download(hfx.TDISF_UPTS), d["s0_tdisf_upts_inv"]) < RTOL1
     for f in faces:
@@ -229,7 +232,8 @@ def test_stage_states_vs_reference(ctx, name):
     e.close()
 
 
-@pytest.mark.parametrize("name", ["hex_p4_n3_deformed", "hex_p3_n3_deformed", "hex_p1_roem"])
+@pytest.mark.parametrize("name", ["hex_p4_n3_deformed", "hex_p3_n3_deformed", "hex_p1_roem", "hex_p4_jet", "hex_p3_shock",
+                                  "quad_p3_shock", "quad_p3_overint"])
 def test_dense_mfma_path_vs_reference(ctx, name):
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     e, faces = build(ctx, d, hfx.CONTRACT_DENSE)
