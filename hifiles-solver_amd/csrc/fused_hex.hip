@@ -3094,6 +3094,12 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     else if (p.viscous && mpi_all(4))
       return 1;
     if (split_stage(e, int_faces, n_int, in_step, last, 4, variant)) return 1; // residual, RK, new disu_fpts (swaps)
+    if (e->shock_ready)
+    {
+      // src/HiFiLES.cpp:214-216: the filter changes disu_upts(0) after the stage -- redo the flux-point solution
+      if (hfx_eles_shock_capture(e)) return 1;
+      if (hfx_eles_extrapolate_solution(e)) return 1;
+    }
     return mpi_all(0);
   default:
     HFX_CHECK(false, "hfx_stage_partitioned: phase %d out of range", phase);

@@ -36,6 +36,41 @@ def test_gpu_partition_invariance(tmp_path, mode, n_local, pgrid, kw):
     assert rel(div, div1) < 5e-10
 
 
+@pytest.mark.parametrize("mode", ["methods", "fused"])
+def test_gpu_partition_dealiasing_and_shock_capturing(tmp_path, mode):
+    """BASELINE.json configs[4]'s ingredients on a partitioned box (2 ranks): over-integration and shock capturing
+    through the mirrored loop and through hfx_stage_partitioned must reproduce the 1-rank run of the same library
+    (which the hex_p4_jet / overint / shock fixtures pin against the genuine reference)."""
+    import ctypes as C
+    import hfx
+    import hfx_host as H
+    n_local, pgrid = [2, 4, 4], [2, 1, 1]
+    cfg = dict(CFG, order=3, riemann_solve_type=3, over_int=1, over_int_order=5, shock_cap=1, s0=1e30, expf_fac=36.0, expf_order=4,
+               expf_cutoff=1, shock_det_field=0)
+    # sensor threshold inside the widest gap of the initial sensor values: rounding cannot flip an element
+    c = H.Case([4, 4, 4], **cfg)
+    c.to_device(0)
+    e = c.handles()[1]
+    hfx.check(hfx.lib().hfx_eles_shock_capture(e))
+    sens = np.zeros(c.n_eles)
+    hfx.check(hfx.lib().hfx_eles_download(e, C.c_int(hfx.SENSOR), sens.ctypes.data_as(hfx.dp)))
+    sens = np.sort(sens)
+    c.close()
+    ratio = sens[1:] / sens[:-1]
+    k = int(np.argmax(ratio))  # some elements are filtered, the others are not
+    assert ratio[k] > 1.001  # rounding differences between the runs are ~1e-13
+    cfg["s0"] = float(np.sqrt(sens[k] * sens[k + 1]))
+    one = H.Case([4, 4, 4], **cfg)
+    one.to_device(0)
+    one.run(2)
+    one.sync_host()
+    u1 = one.array("disu_upts0").copy()
+    one.close()
+    PU.spawn(PU.gpu_worker, 2, (n_local, pgrid, cfg, 2, str(tmp_path), mode))
+    u = PU.assemble(str(tmp_path), "u", n_local, pgrid, u1.shape)
+    assert rel(u, u1) < 1e-11
+
+
 def test_gpu_partition_quads(tmp_path):
     cfg = dict(CFG, dims=2, riemann_solve_type=0)
     n_local, pgrid = [4, 2], [1, 2]
