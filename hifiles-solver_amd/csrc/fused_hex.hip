@@ -2146,7 +2146,7 @@ __device__ __forceinline__ void pencil_div(cdptr coef, const double *st_p, doubl
   }
 }
 
-template <int ND, int N, int WV, bool BUF>
+template <int ND, int N, int WV, bool BUF, bool OI>
 __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kernel(const Split2Args a,
                                                                                                const double *coef_g,
                                                                                                const int *tidx)
@@ -2297,6 +2297,13 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 #if HFX_FLUX_FMETRICS == 2
     fetch_fmetrics();
 #endif
+    // over-integration: the de-aliased inviscid flux of this point is requested here, a phase ahead of its use
+    double td[OI ? NG : 1];
+    if (OI && is_u)
+    {
+#pragma unroll
+      for (int q = 0; q < NG; q++) td[q] = g_td.ld(eu + q * plane_u, lu);
+    }
 
     // ---- A: transformed gradient, pencil-wise; flux-point solution, point-wise
     if (viscous)
@@ -2370,11 +2377,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     if (is_u)
     {
       // the transformed flux is accumulated in this thread's own st column (LDS) instead of 15 registers
-      if (a.tdisf_in)
+      if (OI)
       {
         // over-integration: the de-aliased inviscid flux was evaluated at the cubature points and projected back
 #pragma unroll
-        for (int q = 0; q < NG; q++) st[q * NU + tu] = g_td.ld(eu + q * plane_u, lu);
+        for (int q = 0; q < NG; q++) st[q * NU + tu] = td[q];
       }
       else
       {
@@ -2808,12 +2815,21 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       // buffer-descriptor addressing needs 32-bit byte offsets into the largest array the kernel touches
       static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
       const bool buf = !nobuf && (double)plane_f * e->n_fields * e->n_dims * 8.0 < 4294967296.0;
-      if (F->tensor_ok && !dict_only && waves == 2 && buf)
-        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+      const bool oi = e2.tdisf_in != nullptr;
+#define HFX_FLUX_LAUNCH(WV_, BUF_, OI_)                                                                                        \
+  hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, \
+                     F->t_idx)
+      if (F->tensor_ok && !dict_only && oi && buf)
+        HFX_FLUX_LAUNCH(2, true, true);
+      else if (F->tensor_ok && !dict_only && oi)
+        HFX_FLUX_LAUNCH(2, false, true);
+      else if (F->tensor_ok && !dict_only && waves == 2 && buf)
+        HFX_FLUX_LAUNCH(2, true, false);
       else if (F->tensor_ok && !dict_only && buf)
-        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 3, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+        HFX_FLUX_LAUNCH(3, true, false);
       else if (F->tensor_ok && !dict_only)
-        hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, false>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, F->t_idx);
+        HFX_FLUX_LAUNCH(2, false, false);
+#undef HFX_FLUX_LAUNCH
       else
         hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
     }

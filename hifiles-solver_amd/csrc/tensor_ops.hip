@@ -230,6 +230,10 @@ bool tensor_shock_available(const hfx_eles *e) { return e->tensor_ops && ((Tenso
 // bandwidth (the same arrangement as the flux kernel's sum-factorised contractions).
 typedef const double __attribute__((address_space(4))) *tcptr;
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding GLOBAL load and
+// store of the wave (vmcnt(0)), i.e. drain the prefetches and expose the latency of each result store
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int MO, int MI>
 __device__ __forceinline__ void tpass(const double *in, double *out, tcptr M, int P, int n_pencils)
 {
@@ -266,7 +270,7 @@ __device__ __forceinline__ double *tapply(double *a, double *b, tcptr M, int nf)
 #pragma unroll
     for (int q = d + 1; q < ND; q++) rest *= NIN;
     tpass<NOUT, NIN>(src, dst, M, P, P * rest);
-    __syncthreads();
+    lds_sync();
     P *= NOUT;
     double *t = src;
     src = dst;
@@ -294,6 +298,22 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
   double *R0 = lds, *R1 = R0 + NF * nc, *R2 = R1 + NF * nc;
   const tcptr cI = (tcptr)(uintptr_t)a.I1, cF = (tcptr)(uintptr_t)a.F1;
   const long plane_u = (long)nu * a.n_eles;
+  // software pipeline: the next element's state is requested while this one is worked on
+  constexpr int UPT = (NF * nu + 255) / 256;
+  double pu[UPT];
+  auto fetch_u = [&](long e) {
+#pragma unroll
+    for (int i = 0; i < UPT; i++)
+    {
+      const int q = threadIdx.x + 256 * i;
+      if (q < NF * nu)
+      {
+        const int k = q / nu, pt = q - k * nu;
+        pu[i] = a.u[pt + (long)nu * e + k * plane_u];
+      }
+    }
+  };
+  if ((long)blockIdx.x < a.n_eles) fetch_u(blockIdx.x);
   for (long e = blockIdx.x; e < a.n_eles; e += gridDim.x)
   {
     // the metric tensors of this thread's cubature points: requested first, consumed after the interpolation passes
@@ -309,12 +329,11 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
         for (int m = 0; m < NQ; m++) jg[r][m] = src[m];
       }
     }
-    for (int q = threadIdx.x; q < NF * nu; q += blockDim.x)
-    {
-      const int k = q / nu, pt = q - k * nu;
-      R0[q] = a.u[pt + (long)nu * e + k * plane_u];
-    }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < UPT; i++)
+      if (threadIdx.x + 256 * i < NF * nu) R0[threadIdx.x + 256 * i] = pu[i];
+    lds_sync();
+    if (e + gridDim.x < a.n_eles) fetch_u(e + gridDim.x);
     // solution at the cubature points (opp_over_int_cubpts . u)
     double *ucub = tapply<ND, NC, N>(R0, R1, cI, NF);
     double *fa = (ucub == R0) ? R1 : R0; // two free regions
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
           }
         }
       }
-      __syncthreads();
+      lds_sync();
       // projection back on the solution points (over_int_filter . t)
       double *res = tapply<ND, N, NC>(fa, fb, cF, NF);
       for (int q = threadIdx.x; q < NF * nu; q += blockDim.x)
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
         const int k = q / nu, pt = q - k * nu;
         a.tdisf[pt + (long)nu * e + (k + NF * l) * plane_u] = res[q];
       }
-      __syncthreads();
+      lds_sync();
     }
   }
 }
@@ -439,9 +458,9 @@ __global__ __launch_bounds__(256) void shock_tensor_kernel(const ShockArgs a)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long e = blockIdx.x; e < a.n_eles; e += gridDim.x)
   {
-    __syncthreads();
+    lds_sync();
     for (int q = threadIdx.x; q < nu; q += blockDim.x) R0[q] = a.u[q + (long)nu * e + a.field * plane_u];
-    __syncthreads();
+    lds_sync();
     // modal coefficients of the sensor field (tensor mode order)
     const double *modal = tapply<ND, N, N>(R0, R1, sW, 1);
     double sn = 0.0, sd = 0.0;
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(256) void shock_tensor_kernel(const ShockArgs a)
       red[2 * wave] = sn;
       red[2 * wave + 1] = sd;
     }
-    __syncthreads();
+    lds_sync();
     double num = 0.0, den = 0.0;
 #pragma unroll
     for (int w = 0; w < 4; w++)
@@ -474,13 +493,13 @@ __global__ __launch_bounds__(256) void shock_tensor_kernel(const ShockArgs a)
     if (threadIdx.x == 0) a.sensor[e] = s;
     if (s >= a.s0) // uniform over the workgroup (src/eles.cpp:2936)
     {
-      __syncthreads();
+      lds_sync();
       for (int q = threadIdx.x; q < NF * nu; q += blockDim.x)
       {
         const int k = q / nu, pt = q - k * nu;
         R0[q] = a.u[pt + (long)nu * e + k * plane_u];
       }
-      __syncthreads();
+      lds_sync();
       const double *res = tapply<ND, N, N>(R0, R1, sE, NF);
       for (int q = threadIdx.x; q < NF * nu; q += blockDim.x)
       {
