@@ -2146,8 +2146,45 @@ __device__ __forceinline__ void pencil_div(cdptr coef, const double *st_p, doubl
   }
 }
 
-template <int ND, int N, int WV, bool BUF, bool OI>
-__global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kernel(const Split2Args a,
+// LDS-DMA of one contiguous run: `lanes` lanes of 16 bytes, lane l of wave-instruction j takes bytes
+// [16 (l + 64 j), +16) of the run to the same offset of the LDS region; the partial last instruction is masked (an
+// inactive lane writes nothing).
+typedef __attribute__((address_space(3))) double *lds_dp;
+template <bool BUF>
+__device__ __forceinline__ void dma16_region(const GArr<BUF> &g, lds_dp lds_dst, int lanes, int lane, unsigned soff)
+{
+  typedef __attribute__((address_space(3))) void *lds_vp;
+  __attribute__((address_space(3))) char *base = (__attribute__((address_space(3))) char *)lds_dst;
+#pragma unroll
+  for (int j = 0; j < 16; j++) // `lanes` is a compile-time constant at every call: the loop folds to ceil(lanes / 64) instructions
+    if (64 * j < lanes && lane + 64 * j < lanes)
+    {
+#if __HIP_DEVICE_COMPILE__ // the 16-byte form exists on gfx950 only: the host pass of this file must not see it
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(g.r, (lds_vp)(base + 1024 * j), 16, (unsigned)(lane + 64 * j) * 16u, soff, 0, 0);
+#endif
+    }
+}
+
+// does the loader-wave form fit this element size?  (vmcnt counts at most 63 DMA instructions in flight; two workgroups
+// of input slots + metric slot + work regions must fit the CU's 160 KiB of LDS)
+template <int ND, int N>
+constexpr bool loader_wave_fits()
+{
+  using G = Geo<ND, N>;
+  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, NQ = ND * ND, NG = NF * ND;
+  constexpr int UJ = (2 * NF * NU + 63) / 64, DJ = (2 * NF * NFP + 63) / 64;
+  constexpr int L_JGU = (NQ * NU + 1) / 2, L_DJU = (NU + 1) / 2, L_JGF = (NQ * NFP + 1) / 2, L_DJF = (NFP + 1) / 2;
+  constexpr int N_M = (L_JGU + 63) / 64 + (L_DJU + 63) / 64 + (L_JGF + 63) / 64 + (1 + ND) * ((L_DJF + 63) / 64);
+  constexpr long lds = 8L * (cmax(NF * (NU + NFP), NG * NU) + NG * NU + 2 * 32 * (UJ + DJ) + NQ * (NU + NFP) + NU + (1 + ND) * NFP + 16);
+  return UJ + DJ <= 63 && N_M <= 63 && 2 * lds <= 160 * 1024;
+}
+
+// LW: a LOADER WAVE (one extra wave per workgroup) brings the next element's state and LDG corrections straight into
+// an LDS slot by buffer_load ... lds -- no registers, requested a whole element ahead and counted on the loader's own
+// vmcnt, so the compute waves never wait for them (the register prefetch of the LW = false form is issued in phase C
+// and still needs ~2 500 cycles at the top of the next iteration: the kernel is bound by bytes in flight per CU).
+template <int ND, int N, int WV, bool BUF, bool OI, bool LW>
+__global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_flux_tensor_kernel(const Split2Args a,
                                                                                                const double *coef_g,
                                                                                                const int *tidx)
 {
@@ -2155,9 +2192,22 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
   using T = TGeo<ND, N>;
   constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TB = T::TB, NG = NF * ND, L = T::L, ROUNDS = T::ROUNDS;
   constexpr int R1 = cmax(NF * (NU + NFP), NG * NU);
+  // LW: two input slots; a slot holds u (NF*NU doubles) and delta (NF*NFP doubles), each padded to whole
+  // wave-instructions of 64 dwords (an LDS-DMA writes lane-linear: base + 4 * lane)
+  constexpr int U_DW = ((2 * NF * NU + 63) / 64) * 64, D_DW = ((2 * NF * NFP + 63) / 64) * 64, SLOT = (U_DW + D_DW) / 2;
+  static_assert(!LW || BUF, "the loader wave addresses through buffer descriptors");
   __shared__ double sA[R1];      // su | sd, later st
   __shared__ double sB[NG * NU]; // sg, later the per-direction parts of the divergence
-  double *const su = sA, *const sd = sA + NF * NU, *const st = sA, *const sg = sB, *const sp = sB;
+  __shared__ double s_in[LW ? 2 * SLOT : 1];
+  // LW: ONE metric slot (volume metrics, flux-point metrics, own normals of the element); it is free from the end of
+  // phase B (barrier 3) on, which is when the loader refills it for the next element.  Regions start on 16-byte
+  // boundaries (the loader moves 16 bytes per lane).
+  constexpr int NQ = ND * ND;
+  constexpr int O_JGU = 0, O_DJU = O_JGU + ((NQ * NU + 1) & ~1), O_JGF = O_DJU + ((NU + 1) & ~1), O_DJF = O_JGF + ((NQ * NFP + 1) & ~1),
+                NFPP = (NFP + 1) & ~1, O_NRM = O_DJF + NFPP, MET = O_NRM + ND * NFPP;
+  __shared__ double s_met[LW ? MET : 1];
+  double *su = sA, *sd = sA + NF * NU;
+  double *const st = sA, *const sg = sB, *const sp = sB;
   const cdptr coef = (cdptr)(uintptr_t)coef_g;
   const int t = threadIdx.x;
   const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
@@ -2245,7 +2295,18 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
   double JF[ND * ND], nrm[ND], djf_raw = 1.0;
   long ef_cur = 0;
   auto fetch_fmetrics = [&]() {
-    if (viscous && is_f)
+    if constexpr (LW)
+    {
+      if (viscous && is_f)
+      {
+#pragma unroll
+        for (int q = 0; q < ND * ND; q++) JF[q] = ldsv(&s_met[O_JGF + tf * (ND * ND) + q]);
+        djf_raw = ldsv(&s_met[O_DJF + tf]);
+#pragma unroll
+        for (int m = 0; m < ND; m++) nrm[m] = ldsv(&s_met[O_NRM + m * NFPP + tf]);
+      }
+    }
+    else if (viscous && is_f)
     {
 #pragma unroll
       for (int q = 0; q < ND * ND; q++) JF[q] = g_JGf.ld(ef_cur * (ND * ND), lf * (ND * ND) + q);
@@ -2255,10 +2316,100 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     }
   };
   const EleOrder order(ne, a.xcd_order != 0);
+  if constexpr (LW)
+  {
+    if (t >= TB)
+    {
+      // ---- the loader wave: 4 barriers per element like the compute waves; the DMA of element k+1 is issued after
+      // barrier 1 of element k (slot (k+1)&1 was last read in phase A of element k-1) and waited for on this wave's
+      // own counter before barrier 1 of element k+1
+      const int lane = t - TB;
+      constexpr int UJ = U_DW / 64, DJ = D_DW / 64;
+      unsigned vu[UJ], vd[DJ]; // byte offsets of this lane's dword in every wave-instruction: field plane + run
+#pragma unroll
+      for (int j = 0; j < UJ; j++)
+      {
+        int w = lane + 64 * j;
+        if (w >= 2 * NF * NU) w = 2 * NF * NU - 1; // the padding lanes repeat the last dword
+        const int f = w / (2 * NU), r = w - f * (2 * NU);
+        vu[j] = (unsigned)f * (unsigned)plane_u * 8u + (unsigned)r * 4u;
+      }
+#pragma unroll
+      for (int j = 0; j < DJ; j++)
+      {
+        int w = lane + 64 * j;
+        if (w >= 2 * NF * NFP) w = 2 * NF * NFP - 1;
+        const int f = w / (2 * NFP), r = w - f * (2 * NFP);
+        vd[j] = (unsigned)f * (unsigned)plane_f * 8u + (unsigned)r * 4u;
+      }
+      typedef __attribute__((address_space(3))) void *lds_vp;
+      auto issue = [&](long e, int which) {
+        char *base = (char *)(s_in + which * SLOT);
+#pragma unroll
+        for (int j = 0; j < UJ; j++)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(g_u0.r, (lds_vp)(base + 256 * j), 4, vu[j], (unsigned)((long)NU * e) * 8u, 0, 0);
+        if (viscous)
+        {
+#pragma unroll
+          for (int j = 0; j < DJ; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(g_delta.r, (lds_vp)(base + 4 * U_DW + 256 * j), 4, vd[j],
+                                                     (unsigned)((long)NFP * e) * 8u, 0, 0);
+        }
+      };
+      // metrics: 16 bytes per lane, partial last wave-instruction masked (an inactive lane writes nothing)
+      constexpr int L_JGU = (NQ * NU + 1) / 2, L_DJU = (NU + 1) / 2, L_JGF = (NQ * NFP + 1) / 2, L_DJF = (NFP + 1) / 2; // lanes
+      constexpr int MJ_MAX = (cmax(L_JGU, L_JGF) + 63) / 64;
+      constexpr int N_MU = (L_JGU + 63) / 64 + (L_DJU + 63) / 64;                          // volume metrics
+      constexpr int N_MF = (L_JGF + 63) / 64 + (L_DJF + 63) / 64 + ND * ((L_DJF + 63) / 64); // flux-point metrics, normals
+      constexpr int N_UDV = UJ + DJ, N_UDI = UJ, N_MV = N_MU + N_MF, N_MI = N_MU;
+      static_assert(N_UDV <= 63 && N_MV <= 63, "loader wave: more DMA instructions in flight than vmcnt can count");
+      auto issue_met = [&](long e) {
+        dma16_region(g_JGu, (lds_dp)s_met + O_JGU, L_JGU, lane, (unsigned)((long)NU * NQ * e) * 8u);
+        dma16_region(g_dju, (lds_dp)s_met + O_DJU, L_DJU, lane, (unsigned)((long)NU * e) * 8u);
+        if (viscous)
+        {
+          dma16_region(g_JGf, (lds_dp)s_met + O_JGF, L_JGF, lane, (unsigned)((long)NFP * NQ * e) * 8u);
+          dma16_region(g_djf, (lds_dp)s_met + O_DJF, L_DJF, lane, (unsigned)((long)NFP * e) * 8u);
+#pragma unroll
+          for (int m = 0; m < ND; m++)
+            dma16_region(g_nrm, (lds_dp)s_met + (O_NRM + m * NFPP), L_DJF, lane, (unsigned)((long)NFP * e + m * plane_f) * 8u);
+        }
+      };
+#define HFX_VMCNT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+      if (order.at(0) >= 0)
+      {
+        issue(order.at(0), 0);
+        issue_met(order.at(0));
+      }
+      for (long kk = 0, e = order.at(0), e_next; e >= 0; kk++, e = e_next)
+      {
+        e_next = order.at(kk + 1);
+        // outstanding, oldest first: state/delta of this element, metrics of this element
+        if (viscous) HFX_VMCNT(N_MV); else HFX_VMCNT(N_MI);
+        lds_barrier(); // 1: the compute waves may read the input slot
+        if (e_next >= 0)
+        {
+          issue(e_next, (int)((kk + 1) & 1));
+          if (viscous) HFX_VMCNT(N_UDV); else HFX_VMCNT(N_UDI); // the metrics of this element have landed
+        }
+        else
+          HFX_VMCNT(0);
+        lds_barrier(); // 2: the compute waves may read the metric slot
+        lds_barrier(); // 3: ... and have finished with it
+        if (e_next >= 0) issue_met(e_next);
+        lds_barrier(); // 4
+      }
+#undef HFX_VMCNT
+      return;
+    }
+  }
   if (order.at(0) >= 0)
   {
-    fetch_state(order.at(0));
-    fetch_metrics(order.at(0));
+    if (!LW)
+    {
+      fetch_state(order.at(0));
+      fetch_metrics(order.at(0));
+    }
   }
 
   int it_no = 0;
@@ -2270,7 +2421,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     e_next = order.at(kk + 1);
     const long eu = (long)NU * e, ef = (long)NFP * e;
     stamp(0);
-    const double inv_detjac = viscous ? 1.0 / detjac_raw : 0.0;
+    double inv_detjac = (viscous && !LW) ? 1.0 / detjac_raw : 0.0;
     // the pencil addresses of the flux-point role are loop invariant; left alone the compiler hoists
     // one address register per (plane, m) out of the element loop.  Rebuild the N of them here from an
     // opaque copy and let the plane offsets be immediates.
@@ -2281,14 +2432,22 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
 #pragma unroll
       for (int m = 0; m < N; m++) am[m] = bfo + m * sf;
     }
-#pragma unroll
-    for (int i = 0; i < UNP; i++)
-      if (t + TB * i < NF * NU) su[t + TB * i] = pf_u[i];
-    if (viscous)
+    if constexpr (LW)
+    {
+      su = s_in + (kk & 1) * SLOT;
+      sd = su + U_DW / 2;
+    }
+    else
     {
 #pragma unroll
-      for (int i = 0; i < DNP; i++)
-        if (t + TB * i < NF * NFP) sd[t + TB * i] = pf_d[i];
+      for (int i = 0; i < UNP; i++)
+        if (t + TB * i < NF * NU) su[t + TB * i] = pf_u[i];
+      if (viscous)
+      {
+#pragma unroll
+        for (int i = 0; i < DNP; i++)
+          if (t + TB * i < NF * NFP) sd[t + TB * i] = pf_d[i];
+      }
     }
     stamp(1);
     lds_barrier();
@@ -2376,6 +2535,13 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
     if (is_u)
     {
+      if constexpr (LW)
+      {
+        // volume metrics of this point from the slot the loader wave filled
+#pragma unroll
+        for (int q = 0; q < NQ; q++) JG[q] = ldsv(&s_met[O_JGU + tu * NQ + q]);
+        if (viscous) inv_detjac = 1.0 / ldsv(&s_met[O_DJU + tu]);
+      }
       // the transformed flux is accumulated in this thread's own st column (LDS) instead of 15 registers
       if (OI)
       {
@@ -2478,8 +2644,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), WV) void split_flux_tensor_kerne
     // ---- C: next element's inputs on their way; divergence parts pencil-wise, normal flux at the flux points
     if (e_next >= 0)
     {
-      fetch_state(e_next);
-      fetch_metrics(e_next);
+      if (!LW)
+      {
+        fetch_state(e_next);
+        fetch_metrics(e_next);
+      }
     }
     {
       double xa[ROUNDS][N];
@@ -2736,6 +2905,21 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
   }
 }
 
+// launch of the loader-wave form, instantiated only for element sizes it fits (loader_wave_fits)
+template <int ND, int N, bool OI, bool FITS>
+struct LoaderWaveLaunch
+{
+  static void go(int, hipStream_t, const Split2Args &, const double *, const int *) {}
+};
+template <int ND, int N, bool OI>
+struct LoaderWaveLaunch<ND, N, OI, true>
+{
+  static void go(int grid, hipStream_t st, const Split2Args &e2, const double *coef, const int *idx)
+  {
+    hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true>), dim3(grid), dim3(SGeo<ND, N>::TB + 64), 0, st, e2, coef, idx);
+  }
+};
+
 template <int ND, int N>
 static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, SplitEleArgs &ea, int which, int variant)
 {
@@ -2816,19 +3000,33 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
       const bool buf = !nobuf && (double)plane_f * e->n_fields * e->n_dims * 8.0 < 4294967296.0;
       const bool oi = e2.tdisf_in != nullptr;
-#define HFX_FLUX_LAUNCH(WV_, BUF_, OI_)                                                                                        \
-  hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2, F->t_coef, \
-                     F->t_idx)
-      if (F->tensor_ok && !dict_only && oi && buf)
-        HFX_FLUX_LAUNCH(2, true, true);
+#define HFX_FLUX_LAUNCH(WV_, BUF_, OI_, LW_)                                                                                  \
+  hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_, LW_>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2,   \
+                     F->t_coef, F->t_idx)
+      static const bool no_lw = getenv("HFX_NO_LOADER_WAVE") != nullptr; // A/B switch
+      constexpr bool lw_fits = loader_wave_fits<ND, N>();
+      const bool lw = lw_fits && buf && !no_lw && waves == 2;
+      bool launched = false;
+      if (F->tensor_ok && !dict_only && lw)
+      {
+        if (oi)
+          LoaderWaveLaunch<ND, N, true, lw_fits>::go(grid, st, e2, F->t_coef, F->t_idx);
+        else
+          LoaderWaveLaunch<ND, N, false, lw_fits>::go(grid, st, e2, F->t_coef, F->t_idx);
+        launched = true;
+      }
+      if (launched)
+        ;
+      else if (F->tensor_ok && !dict_only && oi && buf)
+        HFX_FLUX_LAUNCH(2, true, true, false);
       else if (F->tensor_ok && !dict_only && oi)
-        HFX_FLUX_LAUNCH(2, false, true);
+        HFX_FLUX_LAUNCH(2, false, true, false);
       else if (F->tensor_ok && !dict_only && waves == 2 && buf)
-        HFX_FLUX_LAUNCH(2, true, false);
+        HFX_FLUX_LAUNCH(2, true, false, false);
       else if (F->tensor_ok && !dict_only && buf)
-        HFX_FLUX_LAUNCH(3, true, false);
+        HFX_FLUX_LAUNCH(3, true, false, false);
       else if (F->tensor_ok && !dict_only)
-        HFX_FLUX_LAUNCH(2, false, false);
+        HFX_FLUX_LAUNCH(2, false, false, false);
 #undef HFX_FLUX_LAUNCH
       else
         hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
