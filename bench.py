@@ -95,6 +95,38 @@ def cpu_baseline(order, threads):
     return out
 
 
+def reference_baseline(order, n_cells=8, n_steps=8):
+    """The GENUINE reference (oracle/_ref/ref_harness, g++ -O3 of /root/reference/src as it stands, serial, BLAS=NO;
+    built by `make -C oracle ref` in the build container and shipped prebuilt) on the same TGV case, reduced mesh:
+    wall clock of its own RK loop (setup excluded), printed by the harness.  None where the binary is absent."""
+    import re
+    import subprocess
+    import tempfile
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    harness = os.path.join(ref_dir, "ref_harness")
+    if not (os.path.isfile(harness) and os.path.isfile(os.path.join(ref_dir, "data", "JacobiGQ.bin"))):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from capture_golden import BASE
+    from gen_neu_mesh import write_neu
+    keys = dict(BASE, order=order, n_steps=n_steps)
+    with tempfile.TemporaryDirectory() as td:
+        write_neu(os.path.join(td, "mesh.neu"), n_cells, 3, amp=0.0)
+        with open(os.path.join(td, "input"), "w") as f:
+            for k, v in keys.items():
+                f.write("%s %s\n" % (k, repr(v) if isinstance(v, float) else v))
+        r = subprocess.run([harness, "input", "dump.bin", str(n_steps), "0"], cwd=td, env=dict(os.environ, HIFILES_HOME=ref_dir),
+                           capture_output=True, text=True)
+    m = re.search(r"RK loop (\d+) steps (\d+) stages ([0-9.eE+-]+) s", r.stderr)
+    if r.returncode != 0 or not m:
+        sys.stderr.write("reference baseline failed: %s\n" % r.stderr[-500:])
+        return None
+    secs = float(m.group(3))
+    n_upts = (order + 1) ** 3
+    dofs = n_cells ** 3 * n_upts * 5 * int(m.group(2)) * int(m.group(1))
+    return dict(value=dofs / secs, seconds=secs, n_cells=n_cells, steps=int(m.group(1)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,12 +316,21 @@ def main():
             # the GPU box gives one job a 16-CPU share whatever os.cpu_count() says
             threads = max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
             cb = cpu_baseline(args.order, threads)
-            cpu = dict(value=cb["allcores"]["value"], unit="DOF-updates/s", cores=threads, kind="port",
-                       sample="oracle (C restatement of the reference CPU path, OpenMP over elements) on a %d^3 "
-                              "P%d TGV mesh, %d time steps; 1 core on %d^3: %.3g DOF-updates/s" %
-                              (cb["allcores"]["n_cells"], args.order, cb["allcores"]["steps"], cb["1core"]["n_cells"],
-                               cb["1core"]["value"]),
-                       value_1core=cb["1core"]["value"])
+            port_note = ("oracle (C restatement of the reference CPU path, OpenMP over elements) on a %d^3 P%d TGV mesh, "
+                         "%d time steps: %.3g DOF-updates/s on %d cores; on 1 core (%d^3): %.3g" %
+                         (cb["allcores"]["n_cells"], args.order, cb["allcores"]["steps"], cb["allcores"]["value"], threads,
+                          cb["1core"]["n_cells"], cb["1core"]["value"]))
+            rb = reference_baseline(args.order)
+            if rb is not None:
+                # the reference is a serial code (no OpenMP / threads anywhere in its src/): one core is all it uses
+                cpu = dict(value=rb["value"], unit="DOF-updates/s", cores=1, kind="reference",
+                           sample="genuine reference (oracle/_ref/ref_harness: g++ -O3 of the reference's own sources, serial, "
+                                  "BLAS=NO), its RK loop on a %d^3 P%d TGV mesh, %d time steps in %.1f s; beside it the %s" %
+                                  (rb["n_cells"], args.order, rb["steps"], rb["seconds"], port_note),
+                           port_value_allcores=cb["allcores"]["value"], port_cores=threads, port_value_1core=cb["1core"]["value"])
+            else:
+                cpu = dict(value=cb["allcores"]["value"], unit="DOF-updates/s", cores=threads, kind="port", sample=port_note,
+                           value_1core=cb["1core"]["value"])
 
     if rank == 0:
         line = {
