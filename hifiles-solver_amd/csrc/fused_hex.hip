@@ -32,6 +32,7 @@
 // loop instead of ~100.  The arithmetic is unchanged: the same non-zeros, multiplied in
 // the same ascending-column order as the reference dgemm (src/funcs.cpp:110-117).
 #include "fused_hex.hpp"
+#include "tensor_ops.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -3134,6 +3135,15 @@ static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_st
   return 0;
 }
 
+// shock capturing inside a split-path stage: disu_fpts must follow the filtered state.  The sum-factorised kernel
+// rewrites the flux points of the elements it filters; the dense form is followed by a full extrapolate_solution.
+static int shock_capture_keep_fpts(hfx_eles *e)
+{
+  if (tensor_shock_available(e) && e->ctx->contract_mode != HFX_CONTRACT_DENSE) return tensor_shock_launch(e, true);
+  if (hfx_eles_shock_capture(e)) return 1;
+  return hfx_eles_extrapolate_solution(e);
+}
+
 int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int variant)
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
@@ -3152,8 +3162,7 @@ int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps,
       if (e->shock_ready)
       {
         // the filter changes disu_upts(0) after the stage: redo the flux-point solution of the new state
-        if (hfx_eles_shock_capture(e)) return 1;
-        if (hfx_eles_extrapolate_solution(e)) return 1;
+        if (shock_capture_keep_fpts(e)) return 1;
       }
     }
   return 0;
@@ -3316,8 +3325,7 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     if (e->shock_ready)
     {
       // src/HiFiLES.cpp:214-216: the filter changes disu_upts(0) after the stage -- redo the flux-point solution
-      if (hfx_eles_shock_capture(e)) return 1;
-      if (hfx_eles_extrapolate_solution(e)) return 1;
+      if (shock_capture_keep_fpts(e)) return 1;
     }
     return mpi_all(0);
   default:

@@ -445,6 +445,12 @@ struct ShockArgs
   const double *W1, *E1, *wnum, *wden;
   double *sensor;
   double s0;
+  // optional: the flux-point solution of the filtered elements (opp_0 in ELL form), for callers that keep disu_fpts
+  // of the current state (the split fused paths) -- saves them a full extrapolate_solution after the filter
+  double *disu_fpts;
+  const double *o0v;
+  const int *o0i;
+  int o0w, nfp;
 };
 
 // Persson sensor of every element and, where it fires, the exponentially filtered state -- one workgroup per element
@@ -506,6 +512,18 @@ __global__ __launch_bounds__(256) void shock_tensor_kernel(const ShockArgs a)
         const int k = q / nu, pt = q - k * nu;
         a.u[pt + (long)nu * e + k * plane_u] = res[q];
       }
+      if (a.disu_fpts)
+      {
+        // disu_fpts = opp_0 . u of the filtered state, rows in the ascending-column order of the contraction kernels
+        const long plane_f = (long)a.nfp * a.n_eles;
+        for (int q = threadIdx.x; q < NF * a.nfp; q += blockDim.x)
+        {
+          const int k = q / a.nfp, r = q - k * a.nfp;
+          double acc = 0.0;
+          for (int w = 0; w < a.o0w; w++) acc += a.o0v[r + (long)a.nfp * w] * res[k * nu + a.o0i[r + (long)a.nfp * w]];
+          a.disu_fpts[r + (long)a.nfp * e + k * plane_f] = acc;
+        }
+      }
     }
   }
 }
@@ -528,7 +546,7 @@ static int shock_pick_n(hfx_eles *e, const ShockArgs &a, int grid, int n)
   }
 }
 
-int tensor_shock_launch(hfx_eles *e)
+int tensor_shock_launch(hfx_eles *e, bool refresh_disu_fpts)
 {
   TensorOps *T = (TensorOps *)e->tensor_ops;
   HFX_CHECK(T && T->shock, "shock capturing: no tensor factors");
@@ -539,6 +557,11 @@ int tensor_shock_launch(hfx_eles *e)
   a.W1 = T->W1; a.E1 = T->E1; a.wnum = T->wnum; a.wden = T->wden;
   a.sensor = e->arr[HFX_SENSOR];
   a.s0 = e->s0;
+  if (refresh_disu_fpts)
+  {
+    a.disu_fpts = e->arr[HFX_DISU_FPTS];
+    a.o0v = e->opp_0.ell_val; a.o0i = e->opp_0.ell_idx; a.o0w = std::max(e->opp_0.nnz_max, 1); a.nfp = e->n_fpts;
+  }
   const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * 8);
   return e->n_dims == 2 ? shock_pick_n<2, 2>(e, a, grid, T->N) : shock_pick_n<3, 2>(e, a, grid, T->N);
 }

@@ -16,6 +16,7 @@ int tensor_shock_setup(hfx_eles *e, const double *inv_vandermonde, const double 
 bool tensor_over_int_available(const hfx_eles *e);
 bool tensor_shock_available(const hfx_eles *e);
 int tensor_over_int_launch(hfx_eles *e); // disu_upts(0) -> tdisf_upts (the de-aliased transformed inviscid flux)
-int tensor_shock_launch(hfx_eles *e);    // sensor, and the filtered state where sensor >= s0
+// sensor, and the filtered state where sensor >= s0; refresh_disu_fpts: also the flux-point solution of those elements
+int tensor_shock_launch(hfx_eles *e, bool refresh_disu_fpts = false);
 void tensor_ops_destroy(hfx_eles *e);
 } // namespace hfx
