@@ -2019,9 +2019,6 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flu
 #ifndef HFX_FLUX_FMETRICS
 #define HFX_FLUX_FMETRICS 0
 #endif
-#ifndef HFX_B_INTERLEAVE
-#define HFX_B_INTERLEAVE 0 // 1: let the scheduler interleave the solution-point and the flux-point block of phase B
-#endif
 
 // constant address space: loads with a wave-uniform address are selected as scalar loads
 typedef const double __attribute__((address_space(4))) *cdptr;
@@ -2597,9 +2594,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
           }
       }
     }
-#if !HFX_B_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0); // keep the two independent physics blocks apart: interleaving them doubles the live registers
-#endif
     if (viscous && is_f)
     {
       double grf[NG], fq[NG];
