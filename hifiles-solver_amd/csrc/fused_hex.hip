@@ -2173,10 +2173,10 @@ constexpr bool loader_wave_fits()
 {
   using G = Geo<ND, N>;
   constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, NQ = ND * ND, NG = NF * ND;
-  constexpr int UJ = (2 * NF * NU + 63) / 64, DJ = (2 * NF * NFP + 63) / 64;
+  constexpr int UJ = NF * (((NU + 1) / 2 + 63) / 64), DJ = NF * (((NFP + 1) / 2 + 63) / 64);
   constexpr int L_JGU = (NQ * NU + 1) / 2, L_DJU = (NU + 1) / 2, L_JGF = (NQ * NFP + 1) / 2, L_DJF = (NFP + 1) / 2;
   constexpr int N_M = (L_JGU + 63) / 64 + (L_DJU + 63) / 64 + (L_JGF + 63) / 64 + (1 + ND) * ((L_DJF + 63) / 64);
-  constexpr long lds = 8L * (cmax(NF * (NU + NFP), NG * NU) + NG * NU + 2 * 32 * (UJ + DJ) + NQ * (NU + NFP) + NU + (1 + ND) * NFP + 16);
+  constexpr long lds = 8L * (cmax(NF * (NU + NFP), NG * NU) + NG * NU + 2 * NF * (NU + 1 + NFP) + NQ * (NU + NFP) + NU + (1 + ND) * NFP + 16);
   return UJ + DJ <= 63 && N_M <= 63 && 2 * lds <= 160 * 1024;
 }
 
@@ -2193,9 +2193,10 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   using T = TGeo<ND, N>;
   constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TB = T::TB, NG = NF * ND, L = T::L, ROUNDS = T::ROUNDS;
   constexpr int R1 = cmax(NF * (NU + NFP), NG * NU);
-  // LW: two input slots; a slot holds u (NF*NU doubles) and delta (NF*NFP doubles), each padded to whole
-  // wave-instructions of 64 dwords (an LDS-DMA writes lane-linear: base + 4 * lane)
-  constexpr int U_DW = ((2 * NF * NU + 63) / 64) * 64, D_DW = ((2 * NF * NFP + 63) / 64) * 64, SLOT = (U_DW + D_DW) / 2;
+  // LW: two input slots; a slot holds u and delta, field after field (an LDS-DMA writes lane-linear: base + 16 * lane)
+  // (LW) field stride of the state in the slot: whole 16-byte lanes (P4: 125 -> 126 doubles); NFP is even already
+  constexpr int NUS = LW ? ((NU + 1) & ~1) : NU;
+  constexpr int U_DW = 2 * NF * NUS, D_DW = 2 * NF * NFP, SLOT = (U_DW + D_DW) / 2;
   static_assert(!LW || BUF, "the loader wave addresses through buffer descriptors");
   __shared__ double sA[R1];      // su | sd, later st
   __shared__ double sB[NG * NU]; // sg, later the per-direction parts of the divergence
@@ -2224,7 +2225,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   for (int m = 0; m < N; m++) Lrow[m] = coef_g[T::C_LF + dq * N + m];
   const double sgn1 = coef_g[T::C_L1 + dq * N]; // merged opp_1 row = sgn1 * Lrow (tnorm = +-1)
   // pencil role: ROUNDS work items (field, direction, pencil); a wave's items share the direction
-  int it_d[ROUNDS], it_o[ROUNDS], it_fa[ROUNDS], it_fb[ROUNDS];
+  int it_d[ROUNDS], it_o[ROUNDS], it_fa[ROUNDS], it_fb[ROUNDS], it_k[ROUNDS];
   int it_dq[ROUNDS]; // the round's direction, wave-uniform (inactive lanes included)
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++)
@@ -2243,6 +2244,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     it_d[r] = on ? d : -1;
     it_dq[r] = __builtin_amdgcn_readfirstlane(d);
     it_o[r] = (k + NF * d) * NU + base;
+    it_k[r] = k;
     it_fa[r] = k * NFP + tidx[T::I_PF + (d * L + line) * 2 + 0];
     it_fb[r] = k * NFP + tidx[T::I_PF + (d * L + line) * 2 + 1];
   }
@@ -2325,36 +2327,19 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       // barrier 1 of element k (slot (k+1)&1 was last read in phase A of element k-1) and waited for on this wave's
       // own counter before barrier 1 of element k+1
       const int lane = t - TB;
-      constexpr int UJ = U_DW / 64, DJ = D_DW / 64;
-      unsigned vu[UJ], vd[DJ]; // byte offsets of this lane's dword in every wave-instruction: field plane + run
-#pragma unroll
-      for (int j = 0; j < UJ; j++)
-      {
-        int w = lane + 64 * j;
-        if (w >= 2 * NF * NU) w = 2 * NF * NU - 1; // the padding lanes repeat the last dword
-        const int f = w / (2 * NU), r = w - f * (2 * NU);
-        vu[j] = (unsigned)f * (unsigned)plane_u * 8u + (unsigned)r * 4u;
-      }
-#pragma unroll
-      for (int j = 0; j < DJ; j++)
-      {
-        int w = lane + 64 * j;
-        if (w >= 2 * NF * NFP) w = 2 * NF * NFP - 1;
-        const int f = w / (2 * NFP), r = w - f * (2 * NFP);
-        vd[j] = (unsigned)f * (unsigned)plane_f * 8u + (unsigned)r * 4u;
-      }
-      typedef __attribute__((address_space(3))) void *lds_vp;
+      // state and LDG corrections: one run per field, 16 bytes per lane (the last lane of a state run carries 8 bytes of
+      // the next run into the padding of the slot)
+      constexpr int L_U = (NU + 1) / 2, L_D = (NFP + 1) / 2; // lanes per field run
+      constexpr int UJ = NF * ((L_U + 63) / 64), DJ = NF * ((L_D + 63) / 64);
       auto issue = [&](long e, int which) {
-        char *base = (char *)(s_in + which * SLOT);
+        const lds_dp base = (lds_dp)s_in + which * SLOT;
 #pragma unroll
-        for (int j = 0; j < UJ; j++)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(g_u0.r, (lds_vp)(base + 256 * j), 4, vu[j], (unsigned)((long)NU * e) * 8u, 0, 0);
+        for (int k = 0; k < NF; k++) dma16_region(g_u0, base + k * NUS, L_U, lane, (unsigned)((long)NU * e + k * plane_u) * 8u);
         if (viscous)
         {
 #pragma unroll
-          for (int j = 0; j < DJ; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(g_delta.r, (lds_vp)(base + 4 * U_DW + 256 * j), 4, vd[j],
-                                                     (unsigned)((long)NFP * e) * 8u, 0, 0);
+          for (int k = 0; k < NF; k++)
+            dma16_region(g_delta, base + (U_DW / 2 + k * NFP), L_D, lane, (unsigned)((long)NFP * e + k * plane_f) * 8u);
         }
       };
       // metrics: 16 bytes per lane, partial last wave-instruction masked (an inactive lane writes nothing)
@@ -2477,7 +2462,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       {
         const int d = it_dq[r];
         sr[r] = (d == 0) ? 1 : (d == 1 ? N : N * N);
-        const double *su_p = su + (it_o[r] - NF * d * NU);
+        const double *su_p = su + (it_o[r] - NF * d * NU) + it_k[r] * (NUS - NU);
 #pragma unroll
         for (int m = 0; m < N; m++) xa[r][m] = ldsv(su_p + m * sr[r]);
         da[r] = ldsv(sd + it_fa[r]);
@@ -2504,7 +2489,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     if (is_u)
     {
 #pragma unroll
-      for (int k = 0; k < NF; k++) u[k] = ldsv(&su[k * NU + tu]);
+      for (int k = 0; k < NF; k++) u[k] = ldsv(&su[k * NUS + tu]);
     }
     if (viscous && is_f)
     {
@@ -2517,7 +2502,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       {
         double x[NF];
 #pragma unroll
-        for (int k = 0; k < NF; k++) x[k] = ldsv(&su[k * NU + am[m]]);
+        for (int k = 0; k < NF; k++) x[k] = ldsv(&su[k * NUS + am[m]]);
 #pragma unroll
         for (int k = 0; k < NF; k++) uf[k] += Lrow[m] * x[k];
       }
