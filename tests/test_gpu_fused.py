@@ -102,6 +102,27 @@ def test_fused_quads_vs_methods(mode):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("dims", [2, 3])
+def test_split_paths_every_order_vs_methods(dims, order):
+    """Every instantiated element size (P1..P5, quads and hexes) of the split fused kernels -- with and without the
+    loader wave, whichever the size selects -- against the per-method path on a small deformed periodic mesh."""
+    n = [4, 3, 1] if dims == 2 else [3, 3, 3]
+    ref = H.Case(n, dims=dims, order=order, amp=0.1)
+    ref.to_device(0)
+    ref.run_steps_lib(1, fused=False)
+    ref.sync_host()
+    want = ref.array("disu_upts0").copy()
+    ref.close()
+    for mode in (2, 3):
+        c = H.Case(n, dims=dims, order=order, amp=0.1)
+        c.to_device(0)
+        c.run_steps_lib(1, fused=mode)
+        c.sync_host()
+        assert relerr(c.array("disu_upts0"), want) < 1e-12, (mode, order)
+        c.close()
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_fused_full_size_conservation(mode):
     c = H.Case(32, order=4)
