@@ -113,6 +113,12 @@ CASES = [
     case("pri_p2_n2_deformed", n=2, amp=0.1, level=2, order=2, steps=1, tets="prisms",
          upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
          vcjh_scheme_tri=1, c_tri=0.0),
+    # BASELINE.json configs[3]'s order: P3 tetrahedra and prisms (operators of the size the mixed channel case runs with)
+    case("tet_p3_n2_deformed", n=2, amp=0.1, level=1, order=3, steps=1, tets=True,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p3_n2_deformed", n=2, amp=0.1, level=1, order=3, steps=1, tets="prisms",
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
+         vcjh_scheme_tri=1, c_tri=0.0),
     # LES eddy-viscosity closures: WALE on a periodic box, Smagorinsky with wall damping between two walls
     case("hex_p2_les_wale", amp=0.15, level=2, order=2, steps=1, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0),
     case("hex_p2_les_smag", amp=0.1, level=2, order=2, steps=1, LES=1, SGS_model=0, C_s=0.17, filter_ratio=1.5,
