@@ -54,10 +54,11 @@ BASE = dict(
 BASE.update(TGV_FLUID)
 
 
-def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, tets=False, **over):
+def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, tets=False, keep_every=1, **over):
     d = dict(BASE)
     d.update(over)
-    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs, restart=restart, tets=tets)
+    return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs, restart=restart, tets=tets,
+                keep_every=keep_every)
 
 
 # boundary groups for the bdy_inters fixtures: states near the TGV initial state (rho 8.42e-4, T 300, Mach 0.1)
@@ -113,6 +114,9 @@ CASES = [
     case("pri_p2_n2_deformed", n=2, amp=0.1, level=2, order=2, steps=1, tets="prisms",
          upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
          vcjh_scheme_tri=1, c_tri=0.0),
+    # a longer run: 40 time steps (200 RK stages) of the genuine reference, the state after every step -- rounding
+    # differences between the paths must not grow
+    case("hex_p2_long", amp=0.15, level=0, order=2, steps=40, keep_every=10),
     # BASELINE.json configs[3]'s order: P3 tetrahedra and prisms (operators of the size the mixed channel case runs with)
     case("tet_p3_n2_deformed", n=2, amp=0.1, level=1, order=3, steps=1, tets=True,
          upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
@@ -215,6 +219,11 @@ def run_case(c):
             sys.stderr.write(r.stdout[-3000:] + r.stderr[-3000:])
             raise SystemExit("harness failed for " + c["name"])
         arrs = read_dump(os.path.join(td, "dump.bin"))
+    if c.get("keep_every", 1) > 1:
+        # long runs: keep the state after every keep_every-th step only
+        for k in [k for k in arrs if k.startswith("u_step")]:
+            if (int(k.split("_")[1][4:]) + 1) % c["keep_every"] != 0:
+                del arrs[k]
     if "restart_ascii" in arrs:
         arrs["restart_ascii"] = arrs["restart_ascii"].astype(np.uint8)
     arrs["xv"] = xv

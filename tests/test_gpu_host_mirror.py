@@ -51,6 +51,22 @@ def test_mirrored_rk_loop_vs_reference(name, ref_nodes):
     c.close()
 
 
+@pytest.mark.parametrize("mode", ["methods", 2, 3])
+def test_forty_steps_vs_reference(mode):
+    """200 RK stages of the genuine reference (hex_p2_long: the state after steps 10, 20, 30, 40): the mirrored loop and
+    the split fused paths stay on the reference's trajectory -- rounding differences between the paths do not grow."""
+    c, d = fixture_case("hex_p2_long")
+    c.to_device(0)
+    for last in (9, 19, 29, 39):
+        if mode == "methods":
+            c.run(10)
+        else:
+            c.run_steps_lib(10, fused=mode)
+        c.sync_host()
+        assert rel(c.array("disu_upts0"), d["u_step%d_stage4" % last]) < 1e-11, last
+    c.close()
+
+
 def test_uniform_mesh_vs_oracle(oracle):
     """Computed nodes on the axis-aligned fixture mesh: GPU and oracle see the same registration data."""
     c, d = fixture_case("hex_p2_n3_uniform")
