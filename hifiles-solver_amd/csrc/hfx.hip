@@ -438,6 +438,8 @@ int hfx_eles_destroy(hfx_eles *e)
   free_operator(e->inv_vandermonde); free_operator(e->exp_filter);
   free_operator(e->opp_over_int_cubpts); free_operator(e->over_int_filter);
   free_operator(e->opp_volume_cubpts);
+  free_operator(e->opp_p);
+  if (e->disu_ppts) (void)hipFree(e->disu_ppts);
   for (double *p : {e->weight_volume_cubpts, e->vol_detjac_vol_cubpts, e->iq_u, e->iq_g})
     if (p) (void)hipFree(p);
   for (double *p : {e->JGinv_over_int_cubpts, e->u_cub, e->t_cub})
@@ -897,6 +899,33 @@ int hfx_eles_calc_dt_local(hfx_eles *e, double CFL, double *dt_min)
   HFX_HIP(hipGetLastError());
   HFX_HIP(hipMemcpyAsync(dt_min, e->red_buf, sizeof(double), hipMemcpyDeviceToHost, st));
   HFX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---- plot-point interpolation --------------------------------------------------------------
+int hfx_eles_set_opp_p(hfx_eles *e, int n_ppts, const double *opp_p)
+{
+  HFX_CHECK(e && opp_p && n_ppts > 0, "hfx_eles_set_opp_p: bad argument");
+  free_operator(e->opp_p);
+  if (e->disu_ppts) { (void)hipFree(e->disu_ppts); e->disu_ppts = nullptr; }
+  if (make_operator(e->opp_p, opp_p, n_ppts, e->n_upts)) return 1;
+  if (dev_alloc_copy(&e->disu_ppts, nullptr, (long)n_ppts * e->n_eles * e->n_fields)) return 1;
+  e->n_ppts = n_ppts;
+  return 0;
+}
+
+int hfx_eles_calc_disu_ppts(hfx_eles *e, double *host)
+{
+  HFX_CHECK(e && host, "hfx_eles_calc_disu_ppts: NULL argument");
+  if (e->n_eles == 0) return 0; /* src/eles.cpp:3759 */
+  HFX_CHECK(e->n_ppts > 0, "calc_disu_ppts: hfx_eles_set_opp_p was not called");
+  hfx_ctx *ctx = e->ctx;
+  const Operator *ops[1] = {&e->opp_p};
+  const double *in[1] = {e->arr[HFX_DISU_UPTS0]};
+  if (contract_multi_in(ctx, ops, 1, in, e->disu_ppts, (long)e->n_eles * e->n_fields, 0)) return 1;
+  HFX_HIP(hipMemcpyAsync(host, e->disu_ppts, sizeof(double) * (size_t)e->n_ppts * e->n_eles * e->n_fields, hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HFX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 

@@ -99,6 +99,10 @@ struct hfx_eles
   int n_vol_cubpts = 0;
   hfx::Operator opp_volume_cubpts;
   double *weight_volume_cubpts = nullptr, *vol_detjac_vol_cubpts = nullptr, *iq_u = nullptr, *iq_g = nullptr;
+  // plot-point interpolation (hfx_eles_set_opp_p)
+  int n_ppts = 0;
+  hfx::Operator opp_p;
+  double *disu_ppts = nullptr;
   // over-integration (hfx_eles_set_over_int)
   bool over_int_ready = false;
   int n_cubpts = 0;

@@ -43,6 +43,7 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
   in.Mach_c_ic = d->Mach_c_ic; in.T_c_ic = d->T_c_ic; in.rho_c_ic = d->rho_c_ic;
   in.u_c_ic = d->u_c_ic; in.v_c_ic = d->v_c_ic; in.w_c_ic = d->w_c_ic; in.p_c_ic = d->p_c_ic;
   in.dx_cyclic = in.dy_cyclic = in.dz_cyclic = d->length;
+  if (d->p_res >= 2) in.p_res = d->p_res;
   in.over_int = d->over_int; in.over_int_order = d->over_int_order;
   in.shock_cap = d->shock_cap; in.shock_det_field = d->shock_det_field; in.s0 = d->s0;
   if (d->shock_cap)
@@ -132,6 +133,8 @@ extern "C" int hfxh_case_get_array(hfxh_case *c, const char *name, const double 
     else if (which == 4 && E->viscous) a = &E->opp_4(d);
     else if (which == 5 && E->viscous) a = &E->opp_5(d);
   }
+  else if (n == "opp_p") a = &E->opp_p;
+  else if (n == "loc_ppts") a = &E->loc_ppts;
   else if (n == "inv_vandermonde") a = &E->inv_vandermonde;
   else if (n == "vandermonde") a = &E->vandermonde;
   else if (n == "exp_filter") a = &E->exp_filter;
@@ -298,5 +301,14 @@ extern "C" int hfxh_case_sync_host(hfxh_case *c)
     return 1;
   }
   if (E->viscous && E->cp_grad_disu_upts_gpu_cpu()) { g_err = E->last_error(); return 1; }
+  return 0;
+}
+
+extern "C" int hfxh_case_calc_disu_ppts(hfxh_case *c, const double **out, int dims[3])
+{
+  eles *E = the_eles(c);
+  if (E->calc_disu_ppts_all()) { g_err = E->last_error(); return 1; }
+  *out = E->disu_ppts.get_ptr_cpu();
+  dims[0] = E->n_ppts_per_ele; dims[1] = E->n_eles; dims[2] = E->n_fields;
   return 0;
 }

@@ -39,6 +39,11 @@ int eles::setup(int in_n_eles, int in_max_n_spts_per_ele, input *in_run_input)
   // src/eles_hexas.cpp:74-92, src/eles_quads.cpp:77-102
   if (run_input->shock_cap && set_shock_capture_operators()) return 1;
   if (run_input->over_int && set_over_int()) return 1;
+  if (run_input->p_res >= 2) /* src/eles_hexas.cpp:97-100 */
+  {
+    set_loc_ppts();
+    set_opp_p();
+  }
   shape.setup(n_dims, max_n_spts_per_ele, n_eles);
   n_spts_per_ele.setup(n_eles);
   n_spts_per_ele.initialize_to_value(max_n_spts_per_ele);
@@ -398,6 +403,11 @@ int eles::mv_all_cpu_gpu(hfx_ctx *ctx)
       return 1;
     }
   if (hfx_eles_set_h_ref(dev, h_ref.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
+  if (n_ppts_per_ele > 0 && hfx_eles_set_opp_p(dev, n_ppts_per_ele, opp_p.get_ptr_cpu()))
+  {
+    fail(hfx_last_error());
+    return 1;
+  }
   if (run_input->over_int &&
       hfx_eles_set_over_int(dev, loc_over_int_cubpts.get_dim(1), opp_over_int_cubpts.get_ptr_cpu(), over_int_filter.get_ptr_cpu(),
                             JGinv_over_int_cubpts.get_ptr_cpu()))

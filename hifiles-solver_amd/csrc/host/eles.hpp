@@ -81,6 +81,13 @@ public:
   hf_array<double> vandermonde, inv_vandermonde, exp_filter, norm_basis_persson;
   hf_array<int> persson_high_modes; // 1: a mode with a degree == order in some direction
   hf_array<double> loc_over_int_cubpts, weight_over_int_cubpts, opp_over_int_cubpts, over_int_filter, JGinv_over_int_cubpts;
+  // ---- plot points (src/eles_hexas.cpp:498-521 set_loc_ppts, src/eles.cpp:3600 set_opp_p, :3757 calc_disu_ppts)
+  int p_res = 0, n_ppts_per_ele = 0;
+  hf_array<double> loc_ppts, opp_p, disu_ppts; // disu_ppts (n_ppts, n_eles, n_fields): filled by calc_disu_ppts_all
+  void set_loc_ppts();
+  void set_opp_p();
+  int calc_disu_ppts_all();                                         // every element at once, on the device
+  void calc_disu_ppts(int in_ele, hf_array<double> &out_disu_ppts); // the reference's per-element accessor
   int set_shock_capture_operators(); // set_vandermonde1D/3D, calc_norm_basis, set_exp_filter
   int set_over_int();                // set_over_int (cubature points, interpolation, L2-projection filter)
   void tensor_modes(hf_array<int> &deg) const;

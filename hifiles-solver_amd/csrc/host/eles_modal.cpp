@@ -234,3 +234,50 @@ int eles::set_over_int()
   kron_fill(n_dims, N, Nc, F1, over_int_filter);
   return 0;
 }
+
+// ---- plot points: p_res equispaced points per edge, first direction fastest (src/eles_hexas.cpp:498-521,
+// src/eles_quads.cpp:367-385), and the nodal basis there (eles::set_opp_p, src/eles.cpp:3600-3621)
+void eles::set_loc_ppts()
+{
+  p_res = run_input->p_res;
+  n_ppts_per_ele = 1;
+  for (int d = 0; d < n_dims; d++) n_ppts_per_ele *= p_res;
+  loc_ppts.setup(n_dims, n_ppts_per_ele);
+  for (int ppt = 0; ppt < n_ppts_per_ele; ppt++)
+  {
+    int r = ppt;
+    for (int d = 0; d < n_dims; d++)
+    {
+      loc_ppts(d, ppt) = -1.0 + ((2.0 * (r % p_res)) / (1.0 * (p_res - 1)));
+      r /= p_res;
+    }
+  }
+}
+
+void eles::set_opp_p()
+{
+  hf_array<double> loc(n_dims);
+  opp_p.setup(n_ppts_per_ele, n_upts_per_ele);
+  for (int i = 0; i < n_upts_per_ele; i++)
+    for (int j = 0; j < n_ppts_per_ele; j++)
+    {
+      for (int k = 0; k < n_dims; k++) loc(k) = loc_ppts(k, j);
+      opp_p(j, i) = eval_nodal_basis(i, loc);
+    }
+}
+
+int eles::calc_disu_ppts_all()
+{
+  if (!dev) { fail("element block is not on the device"); return 1; }
+  disu_ppts.setup(n_ppts_per_ele, n_eles, n_fields);
+  if (hfx_eles_calc_disu_ppts(dev, disu_ppts.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
+  return 0;
+}
+
+void eles::calc_disu_ppts(int in_ele, hf_array<double> &out_disu_ppts)
+{
+  // the reference interpolates one element per call; here the whole block is interpolated once and read per element
+  if (disu_ppts.get_dim(0) != n_ppts_per_ele && calc_disu_ppts_all()) return;
+  for (int k = 0; k < n_fields; k++)
+    for (int j = 0; j < n_ppts_per_ele; j++) out_disu_ppts(j, k) = disu_ppts(j, in_ele, k);
+}

@@ -34,6 +34,8 @@ struct input
   int shock_cap = 0, shock_det = 0, shock_det_field = 0;
   double s0 = 0.0, expf_fac = 36.0;
   int expf_order = 4, expf_cutoff = 0;
+  // ---- plotting: points per edge (src/input.cpp:110; the reference's default is 2)
+  int p_res = 2;
   // ---- element parameters
   int upts_type_hexa = 0, vcjh_scheme_hexa = 1;
   double eta_hexa = 0.0;

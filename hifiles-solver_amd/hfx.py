@@ -189,6 +189,16 @@ class Eles:
     def _call(self, name, *args):
         check(getattr(lib(), name)(self.h, *args))
 
+    def set_opp_p(self, opp_p):
+        a = _f(opp_p)
+        self.n_ppts = a.shape[0]
+        check(lib().hfx_eles_set_opp_p(self.h, C.c_int(a.shape[0]), a.ctypes.data_as(dp)))
+
+    def calc_disu_ppts(self):
+        out = np.zeros((self.n_ppts, self.n_eles, self.n_fields), dtype=np.float64, order="F")
+        check(lib().hfx_eles_calc_disu_ppts(self.h, out.ctypes.data_as(dp)))
+        return out
+
     def extrapolate_solution(self): self._call("hfx_eles_extrapolate_solution")
     def calculate_gradient(self): self._call("hfx_eles_calculate_gradient")
     def evaluate_invFlux(self): self._call("hfx_eles_evaluate_invFlux")

@@ -27,7 +27,8 @@ class CaseDesc(C.Structure):
                 ("n_bcs", C.c_int), ("bcs", C.c_void_p), ("side_bc", C.c_int * 6),
                 ("dt_type", C.c_int), ("CFL", C.c_double),
                 ("over_int", C.c_int), ("over_int_order", C.c_int), ("shock_cap", C.c_int), ("shock_det_field", C.c_int),
-                ("s0", C.c_double), ("expf_fac", C.c_double), ("expf_order", C.c_int), ("expf_cutoff", C.c_int)]
+                ("s0", C.c_double), ("expf_fac", C.c_double), ("expf_order", C.c_int), ("expf_cutoff", C.c_int),
+                ("p_res", C.c_int)]
 
 
 class BcDesc(C.Structure):
@@ -269,6 +270,14 @@ class Case:
         v = C.c_double(0)
         check(lib().hfxh_case_calc_time_step(self.h, C.byref(v)))
         return v.value
+
+    def calc_disu_ppts(self):
+        """eles::calc_disu_ppts for every element: (n_ppts, n_eles, n_fields)"""
+        ptr = dp()
+        dims = (C.c_int * 3)()
+        check(lib().hfxh_case_calc_disu_ppts(self.h, C.byref(ptr), dims))
+        n = dims[0] * dims[1] * dims[2]
+        return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(tuple(dims), order="F").copy()
 
     def sync_host(self):
         check(lib().hfxh_case_sync_host(self.h))

@@ -202,6 +202,14 @@ int hfx_eles_set_volume_cubpts(hfx_eles *e, int n_cubpts, const double *opp_volu
  * per-method / fused-mode-2 stage).  The caller adds over blocks and ranks (src/output.cpp:2017-2050). */
 int hfx_eles_CalcIntegralQuantities(hfx_eles *e, int n_quantities, const int *quantity_ids, double *integral_quantities);
 
+/* ---- plot-point interpolation (8f-3: the VTU writer's input) -------------- */
+/* opp_p (n_ppts,n_upts): the nodal basis at the plot points, eles::set_opp_p (src/eles.cpp:3600-3621) */
+int hfx_eles_set_opp_p(hfx_eles *e, int n_ppts, const double *opp_p);
+/* eles::calc_disu_ppts (src/eles.cpp:3757-3778) for every element at once instead of per element:
+ * disu_ppts (n_ppts,n_eles,n_fields) = opp_p . disu_upts(0), written to the HOST array the plot writer reads
+ * (output::write_vtu loops the elements, src/output.cpp) */
+int hfx_eles_calc_disu_ppts(hfx_eles *e, double *disu_ppts_host);
+
 /* ---- CFL time stepping (calc_time_step, src/solver.cpp:484-549) ---------- */
 int hfx_eles_set_h_ref(hfx_eles *e, const double *h_ref); /* eles::h_ref (n_eles), src/eles.cpp:3985 */
 /* dt_local(ic) = eles::calc_dt_local(ic) (src/eles.cpp:1267-1356) for every element -> HFX_DT_LOCAL, and the

@@ -72,6 +72,7 @@ typedef struct hfxh_case_desc
   int shock_cap, shock_det_field;
   double s0, expf_fac;
   int expf_order, expf_cutoff;
+  int p_res; /* plot points per edge (`p_res`, src/input.cpp:110); 0: the reference's default 2 */
 } hfxh_case_desc;
 
 const char *hfxh_last_error(void);
@@ -115,6 +116,8 @@ int hfxh_case_write_restart(hfxh_case *c, const char *dir, int file_num);
 int hfxh_case_read_restart(hfxh_case *c, const char *dir, int file_num, int n_files);
 /* calc_time_step (src/solver.cpp:484-549) on the device; hfxh_case_run calls it before every step */
 int hfxh_case_calc_time_step(hfxh_case *c, double *dt);
+/* eles::calc_disu_ppts for every element (device contraction + download): out (n_ppts, n_eles, n_fields) */
+int hfxh_case_calc_disu_ppts(hfxh_case *c, const double **out, int dims[3]);
 int hfxh_case_sync_host(hfxh_case *c);        /* cp_*_gpu_cpu of state, divergence, gradient */
 
 #ifdef __cplusplus

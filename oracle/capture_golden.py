@@ -54,11 +54,11 @@ BASE = dict(
 BASE.update(TGV_FLUID)
 
 
-def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, tets=False, keep_every=1, **over):
+def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, tets=False, keep_every=1, ppts=False, **over):
     d = dict(BASE)
     d.update(over)
     return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs, restart=restart, tets=tets,
-                keep_every=keep_every)
+                keep_every=keep_every, ppts=ppts)
 
 
 # boundary groups for the bdy_inters fixtures: states near the TGV initial state (rho 8.42e-4, T 300, Mach 0.1)
@@ -114,6 +114,9 @@ CASES = [
     case("pri_p2_n2_deformed", n=2, amp=0.1, level=2, order=2, steps=1, tets="prisms",
          upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
          vcjh_scheme_tri=1, c_tri=0.0),
+    # plot-point interpolation (VTU output's calc_disu_ppts): operator, plot points, interpolated initial state
+    case("hex_p3_plot", amp=0.15, level=0, order=3, steps=1, p_res=4, ppts=True),
+    case("quad_p2_plot", dims=2, n=4, amp=0.1, level=0, order=2, steps=1, p_res=3, ppts=True),
     # a longer run: 40 time steps (200 RK stages) of the genuine reference, the state after every step -- rounding
     # differences between the paths must not grow
     case("hex_p2_long", amp=0.15, level=0, order=2, steps=40, keep_every=10),
@@ -213,6 +216,8 @@ def run_case(c):
         env = dict(os.environ, HIFILES_HOME=REF_HOME)
         if c.get("restart"):
             env["HFX_DUMP_RESTART"] = "1"
+        if c.get("ppts"):
+            env["HFX_DUMP_PPTS"] = "1"
         r = subprocess.run([HARNESS, "input", "dump.bin", str(c["steps"]), str(c["level"])],
                            cwd=td, env=env, capture_output=True, text=True)
         if r.returncode != 0:

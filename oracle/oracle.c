@@ -806,6 +806,21 @@ double orc_calc_dt_local(const orc_eles *e, const orc_params *P, int ele, double
   return fmin(dt_visc, dt_inv);
 }
 
+/* eles::calc_disu_ppts (src/eles.cpp:3757-3778) for every element: out(j, ele, k) = sum_l opp_p(j,l) disu_upts(0)(l, ele, k),
+ * l ascending as in the reference's dgemm (src/funcs.cpp:49-123); opp_p (n_ppts, n_upts) from eles::set_opp_p (:3600) */
+void orc_calc_disu_ppts(const orc_eles *e, int n_ppts, const double *opp_p, double *out)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields;
+  for (int k = 0; k < nf; k++)
+    for (int i = 0; i < ne; i++)
+      for (int j = 0; j < n_ppts; j++)
+      {
+        double s = 0.0;
+        for (int l = 0; l < nu; l++) s += opp_p[j + (long)n_ppts * l] * e->disu_upts[0][l + (long)nu * (i + (long)ne * k)];
+        out[j + (long)n_ppts * (i + (long)ne * k)] = s;
+      }
+}
+
 /* src/eles.cpp:5045-5074 */
 double orc_compute_res_upts(const orc_eles *e, int norm_type, int field)
 {

@@ -174,6 +174,8 @@ void orc_AdvanceSolution(orc_eles *e, const orc_params *p, int in_step); /* :108
 double orc_calc_dt_local(const orc_eles *e, const orc_params *p, int ele, double h_ref, double CFL, int order); /* :1267 */
 /* src/eles.cpp:5045 ; norm_type 0 max, 1 L1 sum, 2 L2 sum */
 double orc_compute_res_upts(const orc_eles *e, int norm_type, int field);
+/* eles::calc_disu_ppts for every element (src/eles.cpp:3757): out (n_ppts, n_eles, n_fields) */
+void orc_calc_disu_ppts(const orc_eles *e, int n_ppts, const double *opp_p, double *out);
 
 /* face methods: src/int_inters.cpp */
 void orc_int_calculate_common_invFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p);  /* :160 */

@@ -369,6 +369,23 @@ int main(int argc, char *argv[])
   }
 
   put_arr("u_init", E->disu_upts(0));
+  if (getenv("HFX_DUMP_PPTS"))
+  {
+    // plot-point interpolation (eles::set_opp_p src/eles.cpp:3600, calc_disu_ppts :3757): the operator, the plot
+    // points and the interpolated initial state of every element, (n_ppts, n_eles, n_fields)
+    const int npp = E->opp_p.get_dim(0), nf = E->disu_upts(0).get_dim(2);
+    put_arr("opp_p", E->opp_p);
+    put_arr("loc_ppts", E->loc_ppts);
+    vector<double> pp((size_t)npp * n_eles * nf);
+    hf_array<double> one(npp, nf);
+    for (int i = 0; i < n_eles; i++)
+    {
+      E->calc_disu_ppts(i, one);
+      for (int k = 0; k < nf; k++)
+        for (int j = 0; j < npp; j++) pp[j + (size_t)npp * (i + (size_t)n_eles * k)] = one(j, k);
+    }
+    put_d("disu_ppts", pp.data(), {npp, n_eles, nf});
+  }
 
   // wall clock of the RK loop alone (setup excluded): what bench.py's cpu_baseline leg reports for the genuine reference
   const auto t_loop0 = std::chrono::steady_clock::now();

@@ -67,6 +67,28 @@ def test_forty_steps_vs_reference(mode):
     c.close()
 
 
+@pytest.mark.parametrize("name", ["hex_p3_plot", "quad_p2_plot"])
+def test_plot_point_interpolation(name):
+    """eles::calc_disu_ppts on the device (one contraction for all elements): through the C ABI with the reference's
+    opp_p, and through the host mirror that builds the plot points and the operator itself."""
+    import hfx
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    kk = meta["keys"]
+    n = meta["n"] if isinstance(meta["n"], list) else [meta["n"]] * meta["dims"]
+    c = H.Case(n + [1] * (3 - len(n)), xv=d["xv"], dims=meta["dims"], order=kk["order"], p_res=kk["p_res"], T_c_ic=kk["T_c_ic"])
+    c.to_device(0)
+    assert rel(c.calc_disu_ppts(), d["disu_ppts"]) < 1e-13
+    # the C ABI with the reference's operator on the same device block
+    ctx, e, faces, nb = c.handles()
+    opp = np.asfortranarray(d["opp_p"])
+    hfx.check(hfx.lib().hfx_eles_set_opp_p(e, C.c_int(opp.shape[0]), opp.ctypes.data_as(hfx.dp)))
+    out = np.zeros(d["disu_ppts"].shape, order="F")
+    hfx.check(hfx.lib().hfx_eles_calc_disu_ppts(e, out.ctypes.data_as(hfx.dp)))
+    assert rel(out, d["disu_ppts"]) < 1e-13
+    c.close()
+
+
 def test_uniform_mesh_vs_oracle(oracle):
     """Computed nodes on the axis-aligned fixture mesh: GPU and oracle see the same registration data."""
     c, d = fixture_case("hex_p2_n3_uniform")

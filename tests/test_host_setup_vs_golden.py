@@ -166,3 +166,16 @@ def test_modal_operators_vs_reference(name):
         assert got.shape == want.shape, k
         assert rel(got, want) < 5e-14, (k, rel(got, want))
     c.close()
+
+
+@pytest.mark.parametrize("name", ["hex_p3_plot", "quad_p2_plot"])
+def test_plot_points_vs_reference(name):
+    """set_loc_ppts / set_opp_p of the host mirror against the genuine reference's plot points and operator."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    kk = meta["keys"]
+    n = meta["n"] if isinstance(meta["n"], list) else [meta["n"]] * meta["dims"]
+    c = H.Case(n + [1] * (3 - len(n)), xv=d["xv"], dims=meta["dims"], order=kk["order"], p_res=kk["p_res"], T_c_ic=kk["T_c_ic"])
+    assert np.array_equal(c.array("loc_ppts"), d["loc_ppts"])
+    assert rel(c.array("opp_p"), d["opp_p"]) < 5e-14
+    c.close()

@@ -216,3 +216,17 @@ def test_les_intermediates(oracle, name):
     assert relerr(c.arr["sgsf_fpts"], d["s0_sgsf_fpts"]) < 1e-12
     assert relerr(c.arr["tdisf_upts"], d["s0_tdisf_upts"]) < 1e-13
     assert relerr(c.arr["div_tconf_upts"], d["s0_div_tconf_upts"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", [n for n in ALL if "_plot" in n])
+def test_plot_point_interpolation(oracle, name):
+    """eles::calc_disu_ppts: the interpolated state at the plot points of every element, from the reference's opp_p."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    e = O.Eles()
+    e.n_eles, e.n_upts, e.n_fpts, e.n_fields, e.n_dims = [int(v) for v in d["sizes"][:5]]
+    u = np.asfortranarray(d["u_init"])
+    e.disu_upts[0] = O.fptr(u)
+    opp_p = np.asfortranarray(d["opp_p"])
+    out = np.zeros(d["disu_ppts"].shape, order="F")
+    oracle.orc_calc_disu_ppts(C.byref(e), C.c_int(opp_p.shape[0]), O.fptr(opp_p), O.fptr(out))
+    assert relerr(out, d["disu_ppts"]) < RTOL
