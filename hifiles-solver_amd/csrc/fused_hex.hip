@@ -2984,7 +2984,12 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       static const int waves = getenv("HFX_SPLIT2T_WAVES") ? atoi(getenv("HFX_SPLIT2T_WAVES")) : HFX_SPLIT2T_WAVES;
       // buffer-descriptor addressing needs 32-bit byte offsets into the largest array the kernel touches
       static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
-      const bool buf = !nobuf && (double)plane_f * e->n_fields * e->n_dims * 8.0 < 4294967296.0;
+      // (the largest array the launch really touches: the metric tensors at the flux points, and the n_fields * n_dims
+      // component arrays only when they are in use -- gradients at boundary points, the de-aliased flux)
+      double most = (double)plane_f * std::max(e->n_dims * e->n_dims, e->n_fields);
+      if (e2.grad_fpts || e2.grad_upts) most = std::max(most, (double)plane_f * e->n_fields * e->n_dims);
+      if (e->over_int_ready) most = std::max(most, (double)e->n_upts * e->n_eles * e->n_fields * e->n_dims);
+      const bool buf = !nobuf && most * 8.0 < 4294967296.0;
       const bool oi = e2.tdisf_in != nullptr;
 #define HFX_FLUX_LAUNCH(WV_, BUF_, OI_, LW_)                                                                                  \
   hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_, LW_>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2,   \
