@@ -71,6 +71,26 @@ def test_gpu_partition_dealiasing_and_shock_capturing(tmp_path, mode):
     assert rel(u, u1) < 1e-11
 
 
+@pytest.mark.parametrize("mode", ["methods", "fused"])
+def test_gpu_partition_with_boundary_faces(tmp_path, mode):
+    """Partition faces and boundary faces in one run (walls on the y sides, periodic and split in x): the mirrored loop
+    and hfx_stage_partitioned reproduce the 1-rank run of the same library (pinned by the bdy fixtures)."""
+    import hfx_host as H
+    P = 0.0008421095852102401 * 286.9 * 300.0
+    bcs = [dict(type="isotherm_wall", T_static=310.0, u=3.0), dict(type="adiabat_wall", v=-2.0),
+           dict(type="sub_out_char", p_static=P * 0.999)]
+    cfg = dict(CFG, order=2, riemann_solve_type=3, bcs=bcs, sides={"y-": 0, "y+": 1, "z+": 2, "z-": 2})
+    one = H.Case([4, 4, 4], **cfg)
+    one.to_device(0)
+    one.run(2)
+    one.sync_host()
+    u1 = one.array("disu_upts0").copy()
+    one.close()
+    PU.spawn(PU.gpu_worker, 2, ([2, 4, 4], [2, 1, 1], cfg, 2, str(tmp_path), mode))
+    u = PU.assemble(str(tmp_path), "u", [2, 4, 4], [2, 1, 1], u1.shape)
+    assert rel(u, u1) < 1e-11
+
+
 def test_gpu_partition_quads(tmp_path):
     cfg = dict(CFG, dims=2, riemann_solve_type=0)
     n_local, pgrid = [4, 2], [1, 2]
