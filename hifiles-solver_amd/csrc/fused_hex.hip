@@ -1087,7 +1087,6 @@ static int tensor_build(hfx_eles *e, FusedData *F, int N, const std::vector<doub
 
 static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allow_unpaired = false)
 {
-  HFX_CHECK(!e->les_ready, "fused path: the LES closure is evaluated by the per-method path only");
   HFX_CHECK(e->ele_type == 4 || e->ele_type == 1, "fused path: tensor-product elements only (hexes, quads)");
   const int N = tensor_n(e);
   HFX_CHECK(N >= 2 && N <= 6, "fused path: built for orders 1..5 (n_upts %d, n_fpts %d)", e->n_upts, e->n_fpts);
@@ -1310,6 +1309,7 @@ int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
     HFX_CHECK(!faces[b]->is_bdy, "the gather-style fused path (fused=1) has no boundary faces: use fused=2 or 3");
   HFX_CHECK(!e->shock_ready, "the gather-style fused path (fused=1) has no shock capturing: use fused=2 or 3");
   HFX_CHECK(!e->over_int_ready, "the gather-style fused path (fused=1) has no over-integration: use fused=3");
+  HFX_CHECK(!e->les_ready, "the gather-style fused path (fused=1) has no LES closure: use fused=2");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
   if (n_steps <= 0) return 0;
@@ -1388,6 +1388,8 @@ void fused_kernel_bytes(const hfx_eles *e, double *bytes)
 
 struct SplitFaceArgs
 {
+  const double *sgsf; // LES: physical SGS flux at the flux points (n_fpts,n_eles,n_fields,n_dims), NULL: off
+
   long npairs;
   const int *L, *R;
   const unsigned char *meta; // bit1 of the LEFT point: beta sign flipped
@@ -1442,6 +1444,9 @@ __global__ __launch_bounds__(256) void face_flux_kernel(const SplitFaceArgs a)
 #pragma unroll
       for (int s = 0; s < NG; s++) gq[s] = a.grad[il + s * a.plane_f];
       calc_visf<ND, true>(a.P, ul, gq, fq);
+      if (a.sgsf) // src/int_inters.cpp:302-318: the SGS flux of each side joins its viscous flux
+#pragma unroll
+        for (int s = 0; s < NG; s++) fq[s] += a.sgsf[il + s * a.plane_f];
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
@@ -1456,6 +1461,9 @@ __global__ __launch_bounds__(256) void face_flux_kernel(const SplitFaceArgs a)
 #pragma unroll
       for (int s = 0; s < NG; s++) gq[s] = a.grad[ir + s * a.plane_f];
       calc_visf<ND, true>(a.P, ur, gq, fq);
+      if (a.sgsf)
+#pragma unroll
+        for (int s = 0; s < NG; s++) fq[s] += a.sgsf[ir + s * a.plane_f];
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
@@ -1492,6 +1500,7 @@ struct SplitEleArgs
   const double *delta, *tconf;
   double *disu_next;
   double *grad_upts, *grad_fpts, *div_out;
+  const double *sgsf_upts; // LES: JGinv * F_sgs at the solution points, added to the total flux (NULL: off)
   const double *src, *dt_local;
   unsigned long long *nan_flag;
   Phys P;
@@ -1676,6 +1685,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT_WAVES_RES) void split_
             double s = st[k + NF * l][tu];
 #pragma unroll
             for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
+            if (a.sgsf_upts) s += a.sgsf_upts[p + (k + NF * l) * plane_u]; // src/eles.cpp:2322-2348
             st[k + NF * l][tu] = s;
           }
       }
@@ -2921,6 +2931,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     a.L = f->L; a.R = f->R; a.meta = F->meta; a.plane_f = plane_f;
     a.disu = e->arr[HFX_DISU_FPTS]; a.grad = e->arr[HFX_GRAD_DISU_FPTS]; a.fnorm = e->norm_fpts; a.tdA = e->tdA_fpts;
     a.delta = e->arr[HFX_DELTA_DISU_FPTS]; a.tconf = e->arr[HFX_NORM_TCONF_FPTS];
+    a.sgsf = (e->les_ready && variant == 2) ? e->arr[HFX_SGSF_FPTS] : nullptr;
     a.P = P;
     return a;
   };
@@ -3028,6 +3039,13 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     ea.pk = F->pk_g;
     ea.tab = F->tab_g;
     hipLaunchKernelGGL((split_gradient_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, ea);
+    if (e->les_ready)
+    {
+      // LES (eddy-viscosity closures): SGS flux at the solution points from the corrected gradient, its extrapolation to
+      // the flux points (src/solver.cpp:162-167); the face kernel adds it to each side, the residual kernel to the total
+      if (hfx_les_sgsf_upts_internal(e)) return 1;
+      if (hfx_eles_extrapolate_sgsFlux(e)) return 1;
+    }
   }
   if (which == 0 || which == 3)
   {
@@ -3099,6 +3117,7 @@ static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_st
   a.disu_next = F->disu_alt;
   a.grad_upts = e->arr[HFX_GRAD_DISU_UPTS]; a.grad_fpts = e->arr[HFX_GRAD_DISU_FPTS];
   a.div_out = e->arr[HFX_DIV_TCONF_UPTS];
+  a.sgsf_upts = (e->les_ready && variant == 2) ? e->arr[HFX_SGSF_UPTS] : nullptr;
   a.src = e->src_nonzero ? e->arr[HFX_SRC_UPTS] : nullptr;
   a.dt_local = e->arr[HFX_DT_LOCAL];
   a.nan_flag = e->nan_flag;
@@ -3133,6 +3152,7 @@ int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps,
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
   HFX_CHECK(!e->over_int_ready || variant == 3, "fused=2 has no over-integration: use fused=3");
+  HFX_CHECK(!e->les_ready || variant == 2, "fused=3 has no LES closure (its flux kernel keeps the gradients in registers): use fused=2");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
   if (n_steps <= 0) return 0;
@@ -3276,6 +3296,7 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
   };
   const bool last = in_step == nst - 1;
   const int variant = (e->ctx->fused_mode == 2) ? 2 : 3; // 3: fluxes in the gradient kernel, Fn on the wire
+  HFX_CHECK(!e->les_ready, "hfx_stage_partitioned: LES needs the third partition-face exchange (sgsf_fpts), which is not built");
   HFX_CHECK(!e->over_int_ready || variant == 3, "fused=2 has no over-integration: use fused=3");
   switch (phase)
   {

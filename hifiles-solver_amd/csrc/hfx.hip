@@ -781,6 +781,24 @@ int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distanc
   return 0;
 }
 
+// sgsf_upts from disu_upts(0) and the corrected gradient in grad_disu_upts (internal: the split fused path, variant 2)
+extern "C" int hfx_les_sgsf_upts_internal(hfx_eles *e)
+{
+  HFX_CHECK(e && e->les_ready, "LES closure not set");
+  hfx_ctx *ctx = e->ctx;
+  const long plane = (long)e->n_upts * e->n_eles;
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(sgsf_upts_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, plane, ctx->phys(), e->les,
+                       e->arr[HFX_DISU_UPTS0], e->arr[HFX_GRAD_DISU_UPTS], e->JGinv_upts, e->detjac_upts, e->wall_distance,
+                       e->arr[HFX_SGSF_UPTS]);
+  else
+    hipLaunchKernelGGL(sgsf_upts_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, plane, ctx->phys(), e->les,
+                       e->arr[HFX_DISU_UPTS0], e->arr[HFX_GRAD_DISU_UPTS], e->JGinv_upts, e->detjac_upts, e->wall_distance,
+                       e->arr[HFX_SGSF_UPTS]);
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
 int hfx_eles_extrapolate_sgsFlux(hfx_eles *e)
 {
   HFX_CHECK(e, "NULL eles");

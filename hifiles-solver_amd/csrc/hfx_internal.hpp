@@ -152,3 +152,5 @@ struct hfx_inters
 // boundary-face kernels (hfx.hip); visc 0: inviscid sweep (+ LDG common solution), 1: viscous sweep;
 // fast: the fused paths' reciprocal-multiply physics
 extern "C" int hfx_bdy_launch_internal(hfx_inters *f, int visc, int fast);
+// LES: sgsf_upts = JGinv * F_sgs from disu_upts(0) and grad_disu_upts (hfx.hip)
+extern "C" int hfx_les_sgsf_upts_internal(hfx_eles *e);

@@ -159,6 +159,47 @@ __global__ __launch_bounds__(PT_BLOCK) void viscflux_les_kernel(long plane, cons
     }
 }
 
+// the SGS part alone: sgsf_upts = JGinv * F_sgs(u, grad u) (the split fused path adds it to its own total flux)
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void sgsf_upts_kernel(long plane, const Phys P, const LesParams Lp, const double *__restrict__ U,
+                                                             const double *__restrict__ G, const double *__restrict__ JGinv,
+                                                             const double *__restrict__ detjac,
+                                                             const double *__restrict__ wall_distance, double *__restrict__ sgsf_upts)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double u[NF], g[NF * ND], sg[NF * ND], JG[ND * ND];
+#pragma unroll
+  for (int k = 0; k < NF; k++) u[k] = U[p + k * plane];
+#pragma unroll
+  for (int q = 0; q < NF * ND; q++) g[q] = G[p + q * plane];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) JG[q] = JGinv[p * (ND * ND) + q];
+  double y = 0.0;
+  if (Lp.sgs_model == 0)
+  {
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+    {
+      const double w = wall_distance[p + i * plane];
+      y += w * w;
+    }
+    y = sqrt(y);
+  }
+  calc_sgsf<ND>(P, Lp, u, g, detjac[p], y, sg);
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      double ts = 0.0;
+#pragma unroll
+      for (int m = 0; m < ND; m++) ts += JG[l + ND * m] * sg[k + NF * m];
+      sgsf_upts[p + (k + NF * l) * plane] = ts;
+    }
+}
+
 // second half of eles::extrapolate_sgsFlux (src/eles.cpp:2862-2893): sgsf_fpts <- |J|^-1 J sgsf_fpts, in place
 template <int ND>
 __global__ __launch_bounds__(PT_BLOCK) void sgsf_to_physical_kernel(long plane, const double *__restrict__ detjac,

@@ -180,8 +180,8 @@ int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calc
  * (n_dims,n_dims,n_fpts,n_eles) is what extrapolate_sgsFlux uses to take the flux back to physical space
  * (src/eles.cpp:2862-2893).  Once set, evaluate_viscFlux adds the SGS flux, hfx_CalcResidual calls
  * extrapolate_sgsFlux (src/solver.cpp:162-167) and interior faces add sgsf_fpts to both sides' viscous flux
- * (src/int_inters.cpp:302-318).  Similarity / SVV models (2-4), the wall model and partition faces with LES are
- * not built and are refused. */
+ * (src/int_inters.cpp:302-318); hfx_run_steps(..., fused=2) does the same inside its split stage.  Similarity / SVV
+ * models (2-4), the wall model, partition faces with LES and LES in fused modes 1 / 3 are not built and are refused. */
 typedef struct hfx_les
 {
   int sgs_model, pad;
