@@ -140,6 +140,8 @@ def main():
     # inviscid flux and shock capturing after every stage
     ap.add_argument("--over-int-order", type=int, default=-1, help="over_int 1 with this over_int_order (cubature points per direction - 1)")
     ap.add_argument("--shock-s0", type=float, default=-1.0, help="shock_cap 1 with this sensor threshold s0")
+    ap.add_argument("--les-cs", type=float, default=-1.0, help="LES 1 with the WALE closure and this C_s (runs the split path that "
+                    "keeps the corrected gradients, --mode split)")
     args = ap.parse_args()
 
     import torch
@@ -173,6 +175,10 @@ def main():
         extra.update(over_int=1, over_int_order=args.over_int_order)
     if args.shock_s0 >= 0:
         extra.update(shock_cap=1, s0=args.shock_s0, expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0)
+    if args.les_cs >= 0:
+        extra.update(LES=1, SGS_model=1, C_s=args.les_cs, filter_ratio=1.0)
+        if args.mode == "auto":
+            args.mode = "split"
     case = H.Case(args.n, order=args.order, rank=rank, pgrid=pgrid, **extra)
     case.to_device(local_rank)
     ctx, e, faces, nb = case.handles()
@@ -341,7 +347,8 @@ def main():
             "config": {"workload": "Taylor-Green vortex, %d^3 hexa per GPU, P%d, Navier-Stokes, HLLC+LDG, RK45, "
                                    "1 step = %d RK stages" % (args.n, args.order, n_stages) +
                                    (", over-integration order %d" % args.over_int_order if args.over_int_order >= 0 else "") +
-                                   (", shock capturing s0 %g" % args.shock_s0 if args.shock_s0 >= 0 else ""),
+                                   (", shock capturing s0 %g" % args.shock_s0 if args.shock_s0 >= 0 else "") +
+                                   (", LES WALE C_s %g" % args.les_cs if args.les_cs >= 0 else ""),
                        "n_eles_per_gpu": case.n_eles, "dof_per_gpu": dof_per_rank, "path": mode,
                        "multi_gpu": "none" if world == 1 else
                        "one periodic box split into %s blocks, partition-face exchange over %s p2p" %

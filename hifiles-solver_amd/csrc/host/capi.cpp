@@ -44,6 +44,12 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
   in.u_c_ic = d->u_c_ic; in.v_c_ic = d->v_c_ic; in.w_c_ic = d->w_c_ic; in.p_c_ic = d->p_c_ic;
   in.dx_cyclic = in.dy_cyclic = in.dz_cyclic = d->length;
   if (d->p_res >= 2) in.p_res = d->p_res;
+  in.LES = d->LES;
+  if (d->LES)
+  {
+    in.SGS_model = d->SGS_model; in.C_s = d->C_s; in.filter_ratio = d->filter_ratio;
+    if (d->prandtl_t > 0) in.prandtl_t = d->prandtl_t;
+  }
   in.over_int = d->over_int; in.over_int_order = d->over_int_order;
   in.shock_cap = d->shock_cap; in.shock_det_field = d->shock_det_field; in.s0 = d->s0;
   if (d->shock_cap)
@@ -133,6 +139,7 @@ extern "C" int hfxh_case_get_array(hfxh_case *c, const char *name, const double 
     else if (which == 4 && E->viscous) a = &E->opp_4(d);
     else if (which == 5 && E->viscous) a = &E->opp_5(d);
   }
+  else if (n == "Jacobian_fpts") a = &E->Jacobian_fpts;
   else if (n == "opp_p") a = &E->opp_p;
   else if (n == "loc_ppts") a = &E->loc_ppts;
   else if (n == "inv_vandermonde") a = &E->inv_vandermonde;

@@ -199,6 +199,7 @@ int eles::set_transforms_pts(int which)
   {
     tdA_fpts.setup(npts, n_eles);
     norm_fpts.setup(npts, n_eles, n_dims);
+    if (run_input->LES) Jacobian_fpts.setup(n_dims, n_dims, npts, n_eles);
   }
   hf_array<double> loc(n_dims), pos(n_dims), d_pos(n_dims, n_dims), v(n_dims);
 
@@ -233,6 +234,9 @@ int eles::set_transforms_pts(int which)
           d_pos(d, k) = q;
         }
       }
+      if (at_fpts && run_input->LES)
+        for (int d = 0; d < n_dims; d++)
+          for (int k = 0; k < n_dims; k++) Jacobian_fpts(d, k, j, i) = d_pos(d, k);
       if (n_dims == 2)
       {
         const double xr = d_pos(0, 0), xs = d_pos(0, 1), yr = d_pos(1, 0), ys = d_pos(1, 1);
@@ -403,6 +407,14 @@ int eles::mv_all_cpu_gpu(hfx_ctx *ctx)
       return 1;
     }
   if (hfx_eles_set_h_ref(dev, h_ref.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
+  if (run_input->LES)
+  {
+    hfx_les l{};
+    l.sgs_model = run_input->SGS_model;
+    l.C_s = run_input->C_s; l.filter_ratio = run_input->filter_ratio; l.Kappa = run_input->Kappa; l.prandtl_t = run_input->prandtl_t;
+    if (run_input->SGS_model == 0) { fail("Smagorinsky closure: the host mirror has no wall distance (use WALE, SGS_model 1)"); return 1; }
+    if (hfx_eles_set_les(dev, &l, nullptr, Jacobian_fpts.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
+  }
   if (n_ppts_per_ele > 0 && hfx_eles_set_opp_p(dev, n_ppts_per_ele, opp_p.get_ptr_cpu()))
   {
     fail(hfx_last_error());
@@ -460,6 +472,7 @@ void eles::evaluate_invFlux_over_int() { HFX_CALL(hfx_eles_evaluate_invFlux_over
 void eles::shock_capture() { HFX_CALL(hfx_eles_shock_capture(dev)); }
 void eles::correct_gradient() { HFX_CALL(hfx_eles_correct_gradient(dev)); }
 void eles::evaluate_viscFlux() { HFX_CALL(hfx_eles_evaluate_viscFlux(dev)); }
+void eles::extrapolate_sgsFlux() { HFX_CALL(hfx_eles_extrapolate_sgsFlux(dev)); }
 void eles::extrapolate_totalFlux() { HFX_CALL(hfx_eles_extrapolate_totalFlux(dev)); }
 void eles::calculate_divergence() { HFX_CALL(hfx_eles_calculate_divergence(dev)); }
 void eles::calculate_corrected_divergence() { HFX_CALL(hfx_eles_calculate_corrected_divergence(dev)); }

@@ -44,6 +44,7 @@ public:
   void shock_capture();             // src/eles.cpp:2918 (run_input.shock_cap), after AdvanceSolution
   void correct_gradient();
   void evaluate_viscFlux();
+  void extrapolate_sgsFlux(); // src/eles.cpp:2817 (run_input.LES)
   void extrapolate_totalFlux();
   void calculate_divergence();
   void calculate_corrected_divergence();
@@ -76,6 +77,7 @@ public:
   hf_array<hf_array<double>> div_tconf_upts;
   hf_array<double> grad_disu_upts;
   hf_array<double> h_ref, dt_local;
+  hf_array<double> Jacobian_fpts; // (n_dims,n_dims,n_fpts,n_eles) d(pos)/d(loc) at the flux points, LES only (src/eles.cpp:4231)
   // ---- modal operators of the tensor-product classes (eles_modal.cpp): shock capturing and over-integration
   // (include/eles.h:926-935; eles_hexas.h / eles_quads.h: vandermonde, inv_vandermonde, norm_basis_persson)
   hf_array<double> vandermonde, inv_vandermonde, exp_filter, norm_basis_persson;

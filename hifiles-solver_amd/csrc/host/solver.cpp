@@ -444,6 +444,8 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_corrected_gradient();
     /*! Compute discontinuous transformed viscous flux at upts and add to total transformed flux. */
     each_ele(&eles::evaluate_viscFlux);
+    /*! If using LES, extrapolate the transformed SGS flux to the flux points and take it back to physical space (src/solver.cpp:162-167). */
+    if (FlowSol->run_input.LES) each_ele(&eles::extrapolate_sgsFlux);
   }
   /*! Compute the transformed normal discontinuous total flux at flux points. */
   each_ele(&eles::extrapolate_totalFlux);

@@ -28,7 +28,8 @@ class CaseDesc(C.Structure):
                 ("dt_type", C.c_int), ("CFL", C.c_double),
                 ("over_int", C.c_int), ("over_int_order", C.c_int), ("shock_cap", C.c_int), ("shock_det_field", C.c_int),
                 ("s0", C.c_double), ("expf_fac", C.c_double), ("expf_order", C.c_int), ("expf_cutoff", C.c_int),
-                ("p_res", C.c_int)]
+                ("LES", C.c_int), ("SGS_model", C.c_int), ("C_s", C.c_double), ("filter_ratio", C.c_double),
+                ("prandtl_t", C.c_double), ("p_res", C.c_int)]
 
 
 class BcDesc(C.Structure):

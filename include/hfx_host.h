@@ -72,6 +72,9 @@ typedef struct hfxh_case_desc
   int shock_cap, shock_det_field;
   double s0, expf_fac;
   int expf_order, expf_cutoff;
+  /* LES eddy-viscosity closure (src/input.cpp:167-182): LES 1, SGS_model 1 (WALE), C_s, filter_ratio, prandtl_t (0: 0.9) */
+  int LES, SGS_model;
+  double C_s, filter_ratio, prandtl_t;
   int p_res; /* plot points per edge (`p_res`, src/input.cpp:110); 0: the reference's default 2 */
 } hfxh_case_desc;
 

@@ -89,6 +89,28 @@ def test_plot_point_interpolation(name):
     c.close()
 
 
+@pytest.mark.parametrize("mode", ["methods", 2])
+@pytest.mark.parametrize("name,dims", [("hex_p2_les_wale", 3), ("quad_p3_les_wale", 2)])
+def test_les_wale_through_the_mirror(name, dims, mode):
+    """LES (WALE closure) from the mesh and the input keys: the mirrored CalcResidual (evaluate_viscFlux +
+    extrapolate_sgsFlux) and the split fused path (fused=2) against the genuine reference's state after a step."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    k = meta["keys"]
+    n = meta["n"] if isinstance(meta["n"], list) else [meta["n"]] * dims
+    c = H.Case(n + [1] * (3 - len(n)), xv=d["xv"], dims=dims, order=k["order"], LES=1, SGS_model=k["SGS_model"], C_s=k["C_s"],
+               filter_ratio=k["filter_ratio"], T_c_ic=k["T_c_ic"])
+    c.to_device(0)
+    if mode == "methods":
+        c.run(1)
+    else:
+        c.run_steps_lib(1, fused=mode)
+    c.sync_host()
+    last = int(d["sizes"][7]) - 1
+    assert rel(c.array("disu_upts0"), d["u_step0_stage%d" % last]) < 1e-11
+    c.close()
+
+
 def test_uniform_mesh_vs_oracle(oracle):
     """Computed nodes on the axis-aligned fixture mesh: GPU and oracle see the same registration data."""
     c, d = fixture_case("hex_p2_n3_uniform")

@@ -179,3 +179,12 @@ def test_plot_points_vs_reference(name):
     assert np.array_equal(c.array("loc_ppts"), d["loc_ppts"])
     assert rel(c.array("opp_p"), d["opp_p"]) < 5e-14
     c.close()
+
+
+def test_les_jacobian_vs_reference():
+    """Jacobian_fpts of the host mirror (what extrapolate_sgsFlux takes the SGS flux back to physical space with)."""
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p2_les_wale.npz")))
+    k = json.loads(bytes(d["meta_json"]).decode())["keys"]
+    c = H.Case(3, xv=d["xv"], order=2, LES=1, SGS_model=1, C_s=k["C_s"], filter_ratio=k["filter_ratio"], T_c_ic=k["T_c_ic"])
+    assert rel(c.array("Jacobian_fpts"), d["Jacobian_fpts"]) < 1e-14
+    c.close()
