@@ -804,12 +804,11 @@ int hfx_eles_extrapolate_sgsFlux(hfx_eles *e)
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
   HFX_CHECK(e->les_ready, "extrapolate_sgsFlux: hfx_eles_set_les was not called");
-  const long su = (long)e->n_upts * e->n_eles * e->n_fields, sf = (long)e->n_fpts * e->n_eles * e->n_fields;
-  for (int d = 0; d < e->n_dims; d++)
+  // sgsf_fpts(:,:,:,d) = opp_0 * sgsf_upts(:,:,:,d): the dim slabs are contiguous -> one launch
   {
     const Operator *ops[1] = {&e->opp_0};
-    const double *in[1] = {e->arr[HFX_SGSF_UPTS] + d * su};
-    if (contract_multi_in(e->ctx, ops, 1, in, e->arr[HFX_SGSF_FPTS] + d * sf, (long)e->n_eles * e->n_fields, 0)) return 1;
+    const double *in[1] = {e->arr[HFX_SGSF_UPTS]};
+    if (contract_multi_in(e->ctx, ops, 1, in, e->arr[HFX_SGSF_FPTS], (long)e->n_eles * e->n_fields * e->n_dims, 0)) return 1;
   }
   const long plane = (long)e->n_fpts * e->n_eles;
   if (e->n_dims == 2)
