@@ -1388,7 +1388,9 @@ void fused_kernel_bytes(const hfx_eles *e, double *bytes)
 
 struct SplitFaceArgs
 {
-  const double *sgsf; // LES: physical SGS flux at the flux points (n_fpts,n_eles,n_fields,n_dims), NULL: off
+  // LES: the SGS flux at the flux points in REFERENCE space (n_fpts,n_eles,n_fields,n_dims), NULL: off; the kernel takes
+  // it to physical space with |J|^-1 J (second half of eles::extrapolate_sgsFlux, src/eles.cpp:2862-2893)
+  const double *sgsf, *jac_fpts, *detjac_fpts;
 
   long npairs;
   const int *L, *R;
@@ -1414,6 +1416,35 @@ __global__ __launch_bounds__(256) void face_delta_kernel(const SplitFaceArgs a)
     const double uc = 0.5 * (ul + ur) - beta * (ul - ur); // src/inters.cpp:637
     a.delta[il + k * a.plane_f] = uc - ul;
     a.delta[ir + k * a.plane_f] = uc - ur;
+  }
+}
+
+// f(k, i) += sum_l (|J|^-1 ts(k, l)) J(i, l): the reference-space SGS flux of flux point `o`, taken to physical space in
+// the operation order of the reference's dgemm (alpha = 1/detjac, l outer; src/funcs.cpp:110-117)
+template <int ND>
+__device__ __forceinline__ void add_sgs_flux(const double *sgsf, const double *jac, const double *detjac, long o, long plane,
+                                             double (&f)[(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+  double J[ND * ND];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) J[q] = jac[o * (ND * ND) + q];
+  const double inv_detjac = 1.0 / detjac[o];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    double ps[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) ps[i] = 0.0;
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      const double temp = inv_detjac * sgsf[o + (k + NF * l) * plane];
+#pragma unroll
+      for (int i = 0; i < ND; i++) ps[i] += temp * J[i + ND * l];
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) f[k + NF * i] += ps[i];
   }
 }
 
@@ -1444,9 +1475,7 @@ __global__ __launch_bounds__(256) void face_flux_kernel(const SplitFaceArgs a)
 #pragma unroll
       for (int s = 0; s < NG; s++) gq[s] = a.grad[il + s * a.plane_f];
       calc_visf<ND, true>(a.P, ul, gq, fq);
-      if (a.sgsf) // src/int_inters.cpp:302-318: the SGS flux of each side joins its viscous flux
-#pragma unroll
-        for (int s = 0; s < NG; s++) fq[s] += a.sgsf[il + s * a.plane_f];
+      if (a.sgsf) add_sgs_flux<ND>(a.sgsf, a.jac_fpts, a.detjac_fpts, il, a.plane_f, fq); // src/int_inters.cpp:302-318
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
@@ -1461,9 +1490,7 @@ __global__ __launch_bounds__(256) void face_flux_kernel(const SplitFaceArgs a)
 #pragma unroll
       for (int s = 0; s < NG; s++) gq[s] = a.grad[ir + s * a.plane_f];
       calc_visf<ND, true>(a.P, ur, gq, fq);
-      if (a.sgsf)
-#pragma unroll
-        for (int s = 0; s < NG; s++) fq[s] += a.sgsf[ir + s * a.plane_f];
+      if (a.sgsf) add_sgs_flux<ND>(a.sgsf, a.jac_fpts, a.detjac_fpts, ir, a.plane_f, fq);
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
@@ -2932,6 +2959,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     a.disu = e->arr[HFX_DISU_FPTS]; a.grad = e->arr[HFX_GRAD_DISU_FPTS]; a.fnorm = e->norm_fpts; a.tdA = e->tdA_fpts;
     a.delta = e->arr[HFX_DELTA_DISU_FPTS]; a.tconf = e->arr[HFX_NORM_TCONF_FPTS];
     a.sgsf = (e->les_ready && variant == 2) ? e->arr[HFX_SGSF_FPTS] : nullptr;
+    a.jac_fpts = e->Jacobian_fpts; a.detjac_fpts = e->detjac_fpts;
     a.P = P;
     return a;
   };
@@ -3044,7 +3072,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       // LES (eddy-viscosity closures): SGS flux at the solution points from the corrected gradient, its extrapolation to
       // the flux points (src/solver.cpp:162-167); the face kernel adds it to each side, the residual kernel to the total
       if (hfx_les_sgsf_upts_internal(e)) return 1;
-      if (hfx_eles_extrapolate_sgsFlux(e)) return 1;
+      if (hfx_les_extrapolate_reference_internal(e)) return 1; // the back-transform happens in the face kernel
     }
   }
   if (which == 0 || which == 3)

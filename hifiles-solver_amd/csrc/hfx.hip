@@ -799,6 +799,16 @@ extern "C" int hfx_les_sgsf_upts_internal(hfx_eles *e)
   return 0;
 }
 
+// first half of extrapolate_sgsFlux only: sgsf_fpts = opp_0 * sgsf_upts, still in reference space (internal: the split
+// fused path applies |J|^-1 J where the face kernel consumes the flux, instead of a separate sweep over sgsf_fpts)
+extern "C" int hfx_les_extrapolate_reference_internal(hfx_eles *e)
+{
+  HFX_CHECK(e && e->les_ready, "LES closure not set");
+  const Operator *ops[1] = {&e->opp_0};
+  const double *in[1] = {e->arr[HFX_SGSF_UPTS]};
+  return contract_multi_in(e->ctx, ops, 1, in, e->arr[HFX_SGSF_FPTS], (long)e->n_eles * e->n_fields * e->n_dims, 0);
+}
+
 int hfx_eles_extrapolate_sgsFlux(hfx_eles *e)
 {
   HFX_CHECK(e, "NULL eles");

@@ -154,3 +154,4 @@ struct hfx_inters
 extern "C" int hfx_bdy_launch_internal(hfx_inters *f, int visc, int fast);
 // LES: sgsf_upts = JGinv * F_sgs from disu_upts(0) and grad_disu_upts (hfx.hip)
 extern "C" int hfx_les_sgsf_upts_internal(hfx_eles *e);
+extern "C" int hfx_les_extrapolate_reference_internal(hfx_eles *e); // sgsf_fpts = opp_0 * sgsf_upts, not yet back-transformed
