@@ -431,7 +431,8 @@ int tensor_over_int_launch(hfx_eles *e)
   a.u = e->arr[HFX_DISU_UPTS0]; a.JGc = e->JGinv_over_int_cubpts; a.I1 = T->I1; a.F1 = T->F1;
   a.tdisf = e->arr[HFX_TDISF_UPTS];
   a.gamma = e->ctx->params.gamma;
-  const size_t lds = sizeof(double) * 3 * (size_t)e->n_fields * e->n_cubpts;
+  // two regions of n_fields * Nc^nd doubles and the projection's intermediate, n_fields * N * Nc^(nd-1)
+  const size_t lds = sizeof(double) * (size_t)e->n_fields * (2 * (size_t)e->n_cubpts + (size_t)T->N * (e->n_cubpts / T->Nc));
   const int per_cu = std::max(1, (int)((160 * 1024) / lds));
   const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * std::min(per_cu, 8));
   return e->n_dims == 2 ? oi_pick_n<2, 2>(e, a, lds, grid, T->N, T->Nc) : oi_pick_n<3, 2>(e, a, lds, grid, T->N, T->Nc);
