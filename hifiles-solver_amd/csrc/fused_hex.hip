@@ -1315,12 +1315,14 @@ int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
   if (n_steps <= 0) return 0;
   const int adv = e->ctx->params.adv_type;
   const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
-  HFX_CHECK(e->ctx->params.dt_type != 2 || e->arr[HFX_DT_LOCAL], "dt_type 2 needs HFX_DT_LOCAL uploaded");
   // disu_fpts of the current state (the caller may have changed disu_upts since the last call)
   if (hfx_eles_extrapolate_solution(e)) return 1;
   for (int s = 0; s < n_steps; s++)
+  {
+    if (calc_time_step(e, nullptr)) return 1; /* src/HiFiLES.cpp:198 */
     for (int rk = 0; rk < nst; rk++)
       if (fused_stage(e, rk, rk == nst - 1)) return 1;
+  }
   return 0;
 }
 
@@ -3186,9 +3188,10 @@ int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps,
   if (n_steps <= 0) return 0;
   const int adv = e->ctx->params.adv_type;
   const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
-  HFX_CHECK(e->ctx->params.dt_type != 2 || e->arr[HFX_DT_LOCAL], "dt_type 2 needs HFX_DT_LOCAL uploaded");
   if (hfx_eles_extrapolate_solution(e)) return 1;
   for (int s = 0; s < n_steps; s++)
+  {
+    if (calc_time_step(e, nullptr)) return 1; /* src/HiFiLES.cpp:198 */
     for (int rk = 0; rk < nst; rk++)
     {
       if (split_stage(e, faces, nfb, rk, rk == nst - 1, 0, variant)) return 1;
@@ -3198,6 +3201,8 @@ int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps,
         if (shock_capture_keep_fpts(e)) return 1;
       }
     }
+    advance_ramp_counters(faces, nfb); /* src/HiFiLES.cpp:224-225 */
+  }
   return 0;
 }
 

@@ -354,6 +354,22 @@ int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode)
   return 0;
 }
 
+int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL)
+{
+  HFX_CHECK(ctx, "NULL ctx");
+  HFX_CHECK(CFL > 0.0, "hfx_ctx_set_CFL: CFL must be positive");
+  ctx->CFL = CFL;
+  ctx->have_CFL = true;
+  return 0;
+}
+
+int hfx_ctx_get_dt(hfx_ctx *ctx, double *dt)
+{
+  HFX_CHECK(ctx && dt, "hfx_ctx_get_dt: NULL argument");
+  *dt = ctx->params.dt;
+  return 0;
+}
+
 int hfx_ctx_synchronize(hfx_ctx *ctx)
 {
   HFX_CHECK(ctx, "NULL ctx");
@@ -1094,6 +1110,7 @@ int hfx_bdy_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, 
   f->ctx = ctx; f->left = left; f->right = nullptr; f->n_inters = n_inters; f->n_fpts_per_inter = nfpi;
   f->is_bdy = true;
   f->n_bcs = n_bcs;
+  for (int b = 0; b < n_bcs; b++) f->any_ramp = f->any_ramp || (bcs[b].flag == HFX_BC_SUB_IN_CHAR && bcs[b].pressure_ramp);
   f->R_ref = R_ref;
   f->hL.assign(L, L + np);
   const size_t ni = (size_t)std::max<long>(np, 1);
@@ -1351,12 +1368,16 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, i
   if (fused == 2 || fused == 3) return split_run_steps(e, faces, nfb, n_steps, fused);
   if (fused) return fused_run_steps(e, faces, nfb, n_steps);
   for (int s = 0; s < n_steps; s++)
+  {
+    if (calc_time_step(e, nullptr)) return 1; /* src/HiFiLES.cpp:198 */
     for (int rk = 0; rk < nst; rk++)
     {
       if (hfx_CalcResidual(e, faces, nfb)) return 1;
       if (hfx_eles_AdvanceSolution(e, rk, adv)) return 1;
       if (e->shock_ready && hfx_eles_shock_capture(e)) return 1; /* src/HiFiLES.cpp:214-216 */
     }
+    advance_ramp_counters(faces, nfb); /* src/HiFiLES.cpp:224-225 */
+  }
   return 0;
 }
 

@@ -68,6 +68,8 @@ struct hfx_ctx
   int contract_mode = HFX_CONTRACT_AUTO;
   int fused_mode = 1; // which fused variant hfx_time_fused_kernels / hfx_fused_kernel_bytes describe
   int n_cu = 256;
+  double CFL = 0.0; // run_input.CFL (hfx_ctx_set_CFL); dt_type 1 / 2 only
+  bool have_CFL = false;
   hfx::Phys phys() const
   {
     hfx::Phys P;
@@ -141,13 +143,37 @@ struct hfx_inters
   // partition faces (is_mpi): R holds the received-record slot lut(j); buffers are owned here
   bool is_mpi = false;
   double *out_disu = nullptr, *in_disu = nullptr, *out_grad = nullptr, *in_grad = nullptr;
+  // neighbour segments (hfx_mpi_inters_set_neighbours): faces [send[s], send[s]+count[s]) go to peer[s], its faces arrive at recv[s]
+  std::vector<int> seg_peer, seg_send, seg_recv, seg_count;
   // boundary faces (is_bdy): left side only
   bool is_bdy = false;
   int *boundary_id = nullptr; // device (n_inters)
   hfx_bc *bcs = nullptr;      // device (n_bcs)
   int n_bcs = 0, ramp_counter = 0;
+  bool any_ramp = false; // a group of this block ramps its total pressure: run_input.pressure_ramp (src/input.cpp:374-377)
   double R_ref = 0.0;
 };
+
+// RCCL transport of the partition-face buffers (comm.hip)
+struct hfx_comm
+{
+  hfx_ctx *ctx = nullptr;
+  void *nccl = nullptr;         // ncclComm_t
+  hipStream_t stream = nullptr; // communication stream
+  int nranks = 1, rank = 0;
+  hipEvent_t packed[2] = {nullptr, nullptr};   // compute -> comm: buffers of kind 0 / 1 are packed
+  hipEvent_t received[2] = {nullptr, nullptr}; // comm -> compute: exchange of kind 0 / 1 complete
+  double *scratch = nullptr;                   // device scratch of the small all-reduces
+};
+
+namespace hfx
+{
+// calc_time_step (src/solver.cpp:484-549) for one block: dt_type 1 sets params.dt to the minimum CFL step (over the ranks
+// of `comm` when given), dt_type 2 refreshes HFX_DT_LOCAL; dt_type 0: nothing (comm.hip)
+int calc_time_step(hfx_eles *e, hfx_comm *comm);
+// run_input.ramp_counter++ after a time step for the boundary blocks with a ramping group (src/HiFiLES.cpp:224-225)
+void advance_ramp_counters(hfx_inters *const *faces, int nfb);
+} // namespace hfx
 
 // boundary-face kernels (hfx.hip); visc 0: inviscid sweep (+ LDG common solution), 1: viscous sweep;
 // fast: the fused paths' reciprocal-multiply physics

@@ -90,6 +90,7 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
     }
   }
   for (int i = 0; i < 3; i++) c->mesh.n[i] = d->n[i];
+  for (int i = 0; i < 3; i++) c->mesh.self_partition[i] = (i < d->dims) ? d->self_partition[i] : 0;
   c->mesh.length = d->length;
   c->mesh.amp = d->amp;
   if (d->xv)
@@ -217,6 +218,33 @@ extern "C" int hfxh_case_get_mpi_faces(hfxh_case *c, const int **L, const int **
   *n_fpts_per_inter = M->n_fpts_per_inter;
   *n_inters = M->n_inters;
   *nout_proc = M->Nout_proc.get_ptr_cpu();
+  return 0;
+}
+
+extern "C" int hfxh_case_get_mpi_segments(hfxh_case *c, const int **peer, const int **send_first, const int **recv_first,
+                                          const int **count, int *n_seg)
+{
+  mpi_inters *M = the_mpi_faces(c);
+  *peer = M->seg_peer.data(); *send_first = M->seg_send.data(); *recv_first = M->seg_recv.data(); *count = M->seg_count.data();
+  *n_seg = (int)M->seg_peer.size();
+  return 0;
+}
+
+extern "C" int hfxh_case_set_reduce_min(hfxh_case *c, hfxh_reduce_min_cb fn, void *user)
+{
+  SetReduceMin(&c->S, fn, user);
+  return 0;
+}
+
+extern "C" int hfxh_case_set_comm(hfxh_case *c, const char *unique_id)
+{
+  if (SetComm(&c->S, unique_id)) { g_err = c->S.err; return 1; }
+  return 0;
+}
+
+extern "C" int hfxh_case_time_partitioned(hfxh_case *c, int reps, double ms[8])
+{
+  if (TimePartitioned(&c->S, reps, ms)) { g_err = c->S.err; return 1; }
   return 0;
 }
 

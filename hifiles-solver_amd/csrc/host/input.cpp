@@ -101,6 +101,7 @@ int input::read_boundary_param(std::string &err)
 {
   bc_list.assign(bc_specs.size(), hfx_bc{});
   ramp_counter = 0;
+  pressure_ramp = 0;
   for (size_t i = 0; i < bc_specs.size(); i++)
   {
     const bc_spec &in = bc_specs[i];
@@ -129,6 +130,7 @@ int input::read_boundary_param(std::string &err)
       b.pressure_ramp = in.pressure_ramp;
       if (in.pressure_ramp)
       {
+        pressure_ramp = 1; /* src/input.cpp:376 */
         ramp_counter = 1; /* src/input.cpp:377 */
         b.p_ramp_coeff = in.p_ramp_coeff; b.T_ramp_coeff = in.T_ramp_coeff;
         b.p_total_old = in.p_total_old;

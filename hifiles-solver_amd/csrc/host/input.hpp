@@ -67,6 +67,7 @@ struct input
   std::vector<bc_spec> bc_specs;
   std::vector<hfx_bc> bc_list;
   int ramp_counter = 0;
+  int pressure_ramp = 0; // 1 when a group ramps its total pressure (src/input.cpp:374-377)
   // input::read_boundary_param (src/input.cpp:328-525) after setup_params()
   int read_boundary_param(std::string &err);
   double bc_R_ref() const { return viscous ? R_ref : R_gas; } // src/bdy_inters.cpp:368-369

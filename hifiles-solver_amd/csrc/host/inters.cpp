@@ -181,22 +181,58 @@ int mpi_inters::mv_all_cpu_gpu(hfx_ctx *ctx, struct solution *FlowSol)
     if (n_inters != 0 && (expr) != 0 && err.empty()) err = hfx_last_error(); \
   } while (0)
 
+void mpi_inters::add_segment(int peer, int send_first, int recv_first, int count)
+{
+  seg_peer.push_back(peer); seg_send.push_back(send_first); seg_recv.push_back(recv_first); seg_count.push_back(count);
+}
+
+// the reference's layout: the faces shared with rank p are contiguous, ranks ascending (src/mpi_inters.cpp:244-256)
+void mpi_inters::set_segments_from_nout()
+{
+  seg_peer.clear(); seg_send.clear(); seg_recv.clear(); seg_count.clear();
+  int start = 0;
+  for (int p = 0; p < nproc; p++)
+    if (Nout_proc(p))
+    {
+      add_segment(p, start, start, Nout_proc(p));
+      start += Nout_proc(p);
+    }
+}
+
+int mpi_inters::set_comm(hfx_comm *c)
+{
+  comm = c;
+  if (n_inters == 0 || !c) return 0;
+  if (hfx_mpi_inters_set_neighbours(dev, (int)seg_peer.size(), seg_peer.data(), seg_send.data(), seg_recv.data(), seg_count.data()))
+  {
+    err = hfx_last_error();
+    return 1;
+  }
+  return 0;
+}
+
+// with the library's transport, send_* = pack + grouped ncclSend / ncclRecv on the communication stream and receive_* = the
+// compute stream's wait for them; with the hook the caller moves the packed buffers
 void mpi_inters::send_solution()
 {
+  if (comm) { HFX_MPI_CALL(hfx_mpi_inters_send_solution(dev, comm)); return; }
   HFX_MPI_CALL(hfx_mpi_inters_pack_solution(dev));
   if (n_inters != 0 && exchange) exchange(exchange_user, 0, 0);
 }
 void mpi_inters::receive_solution()
 {
+  if (comm) { HFX_MPI_CALL(hfx_mpi_inters_receive_solution(dev, comm)); return; }
   if (n_inters != 0 && exchange) exchange(exchange_user, 0, 1);
 }
 void mpi_inters::send_corrected_gradient()
 {
+  if (comm) { HFX_MPI_CALL(hfx_mpi_inters_send_corrected_gradient(dev, comm)); return; }
   HFX_MPI_CALL(hfx_mpi_inters_pack_corrected_gradient(dev));
   if (n_inters != 0 && exchange) exchange(exchange_user, 1, 0);
 }
 void mpi_inters::receive_corrected_gradient()
 {
+  if (comm) { HFX_MPI_CALL(hfx_mpi_inters_receive_corrected_gradient(dev, comm)); return; }
   if (n_inters != 0 && exchange) exchange(exchange_user, 1, 1);
 }
 void mpi_inters::calculate_common_invFlux() { HFX_MPI_CALL(hfx_mpi_inters_calculate_common_invFlux(dev)); }

@@ -7,6 +7,7 @@
 // hfx_int_inters_create (include/hfx.h).
 #pragma once
 #include <string>
+#include <vector>
 
 #include "eles.hpp"
 
@@ -66,6 +67,11 @@ public:
   void calculate_common_invFlux();   // :400
   void calculate_common_viscFlux();  // :485
   void set_exchange(hfxh_exchange_fn fn, void *user) { exchange = fn; exchange_user = user; }
+  // the library's own transport (RCCL send / recv on its communication stream, include/hfx.h): takes the place of the hook
+  int set_comm(hfx_comm *c);
+  // neighbour segments (hfx_mpi_inters_set_neighbours): derived from Nout_proc by set_segments_from_nout, or given
+  void add_segment(int peer, int send_first, int recv_first, int count);
+  void set_segments_from_nout();
 
   int get_n_inters() const { return n_inters; }
   hfx_inters *device() { return dev; }
@@ -75,11 +81,13 @@ public:
   int inters_type = 0, order = 0, viscous = 0, n_inters = 0, n_fpts_per_inter = 0, n_fields = 0, n_dims = 0;
   int nproc = 1, rank = 0, ele_type_l = -1;
   hf_array<int> Nout_proc;                // faces exchanged with each rank; a rank's faces are contiguous
+  std::vector<int> seg_peer, seg_send, seg_recv, seg_count;
   hf_array<int> disu_fpts_l, disu_fpts_r; // left offsets ; received-record slot lut(j)
   hf_array<int> lut;
 
 private:
   hfx_inters *dev = nullptr;
+  hfx_comm *comm = nullptr;
   hfxh_exchange_fn exchange = nullptr;
   void *exchange_user = nullptr;
   std::string err;

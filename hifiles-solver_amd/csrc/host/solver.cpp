@@ -7,6 +7,7 @@
 
 solution::~solution()
 {
+  if (comm) hfx_comm_destroy(comm);
   // face blocks reference element blocks: release them first
   mesh_int_inters.setup(0);
   mesh_bdy_inters.setup(0);
@@ -129,8 +130,9 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
     {
       np *= mesh.pgrid[d];
       if (mesh.pgrid[d] < 1 || mesh.pcoord[d] < 0 || mesh.pcoord[d] >= mesh.pgrid[d]) { S->err = "box mesh: bad process grid"; return 1; }
-      if (mesh.pgrid[d] == 1 && periodic[d] && nn[d] < 3) { S->err = "box mesh: need >= 3 cells per direction (periodic matching)"; return 1; }
-      if (mesh.pgrid[d] > 1 && nn[d] < 2) { S->err = "box mesh: need >= 2 cells per partitioned direction"; return 1; }
+      if (mesh.pgrid[d] == 1 && periodic[d] && !mesh.self_partition[d] && nn[d] < 3) { S->err = "box mesh: need >= 3 cells per direction (periodic matching)"; return 1; }
+      if (mesh.self_partition[d] && (mesh.pgrid[d] != 1 || !periodic[d])) { S->err = "box mesh: self_partition needs a periodic direction that is not split"; return 1; }
+      if ((mesh.pgrid[d] > 1 || mesh.self_partition[d]) && nn[d] < 2) { S->err = "box mesh: need >= 2 cells per partitioned direction"; return 1; }
     }
     if (np != S->nproc) { S->err = "box mesh: process grid does not match nproc"; return 1; }
     if (mesh.rank_of(mesh.pcoord[0], mesh.pcoord[1], dims == 3 ? mesh.pcoord[2] : 0) != S->rank) { S->err = "box mesh: process coordinates do not match rank"; return 1; }
@@ -213,6 +215,7 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
   // pass 1: count.  A face whose neighbour cell lives on another rank is a partition face
   // (src/mesh.cpp match_mpifaces / src/geometry.cpp:566-663 build the same lists from ParMETIS output).
   struct mpi_face { int nbr, key_e, key_f, e, f; };
+  auto split_dir = [&](int d) { return mesh.pgrid[d] > 1 || mesh.self_partition[d]; };
   struct bdy_face { int e, f, g; };
   std::vector<mpi_face> mf;
   std::vector<bdy_face> bf;
@@ -238,13 +241,16 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
           const bool outside = c[d] < 0 || c[d] >= nn[d];
           c[d] = (c[d] + nn[d]) % nn[d];
           const int er = c[0] + nx * (c[1] + ny * c[2]);
-          if (outside && mesh.pgrid[d] > 1)
+          if (outside && split_dir(d))
           {
             int pc[3] = {mesh.pcoord[0], mesh.pcoord[1], dims == 3 ? mesh.pcoord[2] : 0};
             pc[d] = (pc[d] + fd[1] + mesh.pgrid[d]) % mesh.pgrid[d];
             const int nbr = mesh.rank_of(pc[0], pc[1], pc[2]);
-            // both sides list the faces they share in the order of the lower rank's (cell, local face)
+            // both sides list the faces they share in the order of the lower rank's (cell, local face); the faces a rank
+            // shares with itself (self_partition) are grouped by local face and ordered by cell, so that the group of a
+            // face and the group of its mate list the pairs in the same order
             mpi_face m = {nbr, (S->rank < nbr) ? e : er, (S->rank < nbr) ? f : fd[2], e, f};
+            if (nbr == S->rank) { m.key_e = f; m.key_f = e; }
             mf.push_back(m);
           }
           else if (er >= e)
@@ -288,7 +294,7 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
           int c[3] = {i, j, k};
           if (beyond_domain(fd, c)) continue; // boundary face
           c[d] += fd[1];
-          if ((c[d] < 0 || c[d] >= nn[d]) && mesh.pgrid[d] > 1) continue; // partition face
+          if ((c[d] < 0 || c[d] >= nn[d]) && split_dir(d)) continue; // partition face
           c[d] = (c[d] + nn[d]) % nn[d];
           const int er = c[0] + nx * (c[1] + ny * c[2]);
           if (er < e) continue; // created from the other side already
@@ -325,6 +331,27 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
       nout[mf[m].nbr]++;
     }
     for (int p = 0; p < S->nproc; p++) M.set_nout_proc(nout[p], p);
+    // neighbour segments: one per neighbour rank; the faces shared with this rank itself are one segment per local face,
+    // received where the mate's group sits
+    for (size_t m = 0; m < mf.size();)
+    {
+      size_t q = m;
+      if (mf[m].nbr != S->rank)
+      {
+        while (q < mf.size() && mf[q].nbr == mf[m].nbr) q++;
+        M.add_segment(mf[m].nbr, (int)m, (int)m, (int)(q - m));
+      }
+      else
+      {
+        while (q < mf.size() && mf[q].nbr == S->rank && mf[q].f == mf[m].f) q++;
+        const int mate = ((dims == 3) ? hex_face[mf[m].f] : quad_face[mf[m].f])[2];
+        size_t r = 0;
+        while (r < mf.size() && !(mf[r].nbr == S->rank && mf[r].f == mate)) r++;
+        if (r == mf.size()) { S->err = "box mesh: a self-partition face group has no mate"; return 1; }
+        M.add_segment(S->rank, (int)m, (int)r, (int)(q - m));
+      }
+      m = q;
+    }
     if (M.failed()) { S->err = M.last_error(); return 1; }
   }
   return 0;
@@ -393,6 +420,7 @@ int MoveToDevice(solution *S, int device)
   hfx_params p;
   S->run_input.fill(p);
   if (hfx_ctx_set_params(S->ctx, &p)) { S->err = hfx_last_error(); return 1; }
+  if (S->run_input.dt_type != 0 && hfx_ctx_set_CFL(S->ctx, S->run_input.CFL)) { S->err = hfx_last_error(); return 1; }
   for (int i = 0; i < S->n_ele_types; i++)
     if (S->mesh_eles(i) && S->mesh_eles(i)->get_n_eles() != 0)
       if (S->mesh_eles(i)->mv_all_cpu_gpu(S->ctx)) { S->err = S->mesh_eles(i)->last_error(); return 1; }
@@ -480,11 +508,38 @@ int calc_time_step(solution *FlowSol)
       if (hfx_eles_calc_dt_local(FlowSol->mesh_eles(j)->device(), in.CFL, &v)) { FlowSol->err = hfx_last_error(); return 1; }
       if (v < dt_min) dt_min = v;
     }
-  if (FlowSol->nproc > 1 && FlowSol->reduce_min) dt_min = FlowSol->reduce_min(FlowSol->exchange_user, dt_min); // MPI_Allreduce MIN
+  if (FlowSol->nproc > 1 && in.dt_type == 1)
+  {
+    // MPI_Allreduce(MIN) over the ranks (src/solver.cpp:511): without it every rank would advance with its own minimum
+    if (FlowSol->comm)
+    {
+      if (hfx_comm_allreduce(FlowSol->comm, &dt_min, 1, 0)) { FlowSol->err = hfx_last_error(); return 1; }
+    }
+    else if (FlowSol->reduce_min)
+      dt_min = FlowSol->reduce_min(FlowSol->reduce_user, dt_min);
+    else
+    {
+      FlowSol->err = "calc_time_step: dt_type 1 on more than one rank needs a MIN reduction over the ranks (SetComm or SetReduceMin)";
+      return 1;
+    }
+  }
   in.dt = dt_min;
   hfx_params p;
   in.fill(p);
   if (hfx_ctx_set_params(FlowSol->ctx, &p)) { FlowSol->err = hfx_last_error(); return 1; }
+  return 0;
+}
+
+// `if (run_input.pressure_ramp) run_input.ramp_counter++` after every time step (src/HiFiLES.cpp:224-225), passed on to
+// the boundary blocks on the device
+static int advance_ramp(solution *FlowSol)
+{
+  input &in = FlowSol->run_input;
+  if (!in.pressure_ramp) return 0;
+  in.ramp_counter++;
+  for (int j = 0; j < FlowSol->n_bdy_inter_types; j++)
+    if (FlowSol->mesh_bdy_inters(j).get_n_inters() && FlowSol->mesh_bdy_inters(j).device())
+      if (hfx_bdy_inters_set_ramp_counter(FlowSol->mesh_bdy_inters(j).device(), in.ramp_counter)) { FlowSol->err = hfx_last_error(); return 1; }
   return 0;
 }
 
@@ -505,6 +560,7 @@ int RunSteps(solution *FlowSol, int n_steps)
     }
     FlowSol->time += FlowSol->run_input.dt;
     FlowSol->run_input.time = FlowSol->time;
+    if (advance_ramp(FlowSol)) return 1;
   }
   for (int j = 0; j < FlowSol->n_ele_types; j++)
     if (FlowSol->mesh_eles(j) && FlowSol->mesh_eles(j)->failed())
@@ -540,10 +596,27 @@ void SetExchange(solution *FlowSol, hfxh_exchange_fn fn, void *user)
   for (int j = 0; j < FlowSol->n_mpi_inter_types; j++) FlowSol->mesh_mpi_inters(j).set_exchange(fn, user);
 }
 
-int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
+void SetReduceMin(solution *FlowSol, double (*fn)(void *user, double v), void *user)
 {
-  // one tensor-product class, one interior block, at most one partition block
-  eles *E = nullptr;
+  FlowSol->reduce_min = fn;
+  FlowSol->reduce_user = user;
+}
+
+int SetComm(solution *FlowSol, const char *unique_id)
+{
+  if (!FlowSol->ctx) { FlowSol->err = "SetComm: the case is not on the device"; return 1; }
+  if (FlowSol->comm) { hfx_comm_destroy(FlowSol->comm); FlowSol->comm = nullptr; }
+  if (hfx_comm_create(FlowSol->ctx, unique_id, FlowSol->nproc, FlowSol->rank, &FlowSol->comm)) { FlowSol->err = hfx_last_error(); return 1; }
+  for (int j = 0; j < FlowSol->n_mpi_inter_types; j++)
+    if (FlowSol->mesh_mpi_inters(j).set_comm(FlowSol->comm)) { FlowSol->err = FlowSol->mesh_mpi_inters(j).last_error(); return 1; }
+  return 0;
+}
+
+// the blocks of a partitioned run through the split fused kernels: one tensor-product class, its interior and boundary
+// blocks (boundary blocks ride with the interior ones), its partition-face blocks
+static int partitioned_blocks(solution *FlowSol, eles *&E, std::vector<hfx_inters *> &fi, std::vector<hfx_inters *> &fm)
+{
+  E = nullptr;
   for (int j = 0; j < FlowSol->n_ele_types; j++)
     if (FlowSol->mesh_eles(j) && FlowSol->mesh_eles(j)->get_n_eles() != 0)
     {
@@ -551,14 +624,55 @@ int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
       E = FlowSol->mesh_eles(j);
     }
   if (!E) { FlowSol->err = "RunStepsPartitionedFused: no elements"; return 1; }
-  std::vector<hfx_inters *> fi, fm;
   for (int j = 0; j < FlowSol->n_int_inter_types; j++)
     if (FlowSol->mesh_int_inters(j).get_n_inters()) fi.push_back(FlowSol->mesh_int_inters(j).device());
-  for (int j = 0; j < FlowSol->n_bdy_inter_types; j++) // boundary blocks ride with the interior ones
+  for (int j = 0; j < FlowSol->n_bdy_inter_types; j++)
     if (FlowSol->mesh_bdy_inters(j).get_n_inters()) fi.push_back(FlowSol->mesh_bdy_inters(j).device());
   for (int j = 0; j < FlowSol->n_mpi_inter_types; j++)
     if (FlowSol->mesh_mpi_inters(j).get_n_inters()) fm.push_back(FlowSol->mesh_mpi_inters(j).device());
-  const int RKSteps = FlowSol->run_input.n_rk_stages();
+  return 0;
+}
+
+int TimePartitioned(solution *FlowSol, int reps, double ms[8])
+{
+  eles *E;
+  std::vector<hfx_inters *> fi, fm;
+  if (partitioned_blocks(FlowSol, E, fi, fm)) return 1;
+  if (!FlowSol->comm) { FlowSol->err = "TimePartitioned: needs the library's communicator (SetComm)"; return 1; }
+  if (hfx_time_partitioned(E->device(), fi.data(), (int)fi.size(), fm.data(), (int)fm.size(), FlowSol->comm, reps, ms))
+  {
+    FlowSol->err = hfx_last_error();
+    return 1;
+  }
+  return 0;
+}
+
+int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
+{
+  eles *E;
+  std::vector<hfx_inters *> fi, fm;
+  if (partitioned_blocks(FlowSol, E, fi, fm)) return 1;
+  input &in = FlowSol->run_input;
+  if (FlowSol->comm)
+  {
+    // the whole loop inside the library: phases, RCCL exchanges on its communication stream, calc_time_step with the
+    // all-reduce, ramp counters.  With CFL steps the host follows step by step to keep `time` (the library recomputes dt).
+    const int chunk = (in.dt_type == 0) ? n_steps : 1;
+    for (int done = 0; done < n_steps; done += chunk)
+    {
+      if (hfx_run_steps_partitioned(E->device(), fi.data(), (int)fi.size(), fm.data(), (int)fm.size(), FlowSol->comm, chunk))
+      {
+        FlowSol->err = hfx_last_error();
+        return 1;
+      }
+      if (in.dt_type != 0 && hfx_ctx_get_dt(FlowSol->ctx, &in.dt)) { FlowSol->err = hfx_last_error(); return 1; }
+      FlowSol->time += chunk * in.dt;
+      if (in.pressure_ramp) in.ramp_counter += chunk; // the library advanced its boundary blocks' counters
+    }
+    in.time = FlowSol->time;
+    return 0;
+  }
+  const int RKSteps = in.n_rk_stages();
   const bool ex = !fm.empty() && FlowSol->exchange;
   auto phase = [&](int ph, int stage, int first) {
     return hfx_stage_partitioned(E->device(), fi.data(), (int)fi.size(), fm.data(), (int)fm.size(), ph, stage, first);
@@ -566,10 +680,11 @@ int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
   auto xch = [&](int kind, int ph) {
     if (ex) FlowSol->exchange(FlowSol->exchange_user, kind, ph);
   };
-  const bool visc = FlowSol->run_input.viscous != 0;
+  const bool visc = in.viscous != 0;
   bool first = true;
   for (int i_steps = 0; i_steps < n_steps; i_steps++)
   {
+    if (calc_time_step(FlowSol)) return 1; /* src/HiFiLES.cpp:198 */
     for (int i = 0; i < RKSteps; i++)
     {
       if (first)
@@ -587,8 +702,9 @@ int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
       if (phase(4, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
       xch(0, 0);
     }
-    FlowSol->time += FlowSol->run_input.dt;
-    FlowSol->run_input.time = FlowSol->time;
+    FlowSol->time += in.dt;
+    in.time = FlowSol->time;
+    if (advance_ramp(FlowSol)) return 1;
   }
   // the exchange started after the last stage belongs to a stage that is not run: complete it so that
   // no request is left in flight (a following call starts over with `first`)

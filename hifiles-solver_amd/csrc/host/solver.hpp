@@ -33,6 +33,8 @@ struct solution
   hfxh_exchange_fn exchange = nullptr;
   void *exchange_user = nullptr;
   double (*reduce_min)(void *user, double v) = nullptr; // MPI_Allreduce(MIN) of calc_time_step, supplied by the caller
+  void *reduce_user = nullptr;
+  hfx_comm *comm = nullptr; // the library's RCCL transport (SetComm); takes the place of `exchange` and `reduce_min`
   std::string err;
   ~solution();
 };
@@ -49,6 +51,10 @@ struct box_mesh
   // structured block split is the documented stand-in.
   int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
   int rank_of(int px, int py, int pz) const { return px + pgrid[0] * (py + pgrid[1] * pz); }
+  // a periodic direction that is NOT split (pgrid 1) whose wrap-around faces are nevertheless made partition faces, with
+  // this rank as its own neighbour: the whole partition-face path (pack, exchange, one-sided kernels) then runs on one
+  // rank -- how the RCCL transport is exercised on a one-GPU box
+  int self_partition[3] = {0, 0, 0};
   // boundary group of each side of the GLOBAL box, indexed by the element-local face number (hex: z- y- x+ y+ x-
   // z+, quad: y- x+ y+ x-): index into run_input.bc_specs; -1 or a cyclic group = periodic.  A direction is
   // periodic when both of its sides are.
@@ -77,3 +83,8 @@ int RunSteps(solution *FlowSol, int n_steps);
 // phases of hfx_stage_partitioned
 int RunStepsPartitionedFused(solution *FlowSol, int n_steps);
 void SetExchange(solution *FlowSol, hfxh_exchange_fn fn, void *user);
+void SetReduceMin(solution *FlowSol, double (*fn)(void *user, double v), void *user);
+// collective: the library's communicator for this rank (id from hfx_comm_get_unique_id on rank 0)
+int SetComm(solution *FlowSol, const char *unique_id);
+// per-phase / per-exchange times of the partitioned fused stage (hfx_time_partitioned)
+int TimePartitioned(solution *FlowSol, int reps, double ms[8]);

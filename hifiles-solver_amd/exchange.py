@@ -25,12 +25,13 @@ def device_tensor(ptr, n, device):
 
 
 def segments(nout_proc, rank, allow_self=False):
-    """[(peer, first face, faces)] in buffer order."""
+    """[(peer, first face sent, first face received, faces)] in buffer order, from the reference's Nout_proc table
+    (faces of one rank contiguous, ranks ascending, src/mpi_inters.cpp:244-256)."""
     seg, start = [], 0
     for p, c in enumerate(np.asarray(nout_proc).tolist()):
         if c:
             assert allow_self or p != rank
-            seg.append((p, start, c))
+            seg.append((p, start, start, c))
             start += c
     return seg
 
@@ -41,9 +42,11 @@ class Exchange:
     CPU tensors go straight through the process group.  Device tensors go through the group directly
     when it is RCCL, and through pinned host staging when it is gloo."""
 
-    def __init__(self, nout_proc, rank, bufs, group=None, stream=None, allow_self=False):
-        self.seg = segments(nout_proc, rank, allow_self)
-        self.n_faces = sum(c for _, _, c in self.seg)
+    def __init__(self, nout_proc, rank, bufs, group=None, stream=None, allow_self=False, seg=None):
+        """seg: [(peer, send_first, recv_first, count)] (hfx_host.Case.mpi_segments); default: from nout_proc"""
+        self.seg = list(seg) if seg is not None else segments(nout_proc, rank, allow_self)
+        self.rank = rank
+        self.n_faces = sum(c for _, _, _, c in self.seg)
         self.bufs = bufs  # {kind: (out, in)}
         self.group = group
         self.backend = dist.get_backend(group)
@@ -67,9 +70,9 @@ class Exchange:
         if o.is_cuda and self.backend == "nccl":
             with torch.cuda.stream(self.stream):
                 ops = []
-                for p, s, c in self.seg:
+                for p, s, r, c in self.seg:
                     ops.append(dist.P2POp(dist.isend, o[s * rec:(s + c) * rec], p, self.group))
-                    ops.append(dist.P2POp(dist.irecv, i[s * rec:(s + c) * rec], p, self.group))
+                    ops.append(dist.P2POp(dist.irecv, i[r * rec:(r + c) * rec], p, self.group))
                 self.pending.append((kind, dist.batch_isend_irecv(ops)))
             return
         if o.is_cuda:
@@ -79,10 +82,14 @@ class Exchange:
             self.stream.synchronize()
             o, i = so, si
         reqs = []
-        for p, s, c in self.seg:
-            reqs.append(dist.irecv(i[s * rec:(s + c) * rec], src=p, group=self.group, tag=kind))
-        for p, s, c in self.seg:
-            reqs.append(dist.isend(o[s * rec:(s + c) * rec], dst=p, group=self.group, tag=kind))
+        for p, s, r, c in self.seg:
+            if p == self.rank:  # a rank's faces with itself (self-partition): a local copy stands in for the message
+                i[r * rec:(r + c) * rec].copy_(o[s * rec:(s + c) * rec])
+            else:
+                reqs.append(dist.irecv(i[r * rec:(r + c) * rec], src=p, group=self.group, tag=kind))
+        for p, s, r, c in self.seg:
+            if p != self.rank:
+                reqs.append(dist.isend(o[s * rec:(s + c) * rec], dst=p, group=self.group, tag=kind))
         self.pending.append((kind, reqs))
 
     def wait(self, kind):
@@ -132,4 +139,4 @@ def for_case(case, group=None, device=None, projected_flux=False):
     bufs = {0: (t[0], t[1])}
     if p.viscous:
         bufs[1] = (t[2], t[3])
-    return Exchange(nout, case.rank, bufs, group=group, stream=stream)
+    return Exchange(nout, case.rank, bufs, group=group, stream=stream, seg=case.mpi_segments())

@@ -124,6 +124,14 @@ class Context:
     def set_contract_mode(self, mode):
         check(lib().hfx_ctx_set_contract_mode(self.h, C.c_int(mode)))
 
+    def set_CFL(self, CFL):
+        check(lib().hfx_ctx_set_CFL(self.h, C.c_double(CFL)))
+
+    def get_dt(self):
+        v = C.c_double(0)
+        check(lib().hfx_ctx_get_dt(self.h, C.byref(v)))
+        return v.value
+
     def synchronize(self):
         check(lib().hfx_ctx_synchronize(self.h))
 
@@ -340,6 +348,33 @@ class MpiInters:
     def close(self):
         if self.h:
             lib().hfx_inters_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def comm_unique_id():
+    """128 bytes for hfx_comm_create (ncclGetUniqueId): made on rank 0, distributed by the launcher."""
+    b = C.create_string_buffer(128)
+    check(lib().hfx_comm_get_unique_id(b))
+    return b.raw
+
+
+class Comm:
+    """libhfx's RCCL communicator of one rank (hfx_comm_create is collective over the ranks)."""
+
+    def __init__(self, ctx_handle, unique_id, nranks, rank):
+        self.h = C.c_void_p()
+        self._uid = C.create_string_buffer(bytes(unique_id), 128)
+        check(lib().hfx_comm_create(ctx_handle, self._uid, C.c_int(nranks), C.c_int(rank), C.byref(self.h)))
+
+    def allreduce(self, values, op):
+        """op: "min" | "max" | "sum"; returns the reduced list"""
+        a = (C.c_double * len(values))(*values)
+        check(lib().hfx_comm_allreduce(self.h, a, C.c_int(len(values)), C.c_int({"min": 0, "max": 1, "sum": 2}[op])))
+        return list(a)
+
+    def close(self):
+        if self.h:
+            lib().hfx_comm_destroy(self.h)
             self.h = C.c_void_p()
 
 

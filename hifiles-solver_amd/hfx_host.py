@@ -29,7 +29,7 @@ class CaseDesc(C.Structure):
                 ("over_int", C.c_int), ("over_int_order", C.c_int), ("shock_cap", C.c_int), ("shock_det_field", C.c_int),
                 ("s0", C.c_double), ("expf_fac", C.c_double), ("expf_order", C.c_int), ("expf_cutoff", C.c_int),
                 ("LES", C.c_int), ("SGS_model", C.c_int), ("C_s", C.c_double), ("filter_ratio", C.c_double),
-                ("prandtl_t", C.c_double), ("p_res", C.c_int)]
+                ("prandtl_t", C.c_double), ("p_res", C.c_int), ("self_partition", C.c_int * 3)]
 
 
 class BcDesc(C.Structure):
@@ -45,6 +45,7 @@ SIDES3 = ("z-", "y-", "x+", "y+", "x-", "z+")  # element-local face numbers of a
 SIDES2 = ("y-", "x+", "y+", "x-")
 
 EXCHANGE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
+REDUCE_MIN_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_double)
 
 
 # the shipped Taylor-Green case (/root/reference/testcases/navier-stokes/Taylor_Green_vortex/input_TGV_SD_hex)
@@ -74,7 +75,7 @@ def check(rc):
 
 
 class Case:
-    def __init__(self, n, xv=None, loc_1d_upts=None, rank=0, pgrid=None, bcs=None, sides=None, **kw):
+    def __init__(self, n, xv=None, loc_1d_upts=None, rank=0, pgrid=None, bcs=None, sides=None, self_partition=None, **kw):
         """n: cells per direction of THIS rank's block; pgrid: ranks per direction (None: one rank).
         bcs: list of boundary groups, each a dict with `type` (the reference's bc type name) and the type's
         dimensional parameters (rho,u,v,w,p_static,T_static,p_total,T_total,nx,ny,nz,mach,pressure_ramp,...);
@@ -104,6 +105,8 @@ class Case:
             for i in range(3):
                 d.pgrid[i] = pgrid[i] if i < len(pgrid) else 1
         self.nproc = max(1, d.nproc)
+        for i, v in enumerate(self_partition or ()):
+            d.self_partition[i] = int(v)
         for k, v in cfg.items():
             setattr(d, k, v)
         if isinstance(n, int):
@@ -186,6 +189,30 @@ class Case:
         l = np.ctypeslib.as_array(L, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
         r = np.ctypeslib.as_array(R, shape=(n,)).copy().reshape((nf.value, ni.value), order="F")
         return l, r, np.ctypeslib.as_array(nout, shape=(self.nproc,)).copy()
+
+    def mpi_segments(self):
+        """[(peer, send_first, recv_first, count)] of the partition-face block."""
+        a = [ip(), ip(), ip(), ip()]
+        n = C.c_int()
+        check(lib().hfxh_case_get_mpi_segments(self.h, *[C.byref(x) for x in a], C.byref(n)))
+        return [tuple(int(x[s]) for x in a) for s in range(n.value)]
+
+    def set_reduce_min(self, fn):
+        """fn(v) -> min over the ranks: calc_time_step's MPI_Allreduce(MIN) when the transport is the caller's"""
+        self._rcb = REDUCE_MIN_CB(lambda user, v: float(fn(v)))
+        check(lib().hfxh_case_set_reduce_min(self.h, self._rcb, None))
+
+    def set_comm(self, unique_id):
+        """collective: libhfx's own RCCL transport; unique_id = bytes from hfx.comm_unique_id() on rank 0"""
+        assert len(unique_id) == 128
+        self._uid = C.create_string_buffer(bytes(unique_id), 128)
+        check(lib().hfxh_case_set_comm(self.h, self._uid))
+
+    def time_partitioned(self, reps):
+        ms = (C.c_double * 8)()
+        check(lib().hfxh_case_time_partitioned(self.h, C.c_int(reps), ms))
+        return dict(zip(("phase1_interior_ldg", "phase2_gradient_flux", "phase3_interior_common_flux", "phase4_update",
+                         "exchange_solution", "exchange_flux", "stage"), list(ms)[:7]))
 
     def set_exchange(self, fn):
         """fn(kind, phase): kind 0 solution / 1 corrected gradient, phase 0 start / 1 wait."""

@@ -110,6 +110,11 @@ int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode);
 /* which fused variant the measurement entry points describe: 1 gather-style (two kernels per stage),
  * 2 split (pairwise face kernels + element kernels, four launches per stage) */
 int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
+/* run_input.CFL for dt_type 1 / 2 (src/input.cpp:141-158): hfx_run_steps and hfx_run_steps_partitioned then start every
+ * time step with calc_time_step (src/HiFiLES.cpp:198, src/solver.cpp:484-549) */
+int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
+/* run_input.dt as the last calc_time_step left it (dt_type 1), or as set (dt_type 0) */
+int hfx_ctx_get_dt(hfx_ctx *ctx, double *dt);
 int hfx_ctx_synchronize(hfx_ctx *ctx);
 /* the HIP stream (hipStream_t) all kernels of this context are launched on */
 void *hfx_ctx_stream(hfx_ctx *ctx);
@@ -296,6 +301,52 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int 
  * partition faces' common flux is evaluated in phase 4. */
 int hfx_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
                           int n_mpi, int phase, int in_step, int first);
+
+/* ---- partition-face transport inside the library: RCCL point-to-point over xGMI ------------------------
+ * Replaces the MPI_Isend / MPI_Irecv / MPI_Waitall of mpi_inters::send_* / receive_* (src/mpi_inters.cpp:244-270,
+ * 304-332) by grouped ncclSend / ncclRecv on a communication stream the library owns, ordered against the
+ * context's compute stream with events -- no host synchronisation inside a stage.  librccl is resolved at run time
+ * (dlopen "librccl.so.1"; the copy already mapped into the process is reused), so callers that never create a
+ * communicator do not need it.  Launch contract: one process per GPU; rank 0 calls hfx_comm_get_unique_id and the
+ * launcher distributes the 128 bytes (MPI_Bcast in the reference's world, a file / store / gloo broadcast under
+ * Python); then every rank calls hfx_comm_create collectively. */
+typedef struct hfx_comm hfx_comm;
+#define HFX_COMM_ID_BYTES 128
+int hfx_comm_get_unique_id(char id[HFX_COMM_ID_BYTES]);
+int hfx_comm_create(hfx_ctx *ctx, const char id[HFX_COMM_ID_BYTES], int nranks, int rank, hfx_comm **out);
+int hfx_comm_destroy(hfx_comm *c);
+/* MPI_Allreduce(MIN / MAX / SUM) of a few doubles (calc_time_step's dt, src/solver.cpp:511,543; the monitors'
+ * reductions); op 0 min, 1 max, 2 sum.  Synchronises the host with the communication stream. */
+int hfx_comm_allreduce(hfx_comm *c, double *values, int n, int op);
+/* Neighbour table of a partition-face block = mpi_inters::Nout_proc generalised to segments: the faces
+ * [send_first[s], send_first[s]+count[s]) of out_buffer_* go to rank peer[s], and what peer[s] sends in return lands
+ * in the faces [recv_first[s], recv_first[s]+count[s]) of in_buffer_*.  The reference's layout (faces of one rank
+ * contiguous, ordered by rank, src/mpi_inters.cpp:244-256) is send_first == recv_first == running sum of Nout_proc.
+ * peer[s] == own rank is allowed (a periodic direction that is not split). */
+int hfx_mpi_inters_set_neighbours(hfx_inters *f, int n_seg, const int *peer, const int *send_first, const int *recv_first,
+                                  const int *count);
+/* mpi_inters::send_solution / receive_solution / send_corrected_gradient / receive_corrected_gradient
+ * (src/mpi_inters.cpp:218-336): send_* packs on the compute stream and starts the grouped exchange on the
+ * communication stream; receive_* makes the compute stream wait for it (the MPI_Waitall). */
+int hfx_mpi_inters_send_solution(hfx_inters *f, hfx_comm *c);
+int hfx_mpi_inters_receive_solution(hfx_inters *f, hfx_comm *c);
+int hfx_mpi_inters_send_corrected_gradient(hfx_inters *f, hfx_comm *c);
+int hfx_mpi_inters_receive_corrected_gradient(hfx_inters *f, hfx_comm *c);
+/* n_steps time steps of the split fused path on a partitioned block: the five phases of hfx_stage_partitioned with
+ * the two exchanges of every stage started and awaited from inside the library in CalcResidual's order
+ * (src/solver.cpp:68-72,131-139,148-155,197-210): solution exchange in flight during the interior LDG sweep, flux /
+ * gradient exchange in flight during the interior common-flux sweep.  With dt_type 1 / 2 the step starts with
+ * calc_time_step (src/HiFiLES.cpp:198): per-element CFL steps, block minimum, all-reduce MIN over the ranks.
+ * h_ref (hfx_eles_set_h_ref) and run_input.CFL (hfx_ctx_set_CFL) must have been set then.  Boundary blocks in
+ * int_faces get run_input.ramp_counter advanced after every step when one of their groups ramps
+ * (src/HiFiLES.cpp:224-225). */
+int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                              hfx_comm *comm, int n_steps);
+/* Average durations (ms, HIP events) over `reps` stages of the same loop: ms[0..3] phases 1-4 on the compute stream,
+ * ms[4] solution exchange and ms[5] flux / gradient exchange on the communication stream (from the moment their
+ * data is packed to the last byte received), ms[6] the whole stage.  The state advances by reps stages. */
+int hfx_time_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                         hfx_comm *comm, int reps, double ms[8]);
 
 /* ---- measurement ------------------------------------------------------- */
 /* Average duration (ms, HIP events on the context's stream) of every per-method entry

@@ -76,6 +76,11 @@ typedef struct hfxh_case_desc
   int LES, SGS_model;
   double C_s, filter_ratio, prandtl_t;
   int p_res; /* plot points per edge (`p_res`, src/input.cpp:110); 0: the reference's default 2 */
+  /* self_partition[d] != 0: the wrap-around faces of the periodic direction d (which must not be split, pgrid[d] 1)
+   * become partition faces whose neighbour is this rank itself.  The complete partition-face path -- pack, exchange,
+   * one-sided kernels -- then runs on ONE rank: how the RCCL transport is exercised on a one-GPU box, and how
+   * bench.py prices the partitioned stage on one GPU (--self-partition). */
+  int self_partition[3];
 } hfxh_case_desc;
 
 const char *hfxh_last_error(void);
@@ -102,6 +107,20 @@ int hfxh_case_get_mpi_faces(hfxh_case *c, const int **L, const int **Rlut, int *
  * solution, 1 corrected gradient.  The transport (RCCL / gloo through torch.distributed) belongs to the caller. */
 typedef void (*hfxh_exchange_cb)(void *user, int kind, int phase);
 int hfxh_case_set_exchange(hfxh_case *c, hfxh_exchange_cb fn, void *user);
+
+/* neighbour segments of the partition-face block (hfx_mpi_inters_set_neighbours): seg[s] = {peer, send_first, recv_first,
+ * count}; for a block without self-partition faces: one segment per neighbour rank, send_first == recv_first */
+int hfxh_case_get_mpi_segments(hfxh_case *c, const int **peer, const int **send_first, const int **recv_first, const int **count,
+                               int *n_seg);
+/* MPI_Allreduce(MIN) hook of calc_time_step (dt_type 1 on more than one rank) when the transport is the caller's */
+typedef double (*hfxh_reduce_min_cb)(void *user, double v);
+int hfxh_case_set_reduce_min(hfxh_case *c, hfxh_reduce_min_cb fn, void *user);
+/* collective over the case's nproc ranks, after hfxh_case_to_device: the library's own transport (RCCL, hfx_comm_*) with the
+ * 128-byte id of hfx_comm_get_unique_id (made on rank 0, distributed by the launcher).  From then on send_* / receive_*,
+ * hfxh_case_run_partitioned and calc_time_step's MIN reduction go through it instead of the hooks. */
+int hfxh_case_set_comm(hfxh_case *c, const char *unique_id);
+/* hfx_time_partitioned on this case's blocks: ms[0..3] phases 1-4, ms[4] solution exchange, ms[5] flux exchange, ms[6] stage */
+int hfxh_case_time_partitioned(hfxh_case *c, int reps, double ms[8]);
 
 /* device */
 int hfxh_case_to_device(hfxh_case *c, int device);

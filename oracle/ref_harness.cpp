@@ -506,6 +506,13 @@ int main(int argc, char *argv[])
         snprintf(nm, sizeof nm, "u_step%d_stage%d", step, rk);
         put_arr(nm, E->disu_upts(0));
       }
+      if (rk == RKSteps - 1 && getenv("HFX_DUMP_DIV"))
+      {
+        // full-size parity fixtures (oracle/capture_fullsize.py): the residual of the step's last stage
+        char nm[64];
+        snprintf(nm, sizeof nm, "div_step%d", step);
+        put_arr(nm, E->div_tconf_upts(0));
+      }
     }
     FlowSol.time += run_input.dt;
     run_input.time = FlowSol.time;

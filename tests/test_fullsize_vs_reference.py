@@ -1,0 +1,75 @@
+"""Array-level parity with the GENUINE reference at BASELINE.json's headline size.
+
+tests/golden/hex_p4_n32_tgv.npz (oracle/capture_fullsize.py) holds what the reference itself computes for configs[1] --
+the Taylor-Green vortex on the generated periodic 32^3 hexahedral mesh, P4, Navier-Stokes, HLLC + LDG, RK45 -- after one
+and two time steps: per-field norms of disu_upts(0) and div_tconf_upts(0) over the whole mesh and the complete arrays of
+256 sample elements (box corners, edges, faces, interior).  hex_p4_n4_tgv.npz is the same case on 4^3 elements (every
+element sampled), small enough for the CPU oracle.
+
+The mesh is axis-aligned, so the LDG switch of src/inters.cpp:568-581,620-633 is decided by the rounding noise of the
+normals; that noise is reproduced only with the reference's own (not bit-symmetric) solution-point abscissae, which
+the fixture carries as data and the host mirror takes through hfxh_case_desc.loc_1d_upts.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import hfx_host as H
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def norms(a):
+    return np.stack([np.abs(a).sum(axis=(0, 1)), (a * a).sum(axis=(0, 1)), np.abs(a).max(axis=(0, 1))])
+
+
+def check_step(d, s, u, div, tol_u, tol_div):
+    """u, div: (n_upts, n_eles, n_fields) of the whole mesh after step s"""
+    sample = d["sample_eles"]
+    for name, got, tol in (("u", u, tol_u), ("div", div, tol_div)):
+        want = d["%s_sample_step%d" % (name, s)]
+        scale = np.abs(want).max(axis=(0, 1))  # per field
+        err = (np.abs(got[:, sample, :] - want).max(axis=(0, 1)) / scale).max()
+        assert err < tol, (name, s, err)
+        wn = d["%s_norms_step%d" % (name, s)]
+        gn = norms(got)
+        assert (np.abs(gn - wn) / np.abs(wn)).max() < tol, (name, s, "norms")
+
+
+def test_oracle_vs_reference_small():
+    """the host mirror's setup + the oracle on the 4^3 version of the headline case equal the reference's arrays"""
+    import oracle_py as O
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p4_n4_tgv.npz")))
+    case = H.Case(4, order=4, loc_1d_upts=d["loc_1d_upts"])
+    oc = O.Case(case.registration())
+    e, (f, nb) = oc.c_eles(), oc.c_faces()
+    assert np.array_equal(oc.arr["u0"][:, d["sample_eles"], :], d["u_init_sample"])
+    for s in range(2):
+        assert O.load().orc_rk_step(C.byref(e), f, nb, C.byref(oc.params)) == -1
+        check_step(d, s, oc.arr["u0"], oc.arr["div_tconf_upts"], 1e-12, 1e-10)
+    case.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [3, 2, 0])
+def test_gpu_fullsize_vs_reference(fused):
+    """32^3 P4 on the device -- split3 (bench.py's default), split, per-method -- against the reference's own arrays"""
+    import hfx
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p4_n32_tgv.npz")))
+    case = H.Case(32, order=4, loc_1d_upts=d["loc_1d_upts"])
+    assert np.array_equal(case.array("disu_upts0")[:, d["sample_eles"], :], d["u_init_sample"])
+    case.to_device(0)
+    for s in range(2):
+        case.run_steps_lib(1, fused=fused)
+        ctx, e, f, nb = case.handles()
+        shape = (case.n_upts, case.n_eles, case.n_fields)
+        u = np.zeros(shape, order="F")
+        div = np.zeros(shape, order="F")
+        hfx.check(hfx.lib().hfx_eles_download(e, C.c_int(hfx.DISU_UPTS0), u.ctypes.data_as(hfx.dp)))
+        hfx.check(hfx.lib().hfx_eles_download(e, C.c_int(hfx.DIV_TCONF_UPTS), div.ctypes.data_as(hfx.dp)))
+        # 1e-11 on the state (BASELINE.json's bar is 1e-10 on conserved residuals); the divergence is a difference of
+        # terms ~1e3 larger than itself: 5e-10
+        check_step(d, s, u, div, 1e-11, 5e-10)
+    case.close()

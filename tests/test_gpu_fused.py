@@ -31,7 +31,9 @@ def test_fused_vs_reference(ctx, name, mode):
     nstage = int(d["sizes"][7])
     steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
     if "cfl" in name:
-        pytest.skip("CFL time stepping is driven stage by stage (test_gpu_methods_vs_golden.py)")
+        # calc_time_step at the top of every step inside hfx_run_steps (src/HiFiLES.cpp:198)
+        e.set_h_ref(d["h_ref"])
+        ctx.set_CFL(float(np.ravel(d["CFL"])[0]))
     # what a fused path does not do, it refuses (over-integration: mode 3 only -- the de-aliased inviscid flux is
     # evaluated ahead of the flux kernel, which then takes it instead of computing the collocated one)
     over_int = "over_int" in d and int(np.ravel(d["over_int"])[0]) != 0

@@ -100,6 +100,83 @@ def test_gpu_partition_quads(tmp_path):
     assert rel(u, u1) < 1e-11
 
 
+@pytest.mark.parametrize("mode", ["methods", "fused", "fused2"])
+def test_gpu_partition_invariance_8_ranks(mode):
+    """BASELINE.json configs[2]'s decomposition: 8 ranks on a 2x2x2 process grid, three neighbours each.  The ranks are
+    threads of this process (a GPU box allows few processes on its card); the exchange hook pulls the segments out of
+    the peers' device buffers (partition_util.ThreadTransport)."""
+    n_local, pgrid = [2, 2, 2], [2, 2, 2]
+    cfg = dict(CFG, riemann_solve_type=3)
+    parts = PU.threaded_gpu_run(8, n_local, pgrid, cfg, 2, mode)
+    u1, div1 = PU.single_rank_oracle([4, 4, 4], cfg, 2)
+    u = PU.assemble_arrays(parts, 0, n_local, pgrid, u1.shape)
+    div = PU.assemble_arrays(parts, 1, n_local, pgrid, div1.shape)
+    assert rel(u, u1) < 1e-11
+    assert rel(div, div1) < 5e-10
+
+
+@pytest.mark.parametrize("mode", ["methods", "fused", "fused2"])
+@pytest.mark.parametrize("n_local,kw", [
+    ([3, 4, 3], dict(riemann_solve_type=3, self_partition=[1, 0, 1])),
+    ([4, 2, 3], dict(riemann_solve_type=0, order=3, self_partition=[0, 1, 0])),
+])
+def test_gpu_rccl_transport_self_partition(tmp_path, mode, n_local, kw):
+    """libhfx's own transport (hfx_comm_*: grouped ncclSend / ncclRecv on the library's communication stream, ordered
+    against the compute stream by events) under the real partition-face kernels, on the one rank a one-GPU box allows:
+    the wrap-around faces of one or two periodic directions are partition faces whose neighbour is the rank itself.
+    "methods": the mirrored CalcResidual (mpi_inters::send_* / receive_* -> hfx_mpi_inters_send_* / receive_*);
+    "fused" / "fused2": hfx_run_steps_partitioned (the whole RK loop inside the library)."""
+    cfg = dict(CFG)
+    cfg.update(kw)
+    PU.spawn(PU.gpu_worker, 1, (n_local, [1, 1, 1], cfg, 2, str(tmp_path), mode, "gloo", "rccl"))
+    u1, div1 = PU.single_rank_oracle(n_local, cfg, 2)
+    u = PU.assemble(str(tmp_path), "u", n_local, [1, 1, 1], u1.shape)
+    div = PU.assemble(str(tmp_path), "div", n_local, [1, 1, 1], div1.shape)
+    assert rel(u, u1) < 1e-11
+    assert rel(div, div1) < 5e-10
+
+
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_gpu_partitioned_cfl_time_step(tmp_path, transport):
+    """dt_type 1 on the partitioned fused path: calc_time_step at the top of every step (src/HiFiLES.cpp:198), the MIN
+    reduction over the ranks through the library's communicator or the caller's hook; equals the undivided per-method run."""
+    import hfx_host as H
+    n_local = [3, 4, 3]
+    cfg = dict(CFG, riemann_solve_type=3, dt_type=1, CFL=0.3, dt=0.0)
+    one = H.Case(n_local, **cfg)
+    one.to_device(0)
+    one.run(2)
+    one.sync_host()
+    u1 = one.array("disu_upts0").copy()
+    one.close()
+    PU.spawn(PU.gpu_worker, 1, (n_local, [1, 1, 1], dict(cfg, self_partition=[1, 0, 0]), 2, str(tmp_path), "fused", "gloo", transport))
+    u = PU.assemble(str(tmp_path), "u", n_local, [1, 1, 1], u1.shape)
+    assert rel(u, u1) < 1e-11
+
+
+def _time_partitioned_worker(rank, world, port, outdir):
+    import torch
+    import hfx
+    import hfx_host as H
+    torch.cuda.set_device(0)
+    c = H.Case([4, 4, 4], order=3, amp=0.05, self_partition=[1, 1, 1])
+    c.to_device(0)
+    c.set_comm(hfx.comm_unique_id())
+    t = c.time_partitioned(5)
+    comm = hfx.Comm(c.handles()[0], hfx.comm_unique_id(), 1, 0)
+    red = comm.allreduce([3.0, -1.5], "min") + comm.allreduce([2.0], "sum")
+    comm.close()
+    c.close()
+    np.save(outdir + "/t.npy", np.array([t[k] for k in sorted(t)] + red))
+
+
+def test_gpu_time_partitioned_and_allreduce(tmp_path):
+    PU.spawn(_time_partitioned_worker, 1, (str(tmp_path),))
+    v = np.load(str(tmp_path / "t.npy"))
+    assert np.all(v[:7] > 0.0)
+    assert list(v[7:]) == [3.0, -1.5, 2.0]
+
+
 def _nccl_self_worker(rank, world, port, outdir):
     import torch
     import hfx

@@ -19,6 +19,9 @@ def rel(a, b):
     ([4, 2, 4], [1, 2, 1], dict(riemann_solve_type=0)),
     ([4, 4, 2], [1, 1, 2], dict(riemann_solve_type=2)),
     ([2, 2, 4], [2, 2, 1], dict(riemann_solve_type=3)),                   # 4 ranks, 2 neighbours each
+    ([2, 2, 2], [2, 2, 2], dict(riemann_solve_type=3)),                   # 8 ranks, BASELINE.json configs[2]'s 2x2x2 grid
+    ([3, 4, 3], [1, 1, 1], dict(riemann_solve_type=3, self_partition=[1, 0, 1])),  # one rank that is its own neighbour in x and z
+    ([2, 3, 3], [2, 1, 1], dict(riemann_solve_type=0, self_partition=[0, 1, 0])),  # a real neighbour in x, itself in y
     ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=0, viscous=0, ic_form=1, u_c_ic=30.0, v_c_ic=10.0, w_c_ic=5.0,
                                 p_c_ic=101325.0, rho_c_ic=1.2)),          # inviscid: solution exchange only
 ])
