@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- DOF-updates/s and ms/RK-stage of the HiFiLES hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--cells CELLS] [--order P] [--mode fused|methods|dense]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cells CELLS] [--order P] [--mode split3|split|methods|dense]
+                    [--workload tgv|simplex]
 
 One "step" is one time step = 5 RK stages (RK45), each stage = CalcResidual + AdvanceSolution
 (/root/reference/src/HiFiLES.cpp:201-217) over the whole mesh.  Workload at N=1: BASELINE.json
 configs[1], the Taylor-Green vortex on a generated periodic 32^3 hexahedral mesh, P4, Navier-Stokes,
-HLLC + LDG, fixed dt; inputs are resident in HBM before the timed region.
-For N>1 (launched by torch.distributed.run, one rank per GPU over RCCL) the periodic box is split into
-N blocks of 32^3 elements on a process grid (2: 2x1x1, 4: 2x2x1, 8: 2x2x2; weak scaling); every rank
-advances its block and exchanges partition-face solution and gradient records with its neighbours
-(point-to-point over xGMI) twice per RK stage, as the reference's mpi_inters do.
+HLLC + LDG, fixed dt; inputs are resident in HBM before the timed region.  The timed region (K steps between
+barriers + device synchronisation) is repeated 5 times and the MEDIAN is reported.
+For N>1 the periodic box is split into N blocks of 32^3 elements on a process grid (2: 2x1x1, 4: 2x2x1, 8: 2x2x2;
+weak scaling), one rank per GPU; every rank advances its block and exchanges partition-face solution and flux
+records with its neighbours twice per RK stage, as the reference's mpi_inters do -- by grouped ncclSend / ncclRecv
+(RCCL over xGMI) on libhfx's own communication stream, overlapped with the interior face kernels.  Started as
+`python -m torch.distributed.run ... bench.py --gpus N` the process is one rank; started plainly as
+`python bench.py --gpus N` it launches its N ranks itself as CHILD processes (before anything touches a GPU) and
+relays rank 0's line.
 
 Prints ONE JSON line (rank 0).  The oracle under oracle/ is used only for the `cpu_baseline` leg.
 """
@@ -18,6 +23,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -127,14 +134,76 @@ def reference_baseline(order, n_cells=8, n_steps=8):
     return dict(value=dofs / secs, seconds=secs, n_cells=n_cells, steps=int(m.group(1)))
 
 
+def _min_over_ranks(dist, torch, v):
+    t = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.item()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def rocprof_kernel_ms(mode, kernel):
+    """average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this workload"""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.txt" % (rnd, mode))
+        if os.path.exists(path):
+            for line in open(path):
+                if kernel + "<" in line or kernel + "(" in line:
+                    f = [x.strip() for x in line.split("|")]
+                    return float(f[3]) * 1e-3, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of THIS process, which has not
+    touched (and never touches) a GPU, and relay rank 0's JSON line.  Transports are tried in order: libhfx's own RCCL
+    communicator, RCCL through torch.distributed, gloo with host staging."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    order = [os.environ["HFX_BENCH_TRANSPORT"]] if os.environ.get("HFX_BENCH_TRANSPORT") else ["rccl", "torch", "gloo"]
+    s.close()
+    last = ""
+    for transport in order:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+        env = dict(os.environ, HFX_BENCH_TRANSPORT=transport)
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("HFX_BENCH_CHILD_TIMEOUT", "900")))
+        except subprocess.TimeoutExpired as e:
+            last = "transport %s: timed out\n%s" % (transport, (e.stderr or "")[-2000:] if isinstance(e.stderr, str) else "")
+            sys.stderr.write(last + "\n")
+            continue
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+        if r.returncode == 0 and lines:
+            sys.stderr.write(r.stderr[-4000:])
+            print(lines[-1])
+            return 0
+        last = "transport %s: exit code %d\n%s" % (transport, r.returncode, r.stderr[-4000:])
+        sys.stderr.write(last + "\n")
+    raise SystemExit("bench.py --gpus %d: every transport failed\n%s" % (args.gpus, last))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region; the median is reported")
     ap.add_argument("--cells", "--n", dest="n", type=int, default=32, help="cells per direction per GPU")
     ap.add_argument("--order", type=int, default=4)
-    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "split", "split3", "methods", "dense"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "split", "split3", "methods", "dense"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     # BASELINE.json configs[4]'s ingredients on the same mesh (not the default workload): polynomial de-aliasing of the
     # inviscid flux and shock capturing after every stage
@@ -142,28 +211,38 @@ def main():
     ap.add_argument("--shock-s0", type=float, default=-1.0, help="shock_cap 1 with this sensor threshold s0")
     ap.add_argument("--les-cs", type=float, default=-1.0, help="LES 1 with the WALE closure and this C_s (runs the split path that "
                     "keeps the corrected gradients, --mode split)")
+    ap.add_argument("--self-partition", action="store_true", help="N=1 only: the box's wrap-around faces become partition faces "
+                    "to the rank itself, i.e. the partitioned stage with its RCCL exchanges priced on one GPU")
     args = ap.parse_args()
 
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (start N ranks with torch.distributed.run, or run "
+                         "`python bench.py --gpus N` without a launcher)" % (args.gpus, world))
+
+    import torch
     dist = None
+    transport = "none"
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # HFX_BENCH_BACKEND=gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (host-staged
-        # exchange, ranks share the cards); the measured configuration is RCCL, one rank per GPU
-        backend = os.environ.get("HFX_BENCH_BACKEND", "nccl")
-        if backend != "nccl":
+        # rccl : libhfx's own communicator (grouped ncclSend / ncclRecv on its communication stream); torch.distributed
+        #        over gloo is the control plane only (unique id, barriers, the MAX of the elapsed time)
+        # torch: the exchange hook through torch.distributed's RCCL backend
+        # gloo : host-staged exchange, ranks may share cards (rehearsal on a box with fewer GPUs than ranks)
+        transport = os.environ.get("HFX_BENCH_TRANSPORT", "rccl")
+        if transport == "gloo":
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
+        if transport == "torch":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=backend)
-    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+            dist.init_process_group(backend="gloo")
     torch.cuda.set_device(local_rank)
 
     import hfx
@@ -179,53 +258,99 @@ def main():
         extra.update(LES=1, SGS_model=1, C_s=args.les_cs, filter_ratio=1.0)
         if args.mode == "auto":
             args.mode = "split"
-    case = H.Case(args.n, order=args.order, rank=rank, pgrid=pgrid, **extra)
+    # the reference's own solution-point abscissae (the data/JacobiGQ.bin row, carried as data by the full-size fixture):
+    # with them the LDG switch on this axis-aligned mesh falls as in the reference (tests/test_fullsize_vs_reference.py)
+    nodes = None
+    fx = os.path.join(ROOT, "tests", "golden", "hex_p4_n32_tgv.npz")
+    if args.order == 4 and os.path.exists(fx):
+        nodes = np.load(fx)["loc_1d_upts"]
+    selfp = [1, 1, 1] if (args.self_partition and world == 1) else None
+    case = H.Case(args.n, order=args.order, rank=rank, pgrid=pgrid, loc_1d_upts=nodes, self_partition=selfp, **extra)
     case.to_device(local_rank)
     ctx, e, faces, nb = case.handles()
     lib = hfx.lib()
     ex = None
-    if world > 1:
-        import exchange
+    partitioned = world > 1 or selfp is not None
+    if partitioned:
         if args.mode not in ("auto", "split", "split3", "methods"):
-            raise SystemExit("N>1 runs the split fused path or the per-method path")
+            raise SystemExit("a partitioned run takes the split fused path or the per-method path")
+        if selfp is not None:
+            transport = "rccl"
         pf = args.mode in ("auto", "split3")
         dev = torch.device("cuda", local_rank)
-        transport = dist.get_backend()
-        ex = exchange.for_case(case, device=dev, projected_flux=pf)
-        if transport == "nccl":
-            # one trial exchange on RCCL; if any rank fails, every rank falls back to the host-staged gloo exchange
-            # (slower, still correct) instead of losing the run
-            gloo = dist.new_group(backend="gloo")
-            ok = 1
+
+        def agreed(ok):
+            """True when the step succeeded on EVERY rank (control plane)"""
+            if dist is None:
+                return bool(ok)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def trial():
             try:
-                ex(0, 0); ex(0, 1)
+                if args.mode == "methods":
+                    case.CalcResidual()
+                else:
+                    case.run_partitioned(1)
                 torch.cuda.synchronize()
+                return True
             except Exception as err:  # noqa: BLE001
-                sys.stderr.write("rank %d: RCCL partition-face exchange failed (%s); falling back to gloo\n" % (rank, err))
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
-            if int(flag.item()) == 0:
+                sys.stderr.write("rank %d: partition-face exchange over %s failed: %s\n" % (rank, transport, err))
+                return False
+
+        if transport == "rccl":
+            ok = True
+            try:
+                uid = [hfx.comm_unique_id() if rank == 0 else None]
+            except Exception as err:  # noqa: BLE001
+                sys.stderr.write("rank %d: %s\n" % (rank, err))
+                uid, ok = [None], False
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)
+            ok = ok and uid[0] is not None
+            if agreed(ok):
+                try:
+                    case.set_comm(uid[0])  # collective: ncclCommInitRank
+                except Exception as err:  # noqa: BLE001
+                    sys.stderr.write("rank %d: %s\n" % (rank, err))
+                    ok = False
+            if not (agreed(ok) and agreed(trial())):
+                if selfp is not None:
+                    raise SystemExit("--self-partition needs libhfx's RCCL transport")
+                case.set_comm(None)
+                transport = "torch"
+        if transport != "rccl":
+            import exchange
+            group = None
+            if transport == "torch" and dist.get_backend() != "nccl":
+                # the launcher's control plane is gloo: a second group on RCCL for the data path
+                try:
+                    group = dist.new_group(backend="nccl", device_id=dev)
+                except TypeError:
+                    group = dist.new_group(backend="nccl")
+            ex = exchange.for_case(case, group=group, device=dev, projected_flux=pf)
+            case.set_exchange(ex)
+            case.set_reduce_min(lambda v: float(_min_over_ranks(dist, torch, v)))
+            if transport == "torch" and not agreed(trial()):
                 ex.close()
-                ex = exchange.for_case(case, group=gloo, device=dev, projected_flux=pf)
-                transport = "gloo (fallback, host staged)"
-        case.set_exchange(ex)
+                transport = "gloo"
+                ex = exchange.for_case(case, device=dev, projected_flux=pf)  # host staged through the gloo control group
+                case.set_exchange(ex)
 
     mode = args.mode
-    fused_ok = False
-    if world > 1:
+    if partitioned:
         mode = "split3" if mode == "auto" else mode
-    elif mode in ("auto", "fused", "split", "split3"):
-        probe = {"fused": 1, "split": 2, "split3": 3}[DEFAULT_FUSED if mode == "auto" else mode]
+    elif mode in ("auto", "split", "split3"):
+        probe = {"split": 2, "split3": 3}[DEFAULT_FUSED if mode == "auto" else mode]
         rc = lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(0), C.c_int(probe))
-        fused_ok = (rc == 0)
-        if mode != "auto" and not fused_ok:
+        if mode != "auto" and rc != 0:
             raise SystemExit("fused path unavailable: " + lib.hfx_last_error().decode())
         if mode == "auto":
-            mode = DEFAULT_FUSED if fused_ok else "methods"
+            mode = DEFAULT_FUSED if rc == 0 else "methods"
     if mode == "dense":
         hfx.check(lib.hfx_ctx_set_contract_mode(ctx, C.c_int(hfx.CONTRACT_DENSE)))
-    fused = {"fused": 1, "split": 2, "split3": 3}.get(mode, 0)
+    fused = {"split": 2, "split3": 3}.get(mode, 0)
     if fused:
         hfx.check(lib.hfx_ctx_set_fused_mode(ctx, C.c_int(fused)))
 
@@ -234,27 +359,31 @@ def main():
             dist.barrier()
 
     def run(nsteps):
-        if world == 1:
+        if not partitioned:
             hfx.check(lib.hfx_run_steps(e, faces, C.c_int(nb), C.c_int(nsteps), C.c_int(fused)))
         elif fused:
-            case.run_partitioned(nsteps)  # hfx_stage_partitioned phases + exchanges
+            case.run_partitioned(nsteps)  # hfx_run_steps_partitioned (RCCL inside libhfx) or phases + exchange hook
         elif nsteps:
             case.run(nsteps)              # mirrored CalcResidual with the mpi_inters calls
 
     run(args.warmup)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    samples = []
+    for _ in range(max(1, args.reps)):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        samples.append(el)
+    elapsed = float(np.median(samples))
 
     # state sanity: the run must not have produced NaNs (src/eles.cpp:1781-1795)
     bad = C.c_long(0)
@@ -268,9 +397,15 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     ms_per_stage = ms_per_step / n_stages
 
+    phases = None
+    if partitioned and fused and transport == "rccl":
+        # per-phase and per-exchange times of the partitioned stage (HIP events on the compute / communication streams);
+        # collective: every rank runs it, rank 0 reports its own
+        phases = case.time_partitioned(10)
+
     roof = None
     cpu = None
-    if rank == 0 and world == 1:
+    if rank == 0 and not partitioned:
         # ---- roofline of the dominant kernel, timed live with HIP events on the library's stream
         if fused:
             kt = (C.c_double * 8)()
@@ -288,13 +423,19 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in separate
             # rocprofv3 runs by tools/profile_round.sh and committed under profiles/); only valid for the
             # workload it was measured on
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % mode)
-            if os.path.exists(tfile) and args.n == 32 and args.order == 4:
-                traffic = json.load(open(tfile)).get(dom, {}).get("traffic_bytes_corrected")
+            traffic, traffic_source = None, None
+            for rnd in ("r02", "r01"):
+                tfile = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, mode))
+                if os.path.exists(tfile) and args.n == 32 and args.order == 4 and not extra:
+                    traffic = json.load(open(tfile)).get(dom, {}).get("traffic_bytes_corrected")
+                    traffic_source = "profiles/%s_%s_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                                     "command on another box, builder run; not measured in this run)" % (rnd, mode)
+                    break
+            k_prof, k_src = rocprof_kernel_ms(mode, dom) if (args.n == 32 and args.order == 4 and not extra) else (None, None)
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, algorithmic_bytes=bytes_launch,
-                        kernel_ms=times[dom],
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source,
+                        algorithmic_bytes=bytes_launch, kernel_ms=times[dom], kernel_ms_source="HIP events in this run",
+                        kernel_ms_rocprof=k_prof, kernel_ms_rocprof_source=k_src,
                         kernels_ms=times, stage_algorithmic_bytes_per_element=per_ele,
                         stage_hbm_frac=per_ele * case.n_eles / (ms_per_stage * 1e-3) / 1e9 / HBM_PEAK_GBS)
         else:
@@ -318,7 +459,7 @@ def main():
                 achieved = mb[dom] * case.n_eles / (times[dom] * 1e-3) / 1e9
                 roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=achieved / HBM_PEAK_GBS, traffic=None, kernel_ms=times[dom], methods_ms=times)
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:
             # the GPU box gives one job a 16-CPU share whatever os.cpu_count() says
             threads = max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
             cb = cpu_baseline(args.order, threads)
@@ -329,39 +470,52 @@ def main():
             rb = reference_baseline(args.order)
             if rb is not None:
                 # the reference is a serial code (no OpenMP / threads anywhere in its src/): one core is all it uses
-                cpu = dict(value=rb["value"], unit="DOF-updates/s", cores=1, kind="reference",
+                cpu = dict(value=rb["value"], unit="DOF-updates/s", cores=1, cpu_model=cpu_model(), kind="reference",
                            sample="genuine reference (oracle/_ref/ref_harness: g++ -O3 of the reference's own sources, serial, "
                                   "BLAS=NO), its RK loop on a %d^3 P%d TGV mesh, %d time steps in %.1f s; beside it the %s" %
                                   (rb["n_cells"], args.order, rb["steps"], rb["seconds"], port_note),
                            port_value_allcores=cb["allcores"]["value"], port_cores=threads, port_value_1core=cb["1core"]["value"])
             else:
-                cpu = dict(value=cb["allcores"]["value"], unit="DOF-updates/s", cores=threads, kind="port", sample=port_note,
-                           value_1core=cb["1core"]["value"])
+                cpu = dict(value=cb["allcores"]["value"], unit="DOF-updates/s", cores=threads, cpu_model=cpu_model(), kind="port",
+                           sample=port_note, value_1core=cb["1core"]["value"])
 
     if rank == 0:
+        knobs = {k: v for k, v in os.environ.items() if k.startswith("HFX_") and k != "HFX_BENCH_CHILD_TIMEOUT"}
+        tname = {"rccl": "RCCL p2p (grouped ncclSend / ncclRecv on libhfx's communication stream, hfx_run_steps_partitioned)",
+                 "torch": "RCCL p2p through torch.distributed (exchange hook)",
+                 "gloo": "gloo p2p, host staged (rehearsal)"}.get(transport, transport)
+        if world > 1:
+            mg = "one periodic box split into %s blocks, partition-face exchange over %s" % ("x".join(map(str, pgrid)), tname)
+        elif selfp is not None:
+            mg = "one rank that is its own neighbour in x, y and z (self-partition): the partitioned stage on one GPU, exchange over " + tname
+        else:
+            mg = "none"
         line = {
             "metric": "DOF-updates/sec", "value": value, "unit": "DOF-updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "ms_per_rk_stage": ms_per_stage, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "timing": {"reps": len(samples), "statistic": "median", "seconds_per_rep": samples, "stages_per_rep": n_stages * args.steps},
             "config": {"workload": "Taylor-Green vortex, %d^3 hexa per GPU, P%d, Navier-Stokes, HLLC+LDG, RK45, "
                                    "1 step = %d RK stages" % (args.n, args.order, n_stages) +
                                    (", over-integration order %d" % args.over_int_order if args.over_int_order >= 0 else "") +
                                    (", shock capturing s0 %g" % args.shock_s0 if args.shock_s0 >= 0 else "") +
                                    (", LES WALE C_s %g" % args.les_cs if args.les_cs >= 0 else ""),
                        "n_eles_per_gpu": case.n_eles, "dof_per_gpu": dof_per_rank, "path": mode,
-                       "multi_gpu": "none" if world == 1 else
-                       "one periodic box split into %s blocks, partition-face exchange over %s p2p" %
-                       ("x".join(map(str, pgrid)), "RCCL" if transport == "nccl" else transport + (" (rehearsal)" if "fallback" not in transport else ""))},
+                       "solution_points": "reference's data/JacobiGQ.bin row" if nodes is not None else "computed Gauss nodes",
+                       "multi_gpu": mg, "env_knobs": knobs},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if phases is not None:
+            line["partitioned_stage_ms"] = phases
         print(json.dumps(line))
     if ex is not None:
         ex.close()
     case.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

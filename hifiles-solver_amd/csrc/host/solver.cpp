@@ -437,6 +437,8 @@ int MoveToDevice(solution *S, int device)
 void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
 {
   int i;
+  // the reference asks `nproc > 1`; a rank that is its own neighbour (self_partition) has partition faces on one rank
+  const bool mpi = FlowSol->nproc > 1 || FlowSol->n_mpi_inters > 0;
   auto each_ele = [&](void (eles::*m)()) {
     for (i = 0; i < FlowSol->n_ele_types; i++)
       if (FlowSol->mesh_eles(i)) (FlowSol->mesh_eles(i)->*m)();
@@ -444,7 +446,7 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   /*! Extrapolate the solution to the flux points. */
   each_ele(&eles::extrapolate_solution);
   /*! Send the solution at the flux points across the MPI interfaces. */
-  if (FlowSol->nproc > 1)
+  if (mpi)
     for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_solution();
   if (FlowSol->run_input.viscous)
     /*! Compute the uncorrected transformed gradient of the solution at the solution points. */
@@ -458,7 +460,7 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_invFlux();
   for (i = 0; i < FlowSol->n_bdy_inter_types; i++)
     FlowSol->mesh_bdy_inters(i).evaluate_boundaryConditions_invFlux(FlowSol, FlowSol->time);
-  if (FlowSol->nproc > 1)
+  if (mpi)
   {
     for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_solution();
     for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).calculate_common_invFlux();
@@ -468,7 +470,7 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
     /*! Compute physical corrected gradient of the solution at the solution and flux points. */
     each_ele(&eles::correct_gradient);
     /*! Send the corrected physical gradients across the MPI interface. */
-    if (FlowSol->nproc > 1)
+    if (mpi)
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_corrected_gradient();
     /*! Compute discontinuous transformed viscous flux at upts and add to total transformed flux. */
     each_ele(&eles::evaluate_viscFlux);
@@ -485,7 +487,7 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
     for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_viscFlux();
     for (i = 0; i < FlowSol->n_bdy_inter_types; i++) FlowSol->mesh_bdy_inters(i).evaluate_boundaryConditions_viscFlux(FlowSol->time);
     /*! Evaluate the MPI interfaces. */
-    if (FlowSol->nproc > 1)
+    if (mpi)
     {
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_corrected_gradient();
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).calculate_common_viscFlux();
@@ -606,6 +608,11 @@ int SetComm(solution *FlowSol, const char *unique_id)
 {
   if (!FlowSol->ctx) { FlowSol->err = "SetComm: the case is not on the device"; return 1; }
   if (FlowSol->comm) { hfx_comm_destroy(FlowSol->comm); FlowSol->comm = nullptr; }
+  if (!unique_id) // back to the caller's hooks
+  {
+    for (int j = 0; j < FlowSol->n_mpi_inter_types; j++) FlowSol->mesh_mpi_inters(j).set_comm(nullptr);
+    return 0;
+  }
   if (hfx_comm_create(FlowSol->ctx, unique_id, FlowSol->nproc, FlowSol->rank, &FlowSol->comm)) { FlowSol->err = hfx_last_error(); return 1; }
   for (int j = 0; j < FlowSol->n_mpi_inter_types; j++)
     if (FlowSol->mesh_mpi_inters(j).set_comm(FlowSol->comm)) { FlowSol->err = FlowSol->mesh_mpi_inters(j).last_error(); return 1; }

@@ -204,6 +204,9 @@ class Case:
 
     def set_comm(self, unique_id):
         """collective: libhfx's own RCCL transport; unique_id = bytes from hfx.comm_unique_id() on rank 0"""
+        if unique_id is None:  # back to the exchange / reduce hooks
+            check(lib().hfxh_case_set_comm(self.h, None))
+            return
         assert len(unique_id) == 128
         self._uid = C.create_string_buffer(bytes(unique_id), 128)
         check(lib().hfxh_case_set_comm(self.h, self._uid))

@@ -118,7 +118,7 @@ def test_gpu_partition_invariance_8_ranks(mode):
 @pytest.mark.parametrize("mode", ["methods", "fused", "fused2"])
 @pytest.mark.parametrize("n_local,kw", [
     ([3, 4, 3], dict(riemann_solve_type=3, self_partition=[1, 0, 1])),
-    ([4, 2, 3], dict(riemann_solve_type=0, order=3, self_partition=[0, 1, 0])),
+    ([4, 3, 3], dict(riemann_solve_type=0, order=3, self_partition=[0, 1, 0])),
 ])
 def test_gpu_rccl_transport_self_partition(tmp_path, mode, n_local, kw):
     """libhfx's own transport (hfx_comm_*: grouped ncclSend / ncclRecv on the library's communication stream, ordered
