@@ -1,36 +1,19 @@
-// fused_hex.hip -- fused per-stage kernels for tensor-product elements (hexes, quads).
+// fused_hex.hip -- the split fused stage for tensor-product elements (hexes, quads).
 //
 // One RK stage = the 17 calls of CalcResidual + AdvanceSolution
 // (/root/reference/src/solver.cpp:50-223, src/HiFiLES.cpp:201-217).  Executed call by
-// call they stream ~64 000 doubles per P4 hex through HBM.  Here a stage is
-// TWO persistent kernels that keep everything element-local in LDS / registers and touch
-// HBM only for what must cross a kernel boundary:
+// call they stream ~64 000 doubles per P4 hex through HBM.  Here the stage is cut at the two
+// places where data must cross elements (the LDG common solution, the common fluxes) and everything element-local
+// between two cuts is one kernel: four launches per stage.  Two variants:
+//   fused = 2: keeps the reference's arrays (grad_disu_upts / grad_disu_fpts in HBM); carries the LES closure
+//   fused = 3: the kernel that has the corrected gradient in registers goes straight on to the fluxes; the default
+// plus the same stage cut into five phases for a partitioned block (hfx_stage_partitioned).
 //
-//   gradient kernel  : u -> own + neighbour disu_fpts -> LDG common solution (delta) ->
-//                      corrected gradient at upts (written) and at fpts (written: the
-//                      neighbours need it)                       [steps 1,3,5(LDG),8]
-//   residual kernel  : u, grad -> inviscid + viscous flux at upts -> divergence and
-//                      normal flux at fpts; Riemann + LDG common fluxes from own and
-//                      neighbour fpt data; correction; RK update; disu_fpts of the NEW
-//                      state (double-buffered)                    [steps 4,10-13,16,17,1']
-//
-// Face coupling is GATHER style: every flux point reads its partner's data through a
-// per-point neighbour index and evaluates the common flux itself, in the reference's
-// left/right argument order with the LEFT normal, so both sides compute bit-identical
-// numbers and nothing is scattered (no atomics, no norm_tconf / delta round trip).
-//
-// Work decomposition (64-wide wavefronts): a workgroup is WU "solution-point" waves
-// (one thread per upt) plus WF "flux-point" waves (one thread per fpt).  The two roles
-// overlap: while the upt waves evaluate fluxes, the fpt waves have their partner gathers
-// in flight.  The element state is double-buffered in LDS so that the next element's
-// loads are issued a full iteration ahead.
-//
-// Operator rows are held in DICTIONARY-COMPRESSED sparse form: a tensor-product operator
-// has only a handful of distinct values (entries of the 1-D matrices), so a row entry is
-// 16 bits (value id, column), two per 32-bit register, and the values sit in a 2 kB LDS
-// table.  A thread keeps the rows of its role in ~12 registers for the whole persistent
-// loop instead of ~100.  The arithmetic is unchanged: the same non-zeros, multiplied in
-// the same ascending-column order as the reference dgemm (src/funcs.cpp:110-117).
+// Operator rows of the element kernels are either sum-factorised (1-D matrices through scalar registers, when the
+// registered operators are bit-exactly tensor products) or DICTIONARY-COMPRESSED sparse rows: a tensor-product
+// operator has only a handful of distinct values, so a row entry is 16 bits (value id, column), two per 32-bit
+// register, the values in a 2 kB LDS table.  The arithmetic is unchanged: the same non-zeros, multiplied in the same
+// ascending-column order as the reference dgemm (src/funcs.cpp:110-117).
 #include "fused_hex.hpp"
 #include "tensor_ops.hpp"
 
@@ -45,29 +28,14 @@ namespace hfx
 
 constexpr int MAX_TAB = 256;
 
-// minimum waves per SIMD the fused kernels are compiled for (second __launch_bounds__ argument):
-// bounds the register allocation; the kernels are latency-bound at low occupancy
-#ifndef HFX_FUSED_WAVES
-#define HFX_FUSED_WAVES 2
-#endif
-// Diagnostic ablation mask (0 in the product build): bit0 A-role Riemann, bit1 B-role viscous
-// fluxes, bit2 U-role fluxes, bit3 operator dot products, bit4 partner gathers are replaced by
-// trivial stand-ins so that their share of a kernel's time can be measured (results are wrong).
+// minimum waves per SIMD the residual kernel of fused = 2 is compiled for (second __launch_bounds__ argument)
 #ifndef HFX_SPLIT_WAVES_RES
 #define HFX_SPLIT_WAVES_RES 4
-#endif
-#ifndef HFX_ABLATE
-#define HFX_ABLATE 0
-#endif
-#ifndef HFX_FUSED_WAVES_RES
-#define HFX_FUSED_WAVES_RES 2
 #endif
 
 struct FusedData
 {
-  int *nbr = nullptr;            // (n_fpts, n_eles) partner offset in the (fpt,ele) plane
-  unsigned char *meta = nullptr; // bit0: this point is the RIGHT side, bit1: beta sign flipped
-  double *fnorm = nullptr;       // (n_fpts, n_eles, n_dims) the LEFT element's unit normal of the pair
+  unsigned char *meta = nullptr; // bit0: this point is the RIGHT side, bit1: beta sign flipped, bit2: boundary point
   double *disu_alt = nullptr;    // second disu_fpts buffer
   double *fn_fpts = nullptr;     // split variant 3: projected viscous flux per flux point (n_fpts,n_eles,n_fields)
   // tensor-product tables of the sum-factorised flux kernel (valid when tensor_ok)
@@ -79,7 +47,6 @@ struct FusedData
   double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)
   int *o1m_dim = nullptr;                    // (n_fpts) dimension slab of the merged opp_1 row
   bool built = false;
-  int grid = 0;
 };
 
 void fused_invalidate(hfx_eles *e)
@@ -91,33 +58,12 @@ void fused_destroy(hfx_eles *e)
 {
   if (!e || !e->fused) return;
   FusedData *f = e->fused;
-  void *p[] = {f->nbr, f->meta, f->fnorm, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
+  void *p[] = {f->meta, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete f;
   e->fused = nullptr;
 }
-
-struct FusedArgs
-{
-  int n_eles;
-  const unsigned *pk; // packed operator rows of this kernel
-  const double *tab;  // value table (MAX_TAB)
-  const int *o1m_dim;
-  const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts, *tdA_fpts, *fnorm;
-  const int *nbr;
-  const unsigned char *meta;
-  double *u0, *u1;
-  const double *disu_cur; // disu_fpts of the current state (read)
-  double *disu_next;      // disu_fpts of the new state (written by the residual kernel)
-  double *grad_upts, *grad_fpts, *div_out;
-  const double *src, *dt_local;
-  unsigned long long *nan_flag;
-  Phys P;
-  // time stepping
-  int adv_type, in_step, dt_local_on, write_div, need_u1;
-  double dt, rk_a, rk_b;
-};
 
 constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
 constexpr int words_of(int w) { return (w + 1) / 2; }
@@ -159,7 +105,6 @@ struct Geo
 template <int W, int OFF, int PW>
 __device__ __forceinline__ double row_dot(const unsigned (&w)[PW], const double *tab, const double *data, double acc)
 {
-  if (HFX_ABLATE & 8) return acc + tab[w[OFF] & 0xffu] * data[0];
 #pragma unroll
   for (int i = 0; i < words_of(W); i++)
   {
@@ -202,609 +147,6 @@ __device__ __forceinline__ void to_physical(const double inv_detjac, const doubl
     const double temp = inv_detjac * tg[l];
 #pragma unroll
     for (int d = 0; d < ND; d++) cg[d] += temp * JG[l + ND * d];
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// gradient kernel
-// ---------------------------------------------------------------------------------------
-template <int ND, int N>
-__global__ __launch_bounds__((Geo<ND, N>::TB), HFX_FUSED_WAVES) void fused_gradient_kernel(const FusedArgs a)
-{
-  using G = Geo<ND, N>;
-  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TU = G::TU, UNP = G::UNP, WN = G::WN;
-  constexpr int PW = cmax(G::G_WU, G::G_WF);
-  __shared__ double tab[MAX_TAB];
-  __shared__ double su[2][NF][NU];
-  __shared__ double sd[NF][NFP];
-  __shared__ double sg[NF * ND][NU];
-  const int tid = threadIdx.x;
-  const bool role_u = tid < TU;
-  const int tu = tid, tf = tid - TU;
-  const bool act = role_u ? (tu < NU) : (tf < NFP);
-  const long ne = a.n_eles;
-  const long plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
-  const long stride = gridDim.x;
-
-  for (int q = tid; q < MAX_TAB; q += G::TB) tab[q] = a.tab[q];
-
-  // the operator rows of this thread's role: upt [opp_4[0..ND) | opp_5[0..ND)], fpt [opp_0 | opp_6]
-  unsigned pw[PW];
-#pragma unroll
-  for (int i = 0; i < PW; i++) pw[i] = 0;
-  if (act)
-  {
-    if (role_u)
-    {
-#pragma unroll
-      for (int d = 0; d < ND; d++)
-      {
-#pragma unroll
-        for (int i = 0; i < WN; i++) pw[d * WN + i] = a.pk[G::G_O4 + (d * WN + i) * NU + tu];
-        pw[ND * WN + d] = a.pk[G::G_O5 + d * NU + tu];
-      }
-    }
-    else
-    {
-#pragma unroll
-      for (int i = 0; i < WN; i++)
-      {
-        pw[i] = a.pk[G::G_O0 + i * NFP + tf];
-        pw[WN + i] = a.pk[G::G_O6 + i * NFP + tf];
-      }
-    }
-  }
-
-  long e = blockIdx.x;
-  long nb = 0;
-  unsigned mt = 0;
-  if (e < ne)
-  {
-    if (role_u)
-    {
-      for (int q = tu; q < NF * NU; q += TU)
-      {
-        const int f = q / NU, p = q - f * NU;
-        su[0][f][p] = a.u0[p + NU * e + f * plane_u];
-      }
-    }
-    else if (act)
-    {
-      nb = a.nbr[tf + NFP * e];
-      mt = a.meta[tf + NFP * e];
-    }
-  }
-  __syncthreads();
-
-  int buf = 0;
-  for (; e < ne; e += stride, buf ^= 1)
-  {
-    const long en = e + stride;
-    const bool has_next = en < ne;
-    double un[UNP];
-    double g[NF][ND];
-    double JG[ND * ND], inv_detjac = 0.0;
-    // ---------------- P1
-    if (role_u)
-    {
-      if (has_next)
-      {
-#pragma unroll
-        for (int r = 0; r < UNP; r++)
-        {
-          const int q = tu + r * TU;
-          if (q < NF * NU)
-          {
-            const int f = q / NU, p = q - f * NU;
-            un[r] = a.u0[p + NU * en + f * plane_u];
-          }
-        }
-      }
-      if (act)
-      {
-        const long p = tu + NU * e;
-#pragma unroll
-        for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
-        inv_detjac = 1.0 / a.detjac_upts[p];
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          g[k][0] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
-          g[k][1] = row_dot<N, WN, PW>(pw, tab, &su[buf][k][0], 0.0);
-          if (ND == 3) g[k][ND - 1] = row_dot<N, (ND - 1) * WN, PW>(pw, tab, &su[buf][k][0], 0.0);
-        }
-      }
-    }
-    else if (act)
-    {
-      const long o = tf + NFP * e;
-      double oth[NF];
-#pragma unroll
-      for (int k = 0; k < NF; k++) oth[k] = a.disu_cur[nb + k * plane_f];
-#pragma unroll
-      for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_fpts[o * (ND * ND) + q];
-      inv_detjac = 1.0 / a.detjac_fpts[o];
-      const bool right = mt & 1;
-      const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        const double own = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
-        const double ul = right ? oth[k] : own, ur = right ? own : oth[k];
-        // u_c = 1/2 (u_l + u_r) - beta (u_l - u_r)   (src/inters.cpp:637)
-        const double uc = 0.5 * (ul + ur) - beta * (ul - ur);
-        sd[k][tf] = uc - own;
-      }
-    }
-    lds_barrier(); // B: sd ready
-
-    // ---------------- P2
-    long nb_next = 0;
-    unsigned mt_next = 0;
-    if (role_u)
-    {
-      if (act)
-      {
-        const long p = tu + NU * e;
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          double tg[ND], cg[ND];
-          tg[0] = row_dot<2, ND * WN + 0, PW>(pw, tab, &sd[k][0], g[k][0]);
-          tg[1] = row_dot<2, ND * WN + 1, PW>(pw, tab, &sd[k][0], g[k][1]);
-          if (ND == 3) tg[ND - 1] = row_dot<2, ND * WN + ND - 1, PW>(pw, tab, &sd[k][0], g[k][ND - 1]);
-#pragma unroll
-          for (int d = 0; d < ND; d++) sg[k + NF * d][tu] = tg[d]; // opp_6 acts on the reference-space gradient
-          to_physical<ND>(inv_detjac, JG, tg, cg);
-#pragma unroll
-          for (int d = 0; d < ND; d++) a.grad_upts[p + (k + NF * d) * plane_u] = cg[d];
-        }
-      }
-      if (has_next)
-      {
-#pragma unroll
-        for (int r = 0; r < UNP; r++)
-        {
-          const int q = tu + r * TU;
-          if (q < NF * NU)
-          {
-            const int f = q / NU, p = q - f * NU;
-            su[buf ^ 1][f][p] = un[r];
-          }
-        }
-      }
-    }
-    else if (act && has_next)
-    {
-      nb_next = a.nbr[tf + NFP * en];
-      mt_next = a.meta[tf + NFP * en];
-    }
-    lds_barrier(); // C: sg ready, su[buf^1] ready
-
-    // ---------------- P3
-    if (!role_u && act)
-    {
-      const long o = tf + NFP * e;
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        double tg[ND], cg[ND];
-#pragma unroll
-        for (int d = 0; d < ND; d++) tg[d] = row_dot<N, WN, PW>(pw, tab, &sg[k + NF * d][0], 0.0);
-        to_physical<ND>(inv_detjac, JG, tg, cg);
-#pragma unroll
-        for (int d = 0; d < ND; d++) a.grad_fpts[o + (k + NF * d) * plane_f] = cg[d];
-      }
-      nb = nb_next;
-      mt = mt_next;
-    }
-    // no barrier: the next iteration's first LDS writes (sd by the fpt waves, sg by the upt waves
-    // after its barrier B) are ordered behind this iteration's last reads by barriers B' / C
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// residual kernel
-//
-// Three roles: U (one thread per solution point), A and B (one thread per flux point each).
-// The flux-point physics is the long pole of a stage (Riemann flux + two viscous fluxes per
-// point), so it is split: A evaluates the inviscid common flux, B the LDG viscous common flux,
-// and U the volume fluxes -- three instruction streams of similar length that run concurrently
-// on the CU's four SIMDs.
-// ---------------------------------------------------------------------------------------
-template <int ND, int N, int RS>
-__global__ __launch_bounds__((Geo<ND, N>::TBR), HFX_FUSED_WAVES_RES) void fused_residual_kernel(const FusedArgs a)
-{
-  using G = Geo<ND, N>;
-  constexpr int NF = G::NF, NU = G::NU, NFP = G::NFP, TU = G::TU, UNP = G::UNP, WN = G::WN;
-  constexpr int TF = 64 * G::WF;
-  constexpr int N3 = 2 * ND;
-  constexpr int PW = cmax(G::R_WU, G::R_WF);
-  __shared__ double tab[MAX_TAB];
-  __shared__ double su[2][NF][NU];
-  __shared__ double st[NF * ND][NU];
-  __shared__ double sc[NF][NFP];
-  __shared__ double sv[NF][NFP];
-  const int tid = threadIdx.x;
-  const int role = tid < TU ? 0 : (tid < TU + TF ? 1 : 2); // 0 U, 1 A, 2 B
-  const int tu = tid, tf = (role == 1) ? tid - TU : tid - TU - TF;
-  const bool act = (role == 0) ? (tu < NU) : (tf < NFP);
-  const long ne = a.n_eles;
-  const long plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
-  const long stride = gridDim.x;
-  const bool viscous = a.P.viscous;
-
-  for (int q = tid; q < MAX_TAB; q += G::TBR) tab[q] = a.tab[q];
-
-  // U [opp_2[0..ND) | opp_3], A [opp_0 | merged opp_1], B [opp_0]
-  unsigned pw[PW];
-#pragma unroll
-  for (int i = 0; i < PW; i++) pw[i] = 0;
-  int d1 = 0;
-  if (act)
-  {
-    if (role == 0)
-    {
-#pragma unroll
-      for (int i = 0; i < ND * WN; i++) pw[i] = a.pk[G::R_O2 + i * NU + tu];
-#pragma unroll
-      for (int i = 0; i < words_of(N3); i++) pw[ND * WN + i] = a.pk[G::R_O3 + i * NU + tu];
-    }
-    else
-    {
-#pragma unroll
-      for (int i = 0; i < WN; i++)
-      {
-        pw[i] = a.pk[G::R_O0 + i * NFP + tf];
-        pw[WN + i] = a.pk[G::R_O1 + i * NFP + tf];
-      }
-      d1 = a.o1m_dim[tf];
-    }
-  }
-
-  long e = blockIdx.x;
-  long nb = 0;
-  unsigned mt = 0;
-  if (e < ne)
-  {
-    if (role == 0)
-    {
-      for (int q = tu; q < NF * NU; q += TU)
-      {
-        const int f = q / NU, p = q - f * NU;
-        su[0][f][p] = a.u0[p + NU * e + f * plane_u];
-      }
-    }
-    else if (act)
-    {
-      nb = a.nbr[tf + NFP * e];
-      mt = a.meta[tf + NFP * e];
-    }
-  }
-  __syncthreads();
-
-  int buf = 0;
-  for (; e < ne; e += stride, buf ^= 1)
-  {
-    const long en = e + stride;
-    const bool has_next = en < ne;
-    double un[UNP];
-    double div[NF], u1v[NF], dj = 1.0;
-    double finv[NF], sgn_tdA = 0.0;
-    // ---------------- P1
-    if (role == 0)
-    {
-      if (has_next)
-      {
-#pragma unroll
-        for (int r = 0; r < UNP; r++)
-        {
-          const int q = tu + r * TU;
-          if (q < NF * NU)
-          {
-            const int f = q / NU, p = q - f * NU;
-            un[r] = a.u0[p + NU * en + f * plane_u];
-          }
-        }
-      }
-      if (act)
-      {
-        const long p = tu + NU * e;
-        double u[NF], f[NF * ND], JG[ND * ND];
-#pragma unroll
-        for (int q = 0; q < ND * ND; q++) JG[q] = a.JGinv_upts[p * (ND * ND) + q];
-        dj = a.detjac_upts[p];
-        if (a.need_u1)
-        {
-#pragma unroll
-          for (int k = 0; k < NF; k++) u1v[k] = a.u1[p + k * plane_u];
-        }
-#pragma unroll
-        for (int k = 0; k < NF; k++) u[k] = su[buf][k][tu];
-        if (HFX_ABLATE & 4)
-        {
-#pragma unroll
-          for (int s = 0; s < NF * ND; s++) f[s] = u[s % NF] * a.P.gamma;
-        }
-        else
-          calc_invf<ND, true>(a.P.gamma, u, f);
-        if (!viscous)
-        {
-#pragma unroll
-          for (int k = 0; k < NF; k++)
-#pragma unroll
-            for (int l = 0; l < ND; l++)
-            {
-              double s = 0.0;
-#pragma unroll
-              for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-              st[k + NF * l][tu] = s;
-            }
-        }
-        else
-        {
-          double td[NF * ND];
-#pragma unroll
-          for (int k = 0; k < NF; k++)
-#pragma unroll
-            for (int l = 0; l < ND; l++)
-            {
-              double s = 0.0;
-#pragma unroll
-              for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-              td[k + NF * l] = s;
-            }
-          {
-            double gr[NF * ND];
-#pragma unroll
-            for (int q = 0; q < NF * ND; q++) gr[q] = a.grad_upts[p + q * plane_u];
-            if (HFX_ABLATE & 4)
-            {
-#pragma unroll
-              for (int s = 0; s < NF * ND; s++) f[s] = gr[s] * u[0];
-            }
-            else
-              calc_visf<ND, true>(a.P, u, gr, f);
-          }
-#pragma unroll
-          for (int k = 0; k < NF; k++)
-#pragma unroll
-            for (int l = 0; l < ND; l++)
-            {
-              double s = td[k + NF * l];
-#pragma unroll
-              for (int m = 0; m < ND; m++) s += JG[l + ND * m] * f[k + NF * m];
-              st[k + NF * l][tu] = s;
-            }
-        }
-      }
-    }
-    else if (act)
-    {
-      const long o = tf + NFP * e;
-      const bool right = mt & 1;
-      double oth[NF], n[ND];
-#pragma unroll
-      for (int k = 0; k < NF; k++) oth[k] = (HFX_ABLATE & 16) ? su[buf][k][tf % NU] : a.disu_cur[nb + k * plane_f];
-#pragma unroll
-      for (int m = 0; m < ND; m++) n[m] = a.fnorm[o + m * plane_f];
-      if (role == 1)
-      {
-        // ---- A: inviscid common flux (src/int_inters.cpp:160-249)
-        const double tdA = a.tdA_fpts[o];
-        sgn_tdA = right ? -tdA : tdA;
-        double ul[NF], ur[NF];
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          const double own = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
-          ul[k] = right ? oth[k] : own;
-          ur[k] = right ? own : oth[k];
-        }
-        if (HFX_ABLATE & 1)
-        {
-#pragma unroll
-          for (int k = 0; k < NF; k++) finv[k] = (ul[k] - ur[k]) * n[0];
-        }
-        else
-          riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, finv);
-      }
-      else if (viscous)
-      {
-        // ---- B: LDG viscous common flux (src/int_inters.cpp:254-343, src/inters.cpp:561-611)
-        // the left state's gradient lives on this point when it is the LEFT side, on the partner otherwise
-        const long ol = right ? nb : o, orr = right ? o : nb;
-        const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
-        double gq[NF * ND];
-#pragma unroll
-        for (int s = 0; s < NF * ND; s++) gq[s] = (HFX_ABLATE & 16) ? su[buf][s % NF][tf % NU] : a.grad_fpts[ol + s * plane_f];
-        double ul[NF], ur[NF];
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          const double own = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
-          ul[k] = right ? oth[k] : own;
-          ur[k] = right ? own : oth[k];
-        }
-        // fn_v = sum_l [(1/2+beta) F_l + (1/2-beta) F_r](k,l) n_l - tau (u_r - u_l).  The left
-        // contribution is projected on the normal before the right flux is evaluated, so that only
-        // NF values stay live across the second evaluation (re-associates the two-side sum).
-        double pl[NF];
-        {
-          double fq[NF * ND];
-          if (HFX_ABLATE & 2)
-          {
-#pragma unroll
-            for (int s = 0; s < NF * ND; s++) fq[s] = gq[s] * ul[0];
-          }
-          else
-            calc_visf<ND, true>(a.P, ul, gq, fq);
-#pragma unroll
-          for (int s = 0; s < NF * ND; s++) gq[s] = (HFX_ABLATE & 16) ? st[s][tf % NU] : a.grad_fpts[orr + s * plane_f];
-#pragma unroll
-          for (int k = 0; k < NF; k++)
-          {
-            double s = 0.0;
-#pragma unroll
-            for (int l = 0; l < ND; l++) s += ((0.5 + beta) * fq[k + NF * l]) * n[l];
-            pl[k] = s;
-          }
-        }
-        {
-          double fq[NF * ND];
-          if (HFX_ABLATE & 2)
-          {
-#pragma unroll
-            for (int s = 0; s < NF * ND; s++) fq[s] = gq[s] * ur[0];
-          }
-          else
-            calc_visf<ND, true>(a.P, ur, gq, fq);
-#pragma unroll
-          for (int k = 0; k < NF; k++)
-          {
-            double s = 0.0;
-#pragma unroll
-            for (int l = 0; l < ND; l++) s += ((0.5 - beta) * fq[k + NF * l]) * n[l];
-            double fv = pl[k] + s;
-            fv -= a.P.ldg_tau * (ur[k] - ul[k]);
-            sv[k][tf] = fv;
-          }
-        }
-      }
-    }
-    lds_barrier(); // B: st, sv ready
-
-    // ---------------- P2
-    long nb_next = 0;
-    unsigned mt_next = 0;
-    if (role == 0)
-    {
-      if (act)
-      {
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          double s = row_dot<N, 0, PW>(pw, tab, &st[k][0], 0.0);
-          s = row_dot<N, WN, PW>(pw, tab, &st[k + NF][0], s);
-          if (ND == 3) s = row_dot<N, (ND - 1) * WN, PW>(pw, tab, &st[k + NF * (ND - 1)][0], s);
-          div[k] = s;
-        }
-      }
-      if (has_next)
-      {
-#pragma unroll
-        for (int r = 0; r < UNP; r++)
-        {
-          const int q = tu + r * TU;
-          if (q < NF * NU)
-          {
-            const int f = q / NU, p = q - f * NU;
-            su[buf ^ 1][f][p] = un[r];
-          }
-        }
-      }
-    }
-    else if (role == 1)
-    {
-      if (act)
-      {
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          const double ntd = row_dot<N, WN, PW>(pw, tab, &st[k + NF * d1][0], 0.0);
-          double tconf = finv[k] * sgn_tdA;                // norm_tconf  = fn * tdA      (int_inters.cpp:217)
-          if (viscous) tconf += sv[k][tf] * sgn_tdA;       // norm_tconf += fn_v * tdA    (int_inters.cpp:329)
-          sc[k][tf] = tconf + -1.0 * ntd;                  // norm_tconf -= norm_tdisf    (eles.cpp:1746)
-        }
-      }
-    }
-    else if (act && has_next)
-    {
-      nb_next = a.nbr[tf + NFP * en];
-      mt_next = a.meta[tf + NFP * en];
-    }
-    lds_barrier(); // C: sc ready, su[buf^1] ready
-
-    // ---------------- P3
-    if (role == 0)
-    {
-      if (act)
-      {
-        const long p = tu + NU * e;
-        const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          const double dv = row_dot<N3, ND * WN, PW>(pw, tab, &sc[k][0], div[k]);
-          const long q = p + k * plane_u;
-          if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)q);
-          if (a.write_div) a.div_out[q] = dv;
-          const double s = a.src ? a.src[q] : 0.0;
-          const double dd = dv / dj;
-          double u = su[buf][k][tu];
-          if (a.adv_type == 0)
-            u -= dt * (dd - s);
-          else if (a.adv_type == 1)
-          {
-            if (a.in_step == 0) a.u1[q] = u;
-            if (a.in_step < 3)
-              u -= dt / 3.0 * (dd - s);
-            else
-            {
-              const double rhs = -dd + s;
-              u = 3.0 / 4.0 * u + 1.0 / 4.0 * u1v[k] + dt / 4.0 * rhs;
-            }
-          }
-          else if (a.adv_type == 2)
-          {
-            if (a.in_step == 0) a.u1[q] = u;
-            if (a.in_step < 2 || a.in_step == 3)
-              u -= dt / 2.0 * (dd - s);
-            else if (a.in_step == 2)
-            {
-              const double rhs = -dd + s;
-              u = 1.0 / 3.0 * u + 2.0 / 3.0 * u1v[k] + dt / 6.0 * rhs;
-            }
-          }
-          else
-          {
-            const double rhs = -dd + s;
-            const double r1 = a.rk_a * u1v[k] + dt * rhs;
-            a.u1[q] = r1;
-            u += a.rk_b * r1;
-          }
-          a.u0[q] = u;
-          su[buf][k][tu] = u; // own point only; the flux-point waves read it after barrier D
-        }
-      }
-    }
-    else if (role == 1 && act && has_next)
-    {
-      nb_next = a.nbr[tf + NFP * en];
-      mt_next = a.meta[tf + NFP * en];
-    }
-    lds_barrier(); // D: su[buf] holds the new state
-
-    // ---------------- P4: disu_fpts of the NEW state into the other buffer (partners still read the
-    // old one); A and B share the fields
-    if (role != 0 && act)
-    {
-      const long o = tf + NFP * e;
-      constexpr int KH = (NF + 1) / 2;
-      if (role == 1)
-      {
-#pragma unroll
-        for (int k = 0; k < KH; k++) a.disu_next[o + k * plane_f] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
-      }
-      else
-      {
-#pragma unroll
-        for (int k = KH; k < NF; k++) a.disu_next[o + k * plane_f] = row_dot<N, 0, PW>(pw, tab, &su[buf][k][0], 0.0);
-      }
-      nb = nb_next;
-      mt = mt_next;
-    }
-    // no barrier: su[buf] is next written in P2 of the following iteration, behind its barrier B
   }
 }
 
@@ -1141,11 +483,10 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
   }
 
   const long plane_f = (long)e->n_fpts * e->n_eles;
-  std::vector<int> nbr(plane_f, -1);
+  std::vector<char> paired(plane_f, 0);
   std::vector<unsigned char> meta(plane_f, 0);
-  std::vector<double> norm((size_t)plane_f * nd), fnorm;
+  std::vector<double> norm((size_t)plane_f * nd);
   HFX_HIP(hipMemcpy(norm.data(), e->norm_fpts, sizeof(double) * norm.size(), hipMemcpyDeviceToHost));
-  fnorm = norm;
   for (int b = 0; b < nfb; b++)
   {
     hfx_inters *f = faces[b];
@@ -1155,7 +496,7 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
       HFX_CHECK(f->left == e, "fused path: boundary block of another element block");
       for (size_t q = 0; q < f->hL.size(); q++)
       {
-        nbr[f->hL[q]] = f->hL[q];
+        paired[f->hL[q]] = 1;
         meta[f->hL[q]] |= 4;
       }
       continue;
@@ -1165,8 +506,7 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
     for (long q = 0; q < np; q++)
     {
       const int il = f->hL[q], ir = f->hR[q];
-      nbr[il] = ir;
-      nbr[ir] = il;
+      paired[il] = paired[ir] = 1;
       // the consistent switch of src/inters.cpp:568-581 on the LEFT normal (exact zero tests);
       // only the sign decision is stored
       const double n[3] = {norm[il], norm[il + plane_f], nd == 3 ? norm[il + 2 * plane_f] : 0.0};
@@ -1185,195 +525,17 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
       const unsigned char flip = (bt < 0) ? 2 : 0;
       meta[il] = flip;
       meta[ir] = flip | 1;
-      for (int d = 0; d < nd; d++) fnorm[ir + d * plane_f] = norm[il + d * plane_f];
     }
   }
   if (!allow_unpaired)
     for (long o = 0; o < plane_f; o++)
-      HFX_CHECK(nbr[o] >= 0, "fused path: flux point %ld has no partner (boundary faces are not fused; partition faces need "
-                             "hfx_stage_partitioned)", o);
-  if (upload((void **)&F->nbr, nbr.data(), sizeof(int) * plane_f)) return 1;
+      HFX_CHECK(paired[o], "fused path: flux point %ld belongs to no registered face (partition faces need "
+                           "hfx_stage_partitioned / hfx_run_steps_partitioned)", o);
   if (upload((void **)&F->meta, meta.data(), plane_f)) return 1;
-  if (upload((void **)&F->fnorm, fnorm.data(), sizeof(double) * plane_f * nd)) return 1;
   if (!F->disu_alt) HFX_HIP(hipMalloc((void **)&F->disu_alt, sizeof(double) * plane_f * e->n_fields));
-  F->grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * 4);
-  if (const char *g = getenv("HFX_FUSED_GRID_PER_CU"))
-    F->grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * std::max(1, atoi(g)));
   F->built = true;
   return 0;
 }
-
-static FusedArgs fused_args(hfx_eles *e)
-{
-  FusedArgs a{};
-  FusedData *F = e->fused;
-  a.n_eles = e->n_eles;
-  a.o1m_dim = F->o1m_dim;
-  a.detjac_upts = e->detjac_upts; a.JGinv_upts = e->JGinv_upts;
-  a.detjac_fpts = e->detjac_fpts; a.JGinv_fpts = e->JGinv_fpts;
-  a.tdA_fpts = e->tdA_fpts; a.fnorm = F->fnorm; a.nbr = F->nbr; a.meta = F->meta;
-  a.u0 = e->arr[HFX_DISU_UPTS0]; a.u1 = e->arr[HFX_DISU_UPTS1];
-  a.disu_cur = e->arr[HFX_DISU_FPTS]; a.disu_next = F->disu_alt;
-  a.grad_upts = e->arr[HFX_GRAD_DISU_UPTS]; a.grad_fpts = e->arr[HFX_GRAD_DISU_FPTS];
-  a.div_out = e->arr[HFX_DIV_TCONF_UPTS];
-  a.src = e->src_nonzero ? e->arr[HFX_SRC_UPTS] : nullptr;
-  a.dt_local = e->arr[HFX_DT_LOCAL];
-  a.nan_flag = e->nan_flag;
-  a.P = e->ctx->phys();
-  a.adv_type = e->ctx->params.adv_type;
-  a.dt_local_on = e->ctx->params.dt_type == 2;
-  a.dt = e->ctx->params.dt;
-  return a;
-}
-
-template <int ND, int N>
-static int launch_stage(hfx_eles *e, FusedArgs &a, bool do_grad, bool do_res)
-{
-  const int grid = e->fused->grid;
-  FusedData *F = e->fused;
-  if (do_grad)
-  {
-    a.pk = F->pk_g;
-    a.tab = F->tab_g;
-    hipLaunchKernelGGL((fused_gradient_kernel<ND, N>), dim3(grid), dim3(Geo<ND, N>::TB), 0, e->ctx->stream, a);
-  }
-  if (do_res)
-  {
-    a.pk = F->pk_r;
-    a.tab = F->tab_r;
-    const int rs = a.P.riemann;
-    if (rs == 0)
-      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 0>), dim3(grid), dim3(Geo<ND, N>::TBR), 0, e->ctx->stream, a);
-    else if (rs == 2)
-      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 2>), dim3(grid), dim3(Geo<ND, N>::TBR), 0, e->ctx->stream, a);
-    else
-      hipLaunchKernelGGL((fused_residual_kernel<ND, N, 3>), dim3(grid), dim3(Geo<ND, N>::TBR), 0, e->ctx->stream, a);
-  }
-  HFX_HIP(hipGetLastError());
-  return 0;
-}
-
-static int dispatch_stage(hfx_eles *e, FusedArgs &a, bool do_grad, bool do_res)
-{
-  const int N = tensor_n(e);
-  if (e->n_dims == 3)
-  {
-    switch (N)
-    {
-    case 2: return launch_stage<3, 2>(e, a, do_grad, do_res);
-    case 3: return launch_stage<3, 3>(e, a, do_grad, do_res);
-    case 4: return launch_stage<3, 4>(e, a, do_grad, do_res);
-    case 5: return launch_stage<3, 5>(e, a, do_grad, do_res);
-    case 6: return launch_stage<3, 6>(e, a, do_grad, do_res);
-    }
-  }
-  else
-  {
-    switch (N)
-    {
-    case 2: return launch_stage<2, 2>(e, a, do_grad, do_res);
-    case 3: return launch_stage<2, 3>(e, a, do_grad, do_res);
-    case 4: return launch_stage<2, 4>(e, a, do_grad, do_res);
-    case 5: return launch_stage<2, 5>(e, a, do_grad, do_res);
-    case 6: return launch_stage<2, 6>(e, a, do_grad, do_res);
-    }
-  }
-  set_error("fused path: no kernel for N = %d, n_dims = %d", N, e->n_dims);
-  return 1;
-}
-
-// one RK stage; which != 0 restricts to the gradient (1) or residual (2) kernel (for timing)
-static int fused_stage(hfx_eles *e, int in_step, bool last_stage, int which = 0)
-{
-  FusedArgs a = fused_args(e);
-  const hfx_params &p = e->ctx->params;
-  a.in_step = in_step;
-  a.rk_a = (p.adv_type >= 3) ? p.RK_a[in_step] : 0.0;
-  a.rk_b = (p.adv_type >= 3) ? p.RK_b[in_step] : 0.0;
-  a.need_u1 = (p.adv_type >= 3) || (p.adv_type == 1 && in_step == 3) || (p.adv_type == 2 && in_step == 2);
-  a.write_div = last_stage ? 1 : 0; // the monitors read the divergence of a step's last stage
-  const bool do_grad = p.viscous && which != 2, do_res = which != 1;
-  if (dispatch_stage(e, a, do_grad, do_res)) return 1;
-  if (do_res)
-  {
-    // the new state's disu_fpts is in the other buffer now
-    std::swap(e->arr[HFX_DISU_FPTS], e->fused->disu_alt);
-  }
-  return 0;
-}
-
-int fused_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps)
-{
-  HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
-  for (int b = 0; b < nfb; b++)
-    HFX_CHECK(!faces[b]->is_bdy, "the gather-style fused path (fused=1) has no boundary faces: use fused=2 or 3");
-  HFX_CHECK(!e->shock_ready, "the gather-style fused path (fused=1) has no shock capturing: use fused=2 or 3");
-  HFX_CHECK(!e->over_int_ready, "the gather-style fused path (fused=1) has no over-integration: use fused=3");
-  HFX_CHECK(!e->les_ready, "the gather-style fused path (fused=1) has no LES closure: use fused=2");
-  if (!e->fused || !e->fused->built)
-    if (fused_build(e, faces, nfb)) return 1;
-  if (n_steps <= 0) return 0;
-  const int adv = e->ctx->params.adv_type;
-  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
-  // disu_fpts of the current state (the caller may have changed disu_upts since the last call)
-  if (hfx_eles_extrapolate_solution(e)) return 1;
-  for (int s = 0; s < n_steps; s++)
-  {
-    if (calc_time_step(e, nullptr)) return 1; /* src/HiFiLES.cpp:198 */
-    for (int rk = 0; rk < nst; rk++)
-      if (fused_stage(e, rk, rk == nst - 1)) return 1;
-  }
-  return 0;
-}
-
-int fused_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double *ms, char *names, int names_len)
-{
-  if (!e->fused || !e->fused->built)
-    if (fused_build(e, faces, nfb)) return 1;
-  const int adv = e->ctx->params.adv_type;
-  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
-  hipStream_t st = e->ctx->stream;
-  hipEvent_t ev[3];
-  for (auto &x : ev) HFX_HIP(hipEventCreate(&x));
-  if (hfx_eles_extrapolate_solution(e)) return 1;
-  double acc[2] = {0, 0};
-  for (int r = 0; r < reps; r++)
-  {
-    const int rk = r % nst;
-    HFX_HIP(hipEventRecord(ev[0], st));
-    if (e->ctx->params.viscous && fused_stage(e, rk, false, 1)) return 1;
-    HFX_HIP(hipEventRecord(ev[1], st));
-    if (fused_stage(e, rk, rk == nst - 1, 2)) return 1;
-    HFX_HIP(hipEventRecord(ev[2], st));
-    HFX_HIP(hipStreamSynchronize(st));
-    float t0 = 0, t1 = 0;
-    HFX_HIP(hipEventElapsedTime(&t0, ev[0], ev[1]));
-    HFX_HIP(hipEventElapsedTime(&t1, ev[1], ev[2]));
-    acc[0] += t0;
-    acc[1] += t1;
-  }
-  for (auto &x : ev) (void)hipEventDestroy(x);
-  for (int i = 0; i < 8; i++) ms[i] = 0.0;
-  ms[0] = acc[0] / reps;
-  ms[1] = acc[1] / reps;
-  snprintf(names, names_len, "fused_gradient_kernel,fused_residual_kernel");
-  return 0;
-}
-
-void fused_kernel_bytes(const hfx_eles *e, double *bytes)
-{
-  // ALGORITHMIC HBM bytes per launch of the two kernels (DESIGN.md "fused path"): what each kernel
-  // must read / write given that gradients and flux-point data cross a kernel boundary; the
-  // grad_disu_upts round trip between the two kernels is an implementation choice and not counted.
-  const double nu = e->n_upts, nfp = e->n_fpts, nf = e->n_fields, nd = e->n_dims, ne = e->n_eles;
-  const double grad = nu * nf + nu * (nd * nd + 1) + nfp * nf /*partner disu*/ + nfp * (nd * nd + 1) + nfp * nf * nd /*write*/;
-  const double res = nu * nf + nu * (nd * nd + 1) + nfp * nf + 2 * nfp * nf * nd + nfp * (nd + 1) + 3 * nu * nf /*u1 r, u0 u1 w*/ +
-                     nfp * nf /*new disu*/;
-  for (int i = 0; i < 8; i++) bytes[i] = 0.0;
-  bytes[0] = 8.0 * grad * ne;
-  bytes[1] = 8.0 * res * ne;
-}
-
 
 // =======================================================================================
 // SPLIT fused path (mode 2): four launches per stage, every one a simple high-occupancy kernel
@@ -3027,8 +2189,10 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
       // (the largest array the launch really touches: the metric tensors at the flux points, and the n_fields * n_dims
       // component arrays only when they are in use -- gradients at boundary points, the de-aliased flux)
-      double most = (double)plane_f * std::max(e->n_dims * e->n_dims, e->n_fields);
-      if (e2.grad_fpts || e2.grad_upts) most = std::max(most, (double)plane_f * e->n_fields * e->n_dims);
+      // -- over BOTH point sets: quads with N >= 5 have more solution points than flux points
+      const double plane_most = (double)std::max<long>(plane_f, (long)e->n_upts * e->n_eles);
+      double most = plane_most * std::max(e->n_dims * e->n_dims, e->n_fields);
+      if (e2.grad_fpts || e2.grad_upts) most = std::max(most, plane_most * e->n_fields * e->n_dims);
       if (e->over_int_ready) most = std::max(most, (double)e->n_upts * e->n_eles * e->n_fields * e->n_dims);
       const bool buf = !nobuf && most * 8.0 < 4294967296.0;
       const bool oi = e2.tdisf_in != nullptr;
@@ -3115,7 +2279,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     {
       // buffer-descriptor addressing needs 32-bit byte offsets
       static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
-      const bool small = (double)plane_f * e->n_fields * 8.0 < 4294967296.0;
+      const bool small = (double)std::max<long>(plane_f, (long)e->n_upts * e->n_eles) * e->n_fields * 8.0 < 4294967296.0;
       if (small && !nobuf)
         hipLaunchKernelGGL((split_update_kernel<ND, N, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
       else

@@ -349,7 +349,7 @@ int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode)
 int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode)
 {
   HFX_CHECK(ctx, "NULL ctx");
-  HFX_CHECK(mode >= 1 && mode <= 3, "hfx_ctx_set_fused_mode: mode must be 1 (gather), 2 (split) or 3 (split, flux in the gradient kernel)");
+  HFX_CHECK(mode == 2 || mode == 3, "hfx_ctx_set_fused_mode: mode must be 2 (split, the reference's arrays kept) or 3 (split, fluxes in the gradient kernel)");
   ctx->fused_mode = mode;
   return 0;
 }
@@ -1365,8 +1365,9 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, i
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   const int adv = e->ctx->params.adv_type;
   const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14; /* src/HiFiLES.cpp:143-150 */
-  if (fused == 2 || fused == 3) return split_run_steps(e, faces, nfb, n_steps, fused);
-  if (fused) return fused_run_steps(e, faces, nfb, n_steps);
+  HFX_CHECK(fused == 0 || fused == 2 || fused == 3, "hfx_run_steps: fused must be 0 (per-method), 2 or 3 (split fused stage); the gather-style "
+                                                    "variant 1 of earlier versions has been retired");
+  if (fused) return split_run_steps(e, faces, nfb, n_steps, fused);
   for (int s = 0; s < n_steps; s++)
   {
     if (calc_time_step(e, nullptr)) return 1; /* src/HiFiLES.cpp:198 */
@@ -1438,17 +1439,13 @@ int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int r
 {
   HFX_CHECK(e && ms && names && reps > 0, "hfx_time_fused_kernels: bad argument");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
-  if (e->ctx->fused_mode >= 2) return split_time_kernels(e, faces, nfb, reps, ms, names, 256, e->ctx->fused_mode);
-  return fused_time_kernels(e, faces, nfb, reps, ms, names, 256);
+  return split_time_kernels(e, faces, nfb, reps, ms, names, 256, e->ctx->fused_mode);
 }
 
 int hfx_fused_kernel_bytes(hfx_eles *e, double bytes[8])
 {
   HFX_CHECK(e && bytes, "hfx_fused_kernel_bytes: bad argument");
-  if (e->ctx->fused_mode >= 2)
-    split_kernel_bytes(e, bytes, e->ctx->fused_mode);
-  else
-    fused_kernel_bytes(e, bytes);
+  split_kernel_bytes(e, bytes, e->ctx->fused_mode);
   return 0;
 }
 

@@ -66,7 +66,7 @@ struct hfx_ctx
   hfx_params params{};
   bool have_params = false;
   int contract_mode = HFX_CONTRACT_AUTO;
-  int fused_mode = 1; // which fused variant hfx_time_fused_kernels / hfx_fused_kernel_bytes describe
+  int fused_mode = 3; // which split variant hfx_time_fused_kernels / hfx_fused_kernel_bytes / hfx_stage_partitioned use (2 or 3)
   int n_cu = 256;
   double CFL = 0.0; // run_input.CFL (hfx_ctx_set_CFL); dt_type 1 / 2 only
   bool have_CFL = false;

@@ -313,6 +313,9 @@ class BdyInters:
         if ramp_counter:
             check(lib().hfx_bdy_inters_set_ramp_counter(self.h, C.c_int(ramp_counter)))
 
+    def set_ramp_counter(self, ramp_counter):
+        check(lib().hfx_bdy_inters_set_ramp_counter(self.h, C.c_int(ramp_counter)))
+
     def evaluate_boundaryConditions_invFlux(self, time=0.0):
         check(lib().hfx_bdy_inters_evaluate_boundaryConditions_invFlux(self.h, C.c_double(time)))
 

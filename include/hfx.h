@@ -107,8 +107,9 @@ int hfx_ctx_create(int device, hfx_ctx **out);
 int hfx_ctx_destroy(hfx_ctx *ctx);
 int hfx_ctx_set_params(hfx_ctx *ctx, const hfx_params *p);
 int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode);
-/* which fused variant the measurement entry points describe: 1 gather-style (two kernels per stage),
- * 2 split (pairwise face kernels + element kernels, four launches per stage) */
+/* which variant of the split fused stage (pairwise face kernels + element kernels, four launches per stage) the
+ * measurement entry points describe and hfx_stage_partitioned / hfx_run_steps_partitioned run: 2 keeps the reference's
+ * gradient arrays in HBM, 3 (default) evaluates the fluxes in the gradient kernel */
 int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
 /* run_input.CFL for dt_type 1 / 2 (src/input.cpp:141-158): hfx_run_steps and hfx_run_steps_partitioned then start every
  * time step with calc_time_step (src/HiFiLES.cpp:198, src/solver.cpp:484-549) */
@@ -274,12 +275,13 @@ int hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(hfx_inters *f, double ti
  * face blocks (any mix, in `faces`), LES / RANS / forcing off; same call order as the reference. */
 int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
 /* n_steps time steps = the RK-stage loop of src/HiFiLES.cpp:194-217:
- * for each stage CalcResidual + AdvanceSolution.  `fused`: 0 the per-method path, 1 the gather-style
- * fused kernels, 2 the split fused kernels, 3 the split kernels with the fluxes evaluated in the
- * gradient kernel (same results to rounding).  All leave disu_upts(0), disu_upts(1), disu_fpts of the
- * new state and, for the step's last stage, div_tconf_upts in the public arrays; modes 1 and 2 also
- * leave grad_disu_upts / grad_disu_fpts of the last stage, mode 3 keeps them in registers (run one
- * per-method stage when a monitor needs them). */
+ * for each stage CalcResidual + AdvanceSolution.  `fused`: 0 the per-method path, 2 the split fused
+ * kernels, 3 the split kernels with the fluxes evaluated in the gradient kernel (same results to
+ * rounding).  All leave disu_upts(0), disu_upts(1), disu_fpts of the new state and, for the step's last
+ * stage, div_tconf_upts in the public arrays; mode 2 also leaves grad_disu_upts / grad_disu_fpts of the
+ * last stage, mode 3 keeps them in registers (run one per-method stage when a monitor needs them).
+ * With dt_type 1 / 2 every step starts with calc_time_step (hfx_ctx_set_CFL, hfx_eles_set_h_ref); boundary
+ * blocks whose groups ramp get run_input.ramp_counter advanced after every step (src/HiFiLES.cpp:224-225). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
 
 /* One RK stage of the split fused path on a PARTITIONED block, cut so that the caller can move the

@@ -174,6 +174,9 @@ CASES = [
          bcs={"y-": "WallT", "y+": "Far2", "x-": "InR", "x+": "Out"},
          bc_Far2_type="char", bc_Far2_p_static=P_TGV, bc_Far2_mach=0.12, bc_Far2_T_static=295.0, bc_Far2_nx=0.8, bc_Far2_ny=0.6,
          **BC_KEYS),
+    # a total-pressure ramp over several time steps: run_input.ramp_counter advances after every step (src/HiFiLES.cpp:224-225)
+    case("quad_p3_ramp", dims=2, n=4, amp=0.1, level=1, order=3, steps=3,
+         bcs={"y-": "WallT", "y+": "Slip", "x-": "InR", "x+": "Out"}, **BC_KEYS),
 ]
 
 

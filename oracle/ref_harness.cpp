@@ -516,6 +516,7 @@ int main(int argc, char *argv[])
     }
     FlowSol.time += run_input.dt;
     run_input.time = FlowSol.time;
+    if (run_input.pressure_ramp) run_input.ramp_counter++; /* src/HiFiLES.cpp:224-225 */
   }
   {
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();

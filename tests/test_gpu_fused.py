@@ -1,4 +1,4 @@
-"""The fused per-stage path (hfx_run_steps(..., fused=1)) against the genuine reference's fixtures,
+"""The split fused stage (hfx_run_steps(..., fused=2 | 3)) against the genuine reference's fixtures,
 against the per-method path, and through the full-size properties."""
 import ctypes as C
 import glob
@@ -22,10 +22,10 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("name", ALL)
 def test_fused_vs_reference(ctx, name, mode):
-    """mode 1: gather-style fused kernels, mode 2: split fused kernels, mode 3: split, fluxes in the gradient kernel"""
+    """mode 2: split fused kernels (the reference's arrays kept), mode 3: split, fluxes in the gradient kernel"""
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     e, faces = build(ctx, d)
     nstage = int(d["sizes"][7])
@@ -38,9 +38,8 @@ def test_fused_vs_reference(ctx, name, mode):
     # evaluated ahead of the flux kernel, which then takes it instead of computing the collocated one)
     over_int = "over_int" in d and int(np.ravel(d["over_int"])[0]) != 0
     # LES closures: mode 2 only (it keeps the corrected gradients in HBM, which the SGS flux is computed from)
-    if (over_int and mode != 3) or ("_les_" in name and mode != 2) or name.startswith(("tet_", "pri_")) or (
-            mode == 1 and ("bdy" in name or "shock" in name or "jet" in name)):
-        with pytest.raises(hfx.HfxError):  # the gather-style kernels have no boundary faces
+    if (over_int and mode != 3) or ("_les_" in name and mode != 2) or name.startswith(("tet_", "pri_")):
+        with pytest.raises(hfx.HfxError):
             hfx.run_steps(e, faces, 1, fused=mode)
         steps = []
     for st in steps:
@@ -52,7 +51,7 @@ def test_fused_vs_reference(ctx, name, mode):
     e.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [2, 3])
 def test_fused_public_arrays_after_a_step(ctx, mode):
     """What the fused paths leave in the public arrays: state, RK register, flux-point solution of the
     NEW state, corrected gradients and the divergence of the step's last stage (for the monitors)."""
@@ -84,14 +83,14 @@ def test_fused_nan_flag(ctx):
     u = np.array(d["u_init"], order="F")
     u[3, 5, 0] = np.nan
     e.upload(hfx.DISU_UPTS0, u)
-    hfx.run_steps(e, faces, 1, fused=True)
+    hfx.run_steps(e, faces, 1, fused=3)
     assert e.check_nan() >= 0
     for f in faces:
         f.close()
     e.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [2, 3])
 def test_fused_quads_vs_methods(mode):
     """2-D tensor-product elements (BASELINE.json configs[0]'s element type) through both paths."""
     a = H.Case([6, 5, 1], dims=2, order=3, amp=0.1)
@@ -126,7 +125,7 @@ def test_split_paths_every_order_vs_methods(dims, order):
         c.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [2, 3])
 def test_fused_full_size_conservation(mode):
     c = H.Case(32, order=4)
     u0 = c.array("disu_upts0")
@@ -149,7 +148,7 @@ def test_fused_full_size_conservation(mode):
     c.close(); m.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [2, 3])
 def test_fused_full_size_residual_norms_vs_reference_stdout(mode):
     """the reference's own iteration-1 row for the 32^3 P4 TGV case."""
     c = H.Case(32, order=4)
@@ -170,7 +169,9 @@ def test_fused_refuses_what_it_cannot_do(ctx):
     d = dict(np.load(os.path.join(GOLDEN, "hex_p1_rusanov.npz")))
     e, faces = build(ctx, d)
     with pytest.raises(hfx.HfxError):
-        hfx.run_steps(e, [], 1, fused=True)  # flux points without partner
+        hfx.run_steps(e, [], 1, fused=3)  # flux points without partner
+    with pytest.raises(hfx.HfxError):
+        hfx.run_steps(e, faces, 1, fused=1)  # the gather-style variant has been retired
     for f in faces:
         f.close()
     e.close()

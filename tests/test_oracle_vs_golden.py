@@ -79,6 +79,10 @@ def test_stage_states(oracle, name):
             key = "u_step%d_stage%d" % (st, rk)
             if key in d:
                 assert relerr(c.arr["u0"], d[key]) < RTOL, key
+        if "bc_flags" in d and d["bc_flags"][1].any():
+            # `if (run_input.pressure_ramp) run_input.ramp_counter++` after every time step (src/HiFiLES.cpp:224-225)
+            c.ramp_counter += 1
+            bd, nbd = c.c_bdy()
 
 
 def test_every_intermediate(oracle):
