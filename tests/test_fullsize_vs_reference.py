@@ -25,10 +25,13 @@ def norms(a):
     return np.stack([np.abs(a).sum(axis=(0, 1)), (a * a).sum(axis=(0, 1)), np.abs(a).max(axis=(0, 1))])
 
 
-def check_step(d, s, u, div, tol_u, tol_div):
-    """u, div: (n_upts, n_eles, n_fields) of the whole mesh after step s.  Two measures: the largest error on the scale
-    of the ARRAY (what every other parity test of this suite uses) against tol, and on the scale of each FIELD
-    separately -- stricter: the z momentum of this flow is 1e-4 of the other components -- against 10 tol."""
+def check_step(d, s, u, div, tol_u, tol_div, tol_norm=1e-10):
+    """u, div: (n_upts, n_eles, n_fields) of the whole mesh after step s.
+    State: the largest error on the scale of the ARRAY (what every other parity test of this suite uses) against tol_u,
+    and on the scale of each FIELD separately -- stricter: the z momentum of this flow is 1e-4 of the other components --
+    against 10 tol_u.  Residual div_tconf_upts: pointwise against tol_div (it is a difference of terms ~1e3 larger than
+    itself), and its per-field L1 / L2 norms -- the "conserved residuals" the reference's monitor prints and
+    BASELINE.json's 1e-10 bar is stated on -- against tol_norm."""
     sample = d["sample_eles"]
     for name, got, tol in (("u", u, tol_u), ("div", div, tol_div)):
         want = d["%s_sample_step%d" % (name, s)]
@@ -38,7 +41,8 @@ def check_step(d, s, u, div, tol_u, tol_div):
         assert per_field < 10 * tol, (name, s, per_field)
         wn = d["%s_norms_step%d" % (name, s)]
         gn = norms(got)
-        assert (np.abs(gn - wn) / np.abs(wn)).max() < 10 * tol, (name, s, "norms")
+        assert (np.abs(gn[:2] - wn[:2]) / np.abs(wn[:2])).max() < tol_norm, (name, s, "L1 / L2 norms")
+        assert (np.abs(gn[2] - wn[2]) / np.abs(wn[2])).max() < 10 * tol, (name, s, "Linf norm")
 
 
 def test_oracle_vs_reference_small():
@@ -72,7 +76,5 @@ def test_gpu_fullsize_vs_reference(fused):
         div = np.zeros(shape, order="F")
         hfx.check(hfx.lib().hfx_eles_download(e, C.c_int(hfx.DISU_UPTS0), u.ctypes.data_as(hfx.dp)))
         hfx.check(hfx.lib().hfx_eles_download(e, C.c_int(hfx.DIV_TCONF_UPTS), div.ctypes.data_as(hfx.dp)))
-        # 1e-11 on the state (BASELINE.json's bar is 1e-10 on conserved residuals); the divergence is a difference of
-        # terms ~1e3 larger than itself: 5e-10
-        check_step(d, s, u, div, 1e-11, 5e-10)
+        check_step(d, s, u, div, 1e-11, 2e-9)
     case.close()
