@@ -1328,27 +1328,45 @@ int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f)
 }
 
 // ---- the caller contract -----------------------------------------------------------
-int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
+int hfx_CalcResidual_blocks(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb)
 {
-  HFX_CHECK(e, "NULL eles");
-  HFX_CHECK(e->ctx->have_params, "parameters not set");
-  const int viscous = e->ctx->params.viscous;
-  /* the call order of src/solver.cpp:65-216 */
-  if (hfx_eles_extrapolate_solution(e)) return 1;
-  if (viscous && hfx_eles_calculate_gradient(e)) return 1;
-  if (e->over_int_ready ? hfx_eles_evaluate_invFlux_over_int(e) : hfx_eles_evaluate_invFlux(e)) return 1; /* src/solver.cpp:82-91 */
+  HFX_CHECK(eles && neb > 0, "hfx_CalcResidual_blocks: no element blocks");
+  hfx_ctx *ctx = eles[0]->ctx;
+  for (int i = 0; i < neb; i++) HFX_CHECK(eles[i] && eles[i]->ctx == ctx, "element blocks of different contexts");
+  HFX_CHECK(ctx->have_params, "parameters not set");
+  const int viscous = ctx->params.viscous;
+  for (int b = 0; b < nfb; b++)
+  {
+    // every face block must connect element blocks of this call
+    bool l = false, r = faces[b]->right == nullptr;
+    for (int i = 0; i < neb; i++)
+    {
+      l = l || faces[b]->left == eles[i];
+      r = r || faces[b]->right == eles[i];
+    }
+    HFX_CHECK(l && r, "face block %d refers to an element block that is not part of this call", b);
+  }
+#define HFX_EACH(call)             \
+  for (int i = 0; i < neb; i++)    \
+    if (call(eles[i])) return 1
+  /* the call order of src/solver.cpp:65-216, every method over all element classes */
+  HFX_EACH(hfx_eles_extrapolate_solution);
+  if (viscous) HFX_EACH(hfx_eles_calculate_gradient);
+  for (int i = 0; i < neb; i++) /* src/solver.cpp:82-91 */
+    if (eles[i]->over_int_ready ? hfx_eles_evaluate_invFlux_over_int(eles[i]) : hfx_eles_evaluate_invFlux(eles[i])) return 1;
   for (int b = 0; b < nfb; b++)
     if (!faces[b]->is_bdy && hfx_int_inters_calculate_common_invFlux(faces[b])) return 1;
   for (int b = 0; b < nfb; b++)
     if (faces[b]->is_bdy && hfx_bdy_inters_evaluate_boundaryConditions_invFlux(faces[b], 0.0)) return 1;
   if (viscous)
   {
-    if (hfx_eles_correct_gradient(e)) return 1;
-    if (hfx_eles_evaluate_viscFlux(e)) return 1;
-    if (e->les_ready && hfx_eles_extrapolate_sgsFlux(e)) return 1; /* src/solver.cpp:162-167 */
+    HFX_EACH(hfx_eles_correct_gradient);
+    HFX_EACH(hfx_eles_evaluate_viscFlux);
+    for (int i = 0; i < neb; i++)
+      if (eles[i]->les_ready && hfx_eles_extrapolate_sgsFlux(eles[i])) return 1; /* src/solver.cpp:162-167 */
   }
-  if (hfx_eles_extrapolate_totalFlux(e)) return 1;
-  if (hfx_eles_calculate_divergence(e)) return 1;
+  HFX_EACH(hfx_eles_extrapolate_totalFlux);
+  HFX_EACH(hfx_eles_calculate_divergence);
   if (viscous)
   {
     for (int b = 0; b < nfb; b++)
@@ -1356,30 +1374,65 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
     for (int b = 0; b < nfb; b++)
       if (faces[b]->is_bdy && hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(faces[b], 0.0)) return 1;
   }
-  return hfx_eles_calculate_corrected_divergence(e);
+  HFX_EACH(hfx_eles_calculate_corrected_divergence);
+#undef HFX_EACH
+  return 0;
+}
+
+int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int nfb)
+{
+  HFX_CHECK(e, "NULL eles");
+  return hfx_CalcResidual_blocks(&e, 1, faces, nfb);
+}
+
+// calc_time_step over several blocks: the minimum over the blocks (src/solver.cpp:498-505)
+static int calc_time_step_blocks(hfx_eles *const *eles, int neb)
+{
+  hfx_ctx *ctx = eles[0]->ctx;
+  if (ctx->params.dt_type != 1 && ctx->params.dt_type != 2) return 0;
+  double dt_min = 1e12;
+  for (int i = 0; i < neb; i++)
+  {
+    if (calc_time_step(eles[i], nullptr)) return 1;
+    dt_min = std::min(dt_min, ctx->params.dt);
+  }
+  ctx->params.dt = dt_min;
+  return 0;
+}
+
+int hfx_run_steps_blocks(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int n_steps, int fused)
+{
+  HFX_CHECK(eles && neb > 0 && eles[0], "hfx_run_steps_blocks: no element blocks");
+  hfx_ctx *ctx = eles[0]->ctx;
+  HFX_CHECK(ctx->have_params, "parameters not set");
+  const int adv = ctx->params.adv_type;
+  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14; /* src/HiFiLES.cpp:143-150 */
+  HFX_CHECK(fused != 4, "the general fused stage (fused 4) is not part of this build");
+  HFX_CHECK(fused == 0 || neb == 1, "hfx_run_steps_blocks: the split fused stage (fused %d) takes one tensor-product element block; "
+                                    "several blocks run per method (0) or through the general fused stage (4)", fused);
+  HFX_CHECK(fused == 0 || fused == 2 || fused == 3, "hfx_run_steps: fused must be 0 (per-method), 2 or 3 (split fused stage), 4 (general fused "
+                                                    "stage); the gather-style variant 1 of earlier versions has been retired");
+  if (fused) return split_run_steps(eles[0], faces, nfb, n_steps, fused);
+  for (int s = 0; s < n_steps; s++)
+  {
+    if (calc_time_step_blocks(eles, neb)) return 1; /* src/HiFiLES.cpp:198 */
+    for (int rk = 0; rk < nst; rk++)
+    {
+      if (hfx_CalcResidual_blocks(eles, neb, faces, nfb)) return 1;
+      for (int i = 0; i < neb; i++)
+        if (hfx_eles_AdvanceSolution(eles[i], rk, adv)) return 1;
+      for (int i = 0; i < neb; i++)
+        if (eles[i]->shock_ready && hfx_eles_shock_capture(eles[i])) return 1; /* src/HiFiLES.cpp:214-216 */
+    }
+    advance_ramp_counters(faces, nfb); /* src/HiFiLES.cpp:224-225 */
+  }
+  return 0;
 }
 
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int fused)
 {
   HFX_CHECK(e, "NULL eles");
-  HFX_CHECK(e->ctx->have_params, "parameters not set");
-  const int adv = e->ctx->params.adv_type;
-  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14; /* src/HiFiLES.cpp:143-150 */
-  HFX_CHECK(fused == 0 || fused == 2 || fused == 3, "hfx_run_steps: fused must be 0 (per-method), 2 or 3 (split fused stage); the gather-style "
-                                                    "variant 1 of earlier versions has been retired");
-  if (fused) return split_run_steps(e, faces, nfb, n_steps, fused);
-  for (int s = 0; s < n_steps; s++)
-  {
-    if (calc_time_step(e, nullptr)) return 1; /* src/HiFiLES.cpp:198 */
-    for (int rk = 0; rk < nst; rk++)
-    {
-      if (hfx_CalcResidual(e, faces, nfb)) return 1;
-      if (hfx_eles_AdvanceSolution(e, rk, adv)) return 1;
-      if (e->shock_ready && hfx_eles_shock_capture(e)) return 1; /* src/HiFiLES.cpp:214-216 */
-    }
-    advance_ramp_counters(faces, nfb); /* src/HiFiLES.cpp:224-225 */
-  }
-  return 0;
+  return hfx_run_steps_blocks(&e, 1, faces, nfb, n_steps, fused);
 }
 
 int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double ms[HFX_N_TIMED_METHODS])

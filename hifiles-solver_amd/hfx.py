@@ -354,6 +354,19 @@ class MpiInters:
             self.h = C.c_void_p()
 
 
+def CalcResidual_blocks(eles, faces):
+    """hfx_CalcResidual_blocks: several element blocks (a mixed mesh), face blocks between any two of them"""
+    ea = (C.c_void_p * len(eles))(*[e.h for e in eles])
+    fa = (C.c_void_p * max(1, len(faces)))(*[f.h for f in faces])
+    check(lib().hfx_CalcResidual_blocks(ea, C.c_int(len(eles)), fa, C.c_int(len(faces))))
+
+
+def run_steps_blocks(eles, faces, n_steps, fused=0):
+    ea = (C.c_void_p * len(eles))(*[e.h for e in eles])
+    fa = (C.c_void_p * max(1, len(faces)))(*[f.h for f in faces])
+    check(lib().hfx_run_steps_blocks(ea, C.c_int(len(eles)), fa, C.c_int(len(faces)), C.c_int(n_steps), C.c_int(int(fused))))
+
+
 def comm_unique_id():
     """128 bytes for hfx_comm_create (ncclGetUniqueId): made on rank 0, distributed by the launcher."""
     b = C.create_string_buffer(128)

@@ -274,6 +274,11 @@ int hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(hfx_inters *f, double ti
 /* CalcResidual (src/solver.cpp:50-223) for one element block and its interior and boundary
  * face blocks (any mix, in `faces`), LES / RANS / forcing off; same call order as the reference. */
 int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
+/* The same for a MIXED mesh: several element blocks (the reference's mesh_eles(i), one per element class) and face blocks
+ * whose left and right sides may belong to different element blocks (int_inters::set_interior is called with
+ * ctype(ic_l), ctype(ic_r), src/geometry.cpp:637-706).  Every method runs for all element blocks before the next one,
+ * exactly as src/solver.cpp:59-221 loops `for (i = 0; i < n_ele_types; i++) mesh_eles(i)->method()`. */
+int hfx_CalcResidual_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *faces, int n_face_blocks);
 /* n_steps time steps = the RK-stage loop of src/HiFiLES.cpp:194-217:
  * for each stage CalcResidual + AdvanceSolution.  `fused`: 0 the per-method path, 2 the split fused
  * kernels, 3 the split kernels with the fluxes evaluated in the gradient kernel (same results to
@@ -283,6 +288,10 @@ int hfx_CalcResidual(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks);
  * With dt_type 1 / 2 every step starts with calc_time_step (hfx_ctx_set_CFL, hfx_eles_set_h_ref); boundary
  * blocks whose groups ramp get run_input.ramp_counter advanced after every step (src/HiFiLES.cpp:224-225). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
+/* The RK loop over several element blocks (mixed meshes).  fused 0: the per-method path; fused 4: the fused stage for
+ * general (non-tensor-product) element classes -- see hfx_general_* below. */
+int hfx_run_steps_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *faces, int n_face_blocks, int n_steps,
+                         int fused);
 
 /* One RK stage of the split fused path on a PARTITIONED block, cut so that the caller can move the
  * partition-face buffers while interior faces are being worked on (the order of CalcResidual's

@@ -24,7 +24,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
-from gen_neu_mesh import write_neu, write_neu_tets, write_neu_prisms  # noqa: E402
+from gen_neu_mesh import write_neu, write_neu_tets, write_neu_prisms, write_neu_mixed  # noqa: E402
 
 REF_HOME = os.environ.get("HIFILES_HOME", "/root/reference")
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
@@ -81,6 +81,15 @@ BC_KEYS = dict(
     bc_Dual_type="slip_wall_dual",
     bc_InR_type="sub_in_char", bc_InR_p_total=P_TGV * 1.0070, bc_InR_T_total=300.6, bc_InR_nx=0.0, bc_InR_ny=1.0, bc_InR_nz=0.0,
     bc_InR_pressure_ramp=1, bc_InR_p_ramp_coeff=0.01, bc_InR_T_ramp_coeff=-1.0, bc_InR_p_total_old=P_TGV * 1.002,
+)
+
+# the mixed channel: element-class keys of both classes, walls moving against the Taylor-Green field so that the viscous
+# wall fluxes are not small
+MIXED_KEYS = dict(
+    upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0,
+    upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0, vcjh_scheme_tri=1, c_tri=0.0,
+    bc_WallLo_type="isotherm_wall", bc_WallLo_T_static=310.0, bc_WallLo_u=3.0,
+    bc_WallHi_type="adiabat_wall", bc_WallHi_w=-2.0,
 )
 
 # threshold inside the widest gap of hex_p4_jet's first-stage sensor values (so that rounding cannot flip an element)
@@ -174,6 +183,11 @@ CASES = [
          bcs={"y-": "WallT", "y+": "Far2", "x-": "InR", "x+": "Out"},
          bc_Far2_type="char", bc_Far2_p_static=P_TGV, bc_Far2_mach=0.12, bc_Far2_T_static=295.0, bc_Far2_nx=0.8, bc_Far2_ny=0.6,
          **BC_KEYS),
+    # BASELINE.json configs[3]: a MIXED mesh -- a channel with a prism layer on either wall and tetrahedra in the core,
+    # isothermal wall below, adiabatic wall above, periodic in x and z; P3 (the configuration's order) with every stage
+    # state, P2 with every intermediate of one residual
+    case("mixed_p3_channel", n=[2, 3, 2], amp=0.08, level=1, order=3, steps=1, tets="mixed", **MIXED_KEYS),
+    case("mixed_p2_channel", n=[2, 3, 2], amp=0.08, level=2, order=2, steps=2, tets="mixed", **MIXED_KEYS),
     # a total-pressure ramp over several time steps: run_input.ramp_counter advances after every step (src/HiFiLES.cpp:224-225)
     case("quad_p3_ramp", dims=2, n=4, amp=0.1, level=1, order=3, steps=3,
          bcs={"y-": "WallT", "y+": "Slip", "x-": "InR", "x+": "Out"}, **BC_KEYS),
@@ -203,7 +217,9 @@ def read_dump(path):
 
 def run_case(c):
     with tempfile.TemporaryDirectory() as td:
-        if c.get("tets") == "prisms":
+        if c.get("tets") == "mixed":
+            xv = write_neu_mixed(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])
+        elif c.get("tets") == "prisms":
             xv = write_neu_prisms(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])
         elif c.get("tets"):
             xv = write_neu_tets(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])

@@ -275,6 +275,90 @@ def write_neu_prisms(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
     return xv
 
 
+def write_neu_mixed(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic", wall_lo="WallLo", wall_hi="WallHi"):
+    """A channel of MIXED elements (BASELINE.json configs[3]): periodic in x and z, walls at y = 0 and y = length.  The
+    cell layers on the two walls (j = 0 and j = ny-1) are triangular prisms extruded in y -- their triangular faces lie
+    on the wall and on the interface to the core -- and the core layers are tetrahedra (6 Kuhn tetrahedra per cell).
+    Both cut the y = const cell faces along the same diagonal (i,k) -> (i+1,k+1), so the prism / tetrahedron interface
+    is conforming (triangle against triangle), as are the periodic images.  Needs ny >= 3.
+    Element records: Gambit type 5 (prism, 6 nodes) and 6 (tetrahedron, 4 nodes), see write_neu_prisms / write_neu_tets
+    for the node and face conventions.  Three boundary groups: `bcname` (the x and z sides), `wall_lo`, `wall_hi`."""
+    import itertools
+    if isinstance(n, int):
+        n = [n] * 3
+    nx, ny, nz = n
+    assert ny >= 3, "need a core layer between the two prism layers"
+    xv = box_vertices(n, 3, length, amp)
+    nv = xv.shape[0]
+
+    def vid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    cells = []  # (gambit type, nodes)
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                if j == 0 or j == ny - 1:
+                    # triangles in the (z, x) plane, counter-clockwise seen from +y, extruded in +y: positive volume
+                    for tri in (((0, 0), (1, 0), (1, 1)), ((0, 0), (1, 1), (0, 1))):  # (dz, dx)
+                        v = [vid(i + b, j, k + a) for a, b in tri] + [vid(i + b, j + 1, k + a) for a, b in tri]
+                        cells.append((5, v))
+                else:
+                    for perm in itertools.permutations(range(3)):
+                        p = [i, j, k]
+                        v = [vid(*p)]
+                        for a in perm:
+                            p[a] += 1
+                            v.append(vid(*p))
+                        x = xv[v]
+                        if np.linalg.det(np.stack([x[1] - x[0], x[2] - x[0], x[3] - x[0]])) < 0:
+                            v[1], v[2] = v[2], v[1]
+                        cells.append((6, v))
+    faces_loc = {6: [(1, 2, 3), (0, 3, 2), (0, 1, 3), (0, 2, 1)],
+                 5: [(0, 2, 1), (3, 4, 5), (0, 1, 4, 3), (1, 2, 5, 4), (2, 0, 3, 5)]}
+    to_k = {6: {0: 3, 1: 4, 2: 2, 3: 1}, 5: {2: 1, 3: 2, 4: 3, 0: 4, 1: 5}}
+    lat = np.zeros((nv, 3), dtype=int)
+    for k in range(nz + 1):
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                lat[vid(i, j, k)] = (i, j, k)
+    groups = {bcname: [], wall_lo: [], wall_hi: []}
+    for e, (ty, v) in enumerate(cells):
+        for f, fl in enumerate(faces_loc[ty]):
+            c = lat[[v[q] for q in fl]]
+            for d in range(3):
+                lo, hi = (c[:, d] == 0).all(), (c[:, d] == n[d]).all()
+                if lo or hi:
+                    g = bcname if d != 1 else (wall_lo if lo else wall_hi)
+                    groups[g].append((e + 1, ty, to_k[ty][f]))
+    ne = len(cells)
+    with open(path, "w") as f:
+        f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\nmixed_channel\n")
+        f.write("PROGRAM:                Gambit     VERSION:  2.3.16\n\n")
+        f.write("     NUMNP     NELEM     NGRPS    NBSETS     NDFCD     NDFVL\n")
+        f.write("%10d%10d%10d%10d%10d%10d\n" % (nv, ne, 1, len(groups), 3, 3))
+        f.write("ENDOFSECTION\n   NODAL COORDINATES 2.3.16\n")
+        for i in range(nv):
+            f.write("%10d" % (i + 1) + "".join(" %.17e" % c for c in xv[i]) + "\n")
+        f.write("ENDOFSECTION\n      ELEMENTS/CELLS 2.3.16\n")
+        for e, (ty, v) in enumerate(cells):
+            f.write("%8d %2d %2d " % (e + 1, ty, len(v)) + "".join("%8d" % (q + 1) for q in v) + "\n")
+        f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
+        f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n" % (1, ne, 2, 1))
+        f.write("                           fluid\n       0\n")
+        ids = list(range(1, ne + 1))
+        for s0 in range(0, ne, 10):
+            f.write("".join("%8d" % q for q in ids[s0:s0 + 10]) + "\n")
+        f.write("ENDOFSECTION\n")
+        for g, lst in groups.items():
+            f.write(" BOUNDARY CONDITIONS 2.3.16\n")
+            f.write("%32s%8d%8d%8d%8d\n" % (g, 1, len(lst), 0, 6))
+            for (el, ty, fc) in lst:
+                f.write("%10d%5d%5d\n" % (el, ty, fc))
+            f.write("ENDOFSECTION\n")
+    return xv
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("out")

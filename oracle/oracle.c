@@ -846,10 +846,12 @@ double orc_compute_res_upts(const orc_eles *e, int norm_type, int field)
 /* face methods                                                              */
 
 /* src/int_inters.cpp:160-249 */
-void orc_int_calculate_common_invFlux(const orc_int_inters *F, orc_eles *e, const orc_params *P)
+void orc_int_calculate_common_invFlux_lr(const orc_int_inters *F, orc_eles *el, orc_eles *er, const orc_params *P)
 {
-  const int nd = e->n_dims, nf = e->n_fields;
-  const long plane = (long)e->n_fpts * e->n_eles;
+  /* the left and right side of a face block may belong to different element classes (a mixed mesh: the reference wires
+   * raw pointers per (ctype(ic_l), ctype(ic_r)), src/geometry.cpp:637-706, src/int_inters.cpp:67-121) */
+  const int nd = el->n_dims, nf = el->n_fields;
+  const long pl = (long)el->n_fpts * el->n_eles, pr = (long)er->n_fpts * er->n_eles;
   const int nfi = F->n_fpts_per_inter;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
   for (int i = 0; i < F->n_inters; i++)
@@ -859,10 +861,10 @@ void orc_int_calculate_common_invFlux(const orc_int_inters *F, orc_eles *e, cons
       double ul[MAXF], ur[MAXF], fl[MAXF * MAXD], fr[MAXF * MAXD], norm[MAXD], fn[MAXF], uc[MAXF];
       for (int k = 0; k < nf; k++)
       {
-        ul[k] = e->disu_fpts[il + k * plane];
-        ur[k] = e->disu_fpts[ir + k * plane];
+        ul[k] = el->disu_fpts[il + k * pl];
+        ur[k] = er->disu_fpts[ir + k * pr];
       }
-      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      for (int m = 0; m < nd; m++) norm[m] = el->norm_fpts[il + m * pl];
       orc_calc_invf(nd, P->gamma, ul, fl);
       orc_calc_invf(nd, P->gamma, ur, fr);
       if (P->riemann_solve_type == 0)
@@ -873,26 +875,31 @@ void orc_int_calculate_common_invFlux(const orc_int_inters *F, orc_eles *e, cons
         orc_hllc_flux(nd, P->gamma, ul, ur, fl, fr, norm, fn);
       for (int k = 0; k < nf; k++)
       {
-        e->norm_tconf_fpts[il + k * plane] = fn[k] * e->tdA_fpts[il];
-        e->norm_tconf_fpts[ir + k * plane] = -fn[k] * e->tdA_fpts[ir];
+        el->norm_tconf_fpts[il + k * pl] = fn[k] * el->tdA_fpts[il];
+        er->norm_tconf_fpts[ir + k * pr] = -fn[k] * er->tdA_fpts[ir];
       }
       if (P->viscous)
       {
         orc_ldg_solution(0, nd, ul, ur, uc, P->ldg_beta, norm);
         for (int k = 0; k < nf; k++)
         {
-          e->delta_disu_fpts[il + k * plane] = (uc[k] - ul[k]);
-          e->delta_disu_fpts[ir + k * plane] = (uc[k] - ur[k]);
+          el->delta_disu_fpts[il + k * pl] = (uc[k] - ul[k]);
+          er->delta_disu_fpts[ir + k * pr] = (uc[k] - ur[k]);
         }
       }
     }
 }
 
-/* src/int_inters.cpp:254-343 (LES off) */
-void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, const orc_params *P)
+void orc_int_calculate_common_invFlux(const orc_int_inters *F, orc_eles *e, const orc_params *P)
 {
-  const int nd = e->n_dims, nf = e->n_fields;
-  const long plane = (long)e->n_fpts * e->n_eles;
+  orc_int_calculate_common_invFlux_lr(F, e, e, P);
+}
+
+/* src/int_inters.cpp:254-343 */
+void orc_int_calculate_common_viscFlux_lr(const orc_int_inters *F, orc_eles *el, orc_eles *er, const orc_params *P)
+{
+  const int nd = el->n_dims, nf = el->n_fields;
+  const long pl = (long)el->n_fpts * el->n_eles, pr = (long)er->n_fpts * er->n_eles;
   const int nfi = F->n_fpts_per_inter;
 #pragma omp parallel for schedule(static) if (g_threads > 1)
   for (int i = 0; i < F->n_inters; i++)
@@ -903,32 +910,37 @@ void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, con
           fn[MAXF];
       for (int k = 0; k < nf; k++)
       {
-        ul[k] = e->disu_fpts[il + k * plane];
-        ur[k] = e->disu_fpts[ir + k * plane];
+        ul[k] = el->disu_fpts[il + k * pl];
+        ur[k] = er->disu_fpts[ir + k * pr];
       }
       for (int k = 0; k < nd; k++)
         for (int l = 0; l < nf; l++)
         {
-          gl[l + nf * k] = e->grad_disu_fpts[il + (l + (long)nf * k) * plane];
-          gr[l + nf * k] = e->grad_disu_fpts[ir + (l + (long)nf * k) * plane];
+          gl[l + nf * k] = el->grad_disu_fpts[il + (l + (long)nf * k) * pl];
+          gr[l + nf * k] = er->grad_disu_fpts[ir + (l + (long)nf * k) * pr];
         }
       orc_calc_visf(nd, P, ul, gl, fl);
       orc_calc_visf(nd, P, ur, gr, fr);
-      if (e->sgs_model >= 0 && e->sgsf_fpts) /* src/int_inters.cpp:302-318 */
+      if (el->sgs_model >= 0 && el->sgsf_fpts && er->sgsf_fpts) /* src/int_inters.cpp:302-318 */
         for (int k = 0; k < nd; k++)
           for (int l = 0; l < nf; l++)
           {
-            fl[l + nf * k] += e->sgsf_fpts[il + (l + (long)nf * k) * plane];
-            fr[l + nf * k] += e->sgsf_fpts[ir + (l + (long)nf * k) * plane];
+            fl[l + nf * k] += el->sgsf_fpts[il + (l + (long)nf * k) * pl];
+            fr[l + nf * k] += er->sgsf_fpts[ir + (l + (long)nf * k) * pr];
           }
-      for (int m = 0; m < nd; m++) norm[m] = e->norm_fpts[il + m * plane];
+      for (int m = 0; m < nd; m++) norm[m] = el->norm_fpts[il + m * pl];
       orc_ldg_flux(0, nd, ul, ur, fl, fr, norm, fn, P->ldg_tau, P->ldg_beta);
       for (int k = 0; k < nf; k++)
       {
-        e->norm_tconf_fpts[il + k * plane] += fn[k] * e->tdA_fpts[il];
-        e->norm_tconf_fpts[ir + k * plane] += -fn[k] * e->tdA_fpts[ir];
+        el->norm_tconf_fpts[il + k * pl] += fn[k] * el->tdA_fpts[il];
+        er->norm_tconf_fpts[ir + k * pr] += -fn[k] * er->tdA_fpts[ir];
       }
     }
+}
+
+void orc_int_calculate_common_viscFlux(const orc_int_inters *F, orc_eles *e, const orc_params *P)
+{
+  orc_int_calculate_common_viscFlux_lr(F, e, e, P);
 }
 
 /* ------------------------------------------------------------------------ */

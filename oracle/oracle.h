@@ -180,6 +180,9 @@ void orc_calc_disu_ppts(const orc_eles *e, int n_ppts, const double *opp_p, doub
 /* face methods: src/int_inters.cpp */
 void orc_int_calculate_common_invFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p);  /* :160 */
 void orc_int_calculate_common_viscFlux(const orc_int_inters *f, orc_eles *e, const orc_params *p); /* :254 */
+/* the same with the two sides of the block in different element classes (mixed meshes, src/geometry.cpp:637-706) */
+void orc_int_calculate_common_invFlux_lr(const orc_int_inters *f, orc_eles *el, orc_eles *er, const orc_params *p);
+void orc_int_calculate_common_viscFlux_lr(const orc_int_inters *f, orc_eles *el, orc_eles *er, const orc_params *p);
 
 /* partition faces: src/mpi_inters.cpp */
 /* eles::evaluate_invFlux_over_int (src/eles.cpp:1480-1545): opp (n_cub,n_upts), filter (n_upts,n_cub), JGinv (nd,nd,n_cub,n_eles) */

@@ -126,23 +126,52 @@ int main(int argc, char *argv[])
   g_out = fopen(argv[2], "wb");
   if (!g_out) { perror("open out"); return 1; }
 
-  // which element class carries the mesh (fixtures are single-type meshes)
-  eles *E = NULL;
-  int etype = -1;
+  // the element classes that carry the mesh.  One class: the arrays keep their plain names (the single-type
+  // fixtures).  Several (a MIXED mesh, e.g. prisms on the walls and tetrahedra in the core): class c's arrays are
+  // prefixed "c<ele_type>_", and the face tables carry the class of either side of every face.
+  vector<eles *> Es;
+  vector<int> etypes;
   for (int i = 0; i < FlowSol.n_ele_types; i++)
     if (FlowSol.mesh_eles(i)->get_n_eles() != 0)
     {
-      if (E) { fprintf(stderr, "harness: mixed meshes not supported\n"); return 1; }
-      E = FlowSol.mesh_eles(i);
-      etype = i;
+      Es.push_back(FlowSol.mesh_eles(i));
+      etypes.push_back(i);
     }
+  const bool mixed = Es.size() > 1;
+  auto pre = [&](size_t c) { return mixed ? "c" + to_string(etypes[c]) + "_" : string(); };
+  eles *E = Es[0];
+  int etype = etypes[0];
   int n_eles = E->n_eles, n_upts = E->n_upts_per_ele, n_fpts = E->n_fpts_per_ele;
   int n_fields = E->n_fields, n_dims = E->n_dims;
-
+  if (mixed && (run_input.LES || run_input.n_integral_quantities != 0 || run_input.over_int || run_input.shock_cap ||
+                run_input.dt_type != 0 || getenv("HFX_DUMP_PPTS") || getenv("HFX_DUMP_RESTART")))
   {
-    int32_t sizes[8] = {n_eles, n_upts, n_fpts, n_fields, n_dims, E->order, etype, RKSteps};
-    put_i("sizes", sizes, {8});
+    fprintf(stderr, "harness: mixed meshes are dumped for the plain Navier-Stokes / Euler path only\n");
+    return 1;
   }
+  for (size_t c = 0; c < Es.size(); c++)
+  {
+    eles *X = Es[c];
+    int32_t sizes[8] = {X->n_eles, X->n_upts_per_ele, X->n_fpts_per_ele, X->n_fields, X->n_dims, X->order, etypes[c], RKSteps};
+    put_i(pre(c) + "sizes", sizes, {8});
+  }
+  if (mixed)
+  {
+    vector<int32_t> cl(etypes.begin(), etypes.end());
+    put_i("classes", cl.data(), {(int64_t)cl.size()});
+  }
+  // which class owns a pointer into a flux-point array, and the offset inside the class's (fpt, ele) plane x fields
+  auto locate = [&](double *ptr, int which, int &cls) -> int64_t {
+    for (size_t c = 0; c < Es.size(); c++)
+    {
+      hf_array<double> &a = (which == 0) ? Es[c]->disu_fpts : (which == 1) ? Es[c]->norm_tconf_fpts : (which == 2) ? Es[c]->tdA_fpts : Es[c]->norm_fpts;
+      double *b = a.get_ptr_cpu();
+      const int64_t n = (int64_t)a.get_dim(0) * a.get_dim(1) * a.get_dim(2) * a.get_dim(3);
+      if (ptr >= b && ptr < b + n) { cls = (int)c; return ptr - b; }
+    }
+    cls = -1;
+    return -1;
+  };
 
   if (level >= 1)
   {
@@ -170,24 +199,29 @@ int main(int argc, char *argv[])
     put_arr("RK_a", run_input.RK_a);
     put_arr("RK_b", run_input.RK_b);
 
-    put_arr("opp_0", E->opp_0);
-    put_arr("opp_3", E->opp_3);
-    for (int d = 0; d < n_dims; d++)
+    for (size_t c = 0; c < Es.size(); c++)
     {
-      string s = to_string(d);
-      put_arr("opp_1_" + s, E->opp_1(d));
-      put_arr("opp_2_" + s, E->opp_2(d));
-      if (run_input.viscous)
+      eles *X = Es[c];
+      const string q = pre(c);
+      put_arr(q + "opp_0", X->opp_0);
+      put_arr(q + "opp_3", X->opp_3);
+      for (int d = 0; d < n_dims; d++)
       {
-        put_arr("opp_4_" + s, E->opp_4(d));
-        put_arr("opp_5_" + s, E->opp_5(d));
+        string s = to_string(d);
+        put_arr(q + "opp_1_" + s, X->opp_1(d));
+        put_arr(q + "opp_2_" + s, X->opp_2(d));
+        if (run_input.viscous)
+        {
+          put_arr(q + "opp_4_" + s, X->opp_4(d));
+          put_arr(q + "opp_5_" + s, X->opp_5(d));
+        }
       }
+      if (run_input.viscous) put_arr(q + "opp_6", X->opp_6);
+      put_arr(q + "loc_upts", X->loc_upts);
+      put_arr(q + "tloc_fpts", X->tloc_fpts);
+      put_arr(q + "tnorm_fpts", X->tnorm_fpts);
+      put_arr(q + "shape", X->shape);
     }
-    if (run_input.viscous) put_arr("opp_6", E->opp_6);
-    put_arr("loc_upts", E->loc_upts);
-    put_arr("tloc_fpts", E->tloc_fpts);
-    put_arr("tnorm_fpts", E->tnorm_fpts);
-    put_arr("shape", E->shape);
 
     // interior face tables as offsets into the owning element arrays
     for (int t = 0; t < FlowSol.n_int_inter_types; t++)
@@ -197,33 +231,40 @@ int main(int argc, char *argv[])
       string s = "int" + to_string(t) + "_";
       int nf = I.n_fpts_per_inter, ni = I.n_inters;
       // field-0 plane; consistency of the other fields / arrays is asserted below
-      vector<int32_t> L((size_t)nf * ni), R((size_t)nf * ni);
-      double *base = E->disu_fpts.get_ptr_cpu();
-      double *base_tc = E->norm_tconf_fpts.get_ptr_cpu();
+      vector<int32_t> L((size_t)nf * ni), R((size_t)nf * ni), cl(ni), cr(ni);
       for (int i = 0; i < ni; i++)
         for (int j = 0; j < nf; j++)
         {
-          L[j + (size_t)nf * i] = (int32_t)(I.disu_fpts_l(j, i, 0) - base);
-          R[j + (size_t)nf * i] = (int32_t)(I.disu_fpts_r(j, i, 0) - base);
+          int kl, kr, k2;
+          const int64_t ol = locate(I.disu_fpts_l(j, i, 0), 0, kl), orr = locate(I.disu_fpts_r(j, i, 0), 0, kr);
+          if (kl < 0 || kr < 0) { fprintf(stderr, "harness: face pointer outside every element class\n"); return 1; }
+          if (j == 0) { cl[i] = etypes[kl]; cr[i] = etypes[kr]; }
+          if (cl[i] != etypes[kl] || cr[i] != etypes[kr]) { fprintf(stderr, "harness: a face changes class between flux points\n"); return 1; }
+          L[j + (size_t)nf * i] = (int32_t)ol;
+          R[j + (size_t)nf * i] = (int32_t)orr;
+          const ptrdiff_t pl = (ptrdiff_t)Es[kl]->n_fpts_per_ele * Es[kl]->n_eles, pr = (ptrdiff_t)Es[kr]->n_fpts_per_ele * Es[kr]->n_eles;
           for (int k = 0; k < n_fields; k++)
           {
-            if (I.disu_fpts_l(j, i, k) - base != L[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles ||
-                I.disu_fpts_r(j, i, k) - base != R[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles ||
-                I.norm_tconf_fpts_l(j, i, k) - base_tc != L[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles ||
-                I.norm_tconf_fpts_r(j, i, k) - base_tc != R[j + (size_t)nf * i] + (ptrdiff_t)k * n_fpts * n_eles)
+            if (locate(I.disu_fpts_l(j, i, k), 0, k2) != ol + k * pl || k2 != kl || locate(I.disu_fpts_r(j, i, k), 0, k2) != orr + k * pr || k2 != kr ||
+                locate(I.norm_tconf_fpts_l(j, i, k), 1, k2) != ol + k * pl || k2 != kl ||
+                locate(I.norm_tconf_fpts_r(j, i, k), 1, k2) != orr + k * pr || k2 != kr)
             {
               fprintf(stderr, "harness: face table layout assumption violated\n");
               return 1;
             }
           }
-          if (I.tdA_fpts_l(j, i) - E->tdA_fpts.get_ptr_cpu() != L[j + (size_t)nf * i] ||
-              I.tdA_fpts_r(j, i) - E->tdA_fpts.get_ptr_cpu() != R[j + (size_t)nf * i] ||
-              I.norm_fpts(j, i, 0) - E->norm_fpts.get_ptr_cpu() != L[j + (size_t)nf * i])
+          if (locate(I.tdA_fpts_l(j, i), 2, k2) != ol || k2 != kl || locate(I.tdA_fpts_r(j, i), 2, k2) != orr || k2 != kr ||
+              locate(I.norm_fpts(j, i, 0), 3, k2) != ol || k2 != kl)
           {
             fprintf(stderr, "harness: face metric table layout assumption violated\n");
             return 1;
           }
         }
+      if (mixed)
+      {
+        put_i(s + "cl", cl.data(), {ni});
+        put_i(s + "cr", cr.data(), {ni});
+      }
       put_i(s + "L", L.data(), {nf, ni});
       put_i(s + "R", R.data(), {nf, ni});
     }
@@ -242,16 +283,19 @@ int main(int argc, char *argv[])
       any = true;
       string s = "bdy" + to_string(t) + "_";
       int nf = B.n_fpts_per_inter, ni = B.n_inters;
-      vector<int32_t> L((size_t)nf * ni), id(ni);
+      vector<int32_t> L((size_t)nf * ni), id(ni), cl(ni);
       for (int i = 0; i < ni; i++)
       {
         id[i] = B.boundary_id(i);
         for (int j = 0; j < nf; j++)
         {
-          L[j + (size_t)nf * i] = (int32_t)(B.disu_fpts_l(j, i, 0) - E->disu_fpts.get_ptr_cpu());
-          if (B.norm_tconf_fpts_l(j, i, 0) - E->norm_tconf_fpts.get_ptr_cpu() != L[j + (size_t)nf * i] ||
-              B.tdA_fpts_l(j, i) - E->tdA_fpts.get_ptr_cpu() != L[j + (size_t)nf * i] ||
-              B.norm_fpts(j, i, 0) - E->norm_fpts.get_ptr_cpu() != L[j + (size_t)nf * i])
+          int kl, k2;
+          const int64_t ol = locate(B.disu_fpts_l(j, i, 0), 0, kl);
+          if (kl < 0) { fprintf(stderr, "harness: boundary face pointer outside every element class\n"); return 1; }
+          if (j == 0) cl[i] = etypes[kl];
+          L[j + (size_t)nf * i] = (int32_t)ol;
+          if (cl[i] != etypes[kl] || locate(B.norm_tconf_fpts_l(j, i, 0), 1, k2) != ol || k2 != kl || locate(B.tdA_fpts_l(j, i), 2, k2) != ol || k2 != kl ||
+              locate(B.norm_fpts(j, i, 0), 3, k2) != ol || k2 != kl)
           {
             fprintf(stderr, "harness: boundary face table layout assumption violated\n");
             return 1;
@@ -260,6 +304,7 @@ int main(int argc, char *argv[])
       }
       put_i(s + "L", L.data(), {nf, ni});
       put_i(s + "id", id.data(), {ni});
+      if (mixed) put_i(s + "cl", cl.data(), {ni});
     }
     if (any)
     {
@@ -357,18 +402,25 @@ int main(int argc, char *argv[])
     put_scalar("shock_cap", run_input.shock_cap);
   }
   if (level >= 1)
-  {
-    put_arr("detjac_upts", E->detjac_upts);
-    put_arr("JGinv_upts", E->JGinv_upts);
-    put_arr("detjac_fpts", E->detjac_fpts);
-    put_arr("JGinv_fpts", E->JGinv_fpts);
-    put_arr("tdA_fpts", E->tdA_fpts);
-    put_arr("norm_fpts", E->norm_fpts);
-    put_arr("pos_upts", E->pos_upts);
-    put_arr("pos_fpts", E->pos_fpts);
-  }
+    for (size_t c = 0; c < Es.size(); c++)
+    {
+      eles *X = Es[c];
+      const string q = pre(c);
+      put_arr(q + "detjac_upts", X->detjac_upts);
+      put_arr(q + "JGinv_upts", X->JGinv_upts);
+      put_arr(q + "detjac_fpts", X->detjac_fpts);
+      put_arr(q + "JGinv_fpts", X->JGinv_fpts);
+      put_arr(q + "tdA_fpts", X->tdA_fpts);
+      put_arr(q + "norm_fpts", X->norm_fpts);
+      put_arr(q + "pos_upts", X->pos_upts);
+      put_arr(q + "pos_fpts", X->pos_fpts);
+    }
 
-  put_arr("u_init", E->disu_upts(0));
+  for (size_t c = 0; c < Es.size(); c++) put_arr(pre(c) + "u_init", Es[c]->disu_upts(0));
+  // one dump of a member array per class: put_all("s0_disu_fpts", [](eles *X) -> hf_array<double> & { return X->disu_fpts; })
+  auto put_all = [&](const string &name, hf_array<double> &(*get)(eles *)) {
+    for (size_t c = 0; c < Es.size(); c++) put_arr(pre(c) + name, get(Es[c]));
+  };
   if (getenv("HFX_DUMP_PPTS"))
   {
     // plot-point interpolation (eles::set_opp_p src/eles.cpp:3600, calc_disu_ppts :3757): the operator, the plot
@@ -417,35 +469,35 @@ int main(int argc, char *argv[])
         // single-rank, LES-off, RANS-off, forcing-off run, with dumps between calls
         int i;
         for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->extrapolate_solution();
-        if (level >= 2) put_arr("s0_disu_fpts", E->disu_fpts);
+        if (level >= 2) put_all("s0_disu_fpts", [](eles *X) -> hf_array<double> & { return X->disu_fpts; });
         if (run_input.viscous)
         {
           for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->calculate_gradient();
-          if (level >= 2) put_arr("s0_grad_disu_upts_ref", E->grad_disu_upts);
+          if (level >= 2) put_all("s0_grad_disu_upts_ref", [](eles *X) -> hf_array<double> & { return X->grad_disu_upts; });
         }
         if (run_input.over_int)
           for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->evaluate_invFlux_over_int();
         else
           for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->evaluate_invFlux();
-        if (level >= 2) put_arr("s0_tdisf_upts_inv", E->tdisf_upts);
+        if (level >= 2) put_all("s0_tdisf_upts_inv", [](eles *X) -> hf_array<double> & { return X->tdisf_upts; });
         for (i = 0; i < FlowSol.n_int_inter_types; i++) FlowSol.mesh_int_inters(i).calculate_common_invFlux();
         for (i = 0; i < FlowSol.n_bdy_inter_types; i++)
           FlowSol.mesh_bdy_inters(i).evaluate_boundaryConditions_invFlux(&FlowSol, FlowSol.time);
         if (level >= 2)
         {
-          put_arr("s0_norm_tconf_fpts_inv", E->norm_tconf_fpts);
-          if (run_input.viscous) put_arr("s0_delta_disu_fpts", E->delta_disu_fpts);
+          put_all("s0_norm_tconf_fpts_inv", [](eles *X) -> hf_array<double> & { return X->norm_tconf_fpts; });
+          if (run_input.viscous) put_all("s0_delta_disu_fpts", [](eles *X) -> hf_array<double> & { return X->delta_disu_fpts; });
         }
         if (run_input.viscous)
         {
           for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->correct_gradient();
           if (level >= 2)
           {
-            put_arr("s0_grad_disu_upts", E->grad_disu_upts);
-            put_arr("s0_grad_disu_fpts", E->grad_disu_fpts);
+            put_all("s0_grad_disu_upts", [](eles *X) -> hf_array<double> & { return X->grad_disu_upts; });
+            put_all("s0_grad_disu_fpts", [](eles *X) -> hf_array<double> & { return X->grad_disu_fpts; });
           }
           for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->evaluate_viscFlux();
-          if (level >= 2) put_arr("s0_tdisf_upts", E->tdisf_upts);
+          if (level >= 2) put_all("s0_tdisf_upts", [](eles *X) -> hf_array<double> & { return X->tdisf_upts; });
           if (run_input.LES)
           {
             // src/solver.cpp:162-167
@@ -458,27 +510,30 @@ int main(int argc, char *argv[])
           }
         }
         for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->extrapolate_totalFlux();
-        if (level >= 2) put_arr("s0_norm_tdisf_fpts", E->norm_tdisf_fpts);
+        if (level >= 2) put_all("s0_norm_tdisf_fpts", [](eles *X) -> hf_array<double> & { return X->norm_tdisf_fpts; });
         for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->calculate_divergence();
-        if (level >= 2) put_arr("s0_div_tconf_upts_disc", E->div_tconf_upts(0));
+        if (level >= 2) put_all("s0_div_tconf_upts_disc", [](eles *X) -> hf_array<double> & { return X->div_tconf_upts(0); });
         if (run_input.viscous)
         {
           for (i = 0; i < FlowSol.n_int_inter_types; i++) FlowSol.mesh_int_inters(i).calculate_common_viscFlux();
           for (i = 0; i < FlowSol.n_bdy_inter_types; i++)
             FlowSol.mesh_bdy_inters(i).evaluate_boundaryConditions_viscFlux(FlowSol.time);
-          if (level >= 2) put_arr("s0_norm_tconf_fpts", E->norm_tconf_fpts);
+          if (level >= 2) put_all("s0_norm_tconf_fpts", [](eles *X) -> hf_array<double> & { return X->norm_tconf_fpts; });
         }
         for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->calculate_corrected_divergence();
-        put_arr("s0_div_tconf_upts", E->div_tconf_upts(0));
+        put_all("s0_div_tconf_upts", [](eles *X) -> hf_array<double> & { return X->div_tconf_upts(0); });
         // residual norms as the reference's monitor computes them (eles.cpp:5045-5074):
         // L1 / L2 sums over all upts of |div_tconf/detjac - src|
-        vector<double> res(2 * n_fields);
-        for (int f = 0; f < n_fields; f++)
+        for (size_t c = 0; c < Es.size(); c++)
         {
-          res[f] = E->compute_res_upts(1, f);
-          res[n_fields + f] = E->compute_res_upts(2, f);
+          vector<double> res(2 * n_fields);
+          for (int f = 0; f < n_fields; f++)
+          {
+            res[f] = Es[c]->compute_res_upts(1, f);
+            res[n_fields + f] = Es[c]->compute_res_upts(2, f);
+          }
+          put_d(pre(c) + "s0_res_sums", res.data(), {n_fields, 2});
         }
-        put_d("s0_res_sums", res.data(), {n_fields, 2});
         if (run_input.n_integral_quantities != 0)
         {
           // state u_init, corrected gradients of this residual (output::CalcIntegralQuantities, src/output.cpp:2017)
@@ -504,14 +559,14 @@ int main(int argc, char *argv[])
       {
         char nm[64];
         snprintf(nm, sizeof nm, "u_step%d_stage%d", step, rk);
-        put_arr(nm, E->disu_upts(0));
+        for (size_t c = 0; c < Es.size(); c++) put_arr(pre(c) + nm, Es[c]->disu_upts(0));
       }
       if (rk == RKSteps - 1 && getenv("HFX_DUMP_DIV"))
       {
         // full-size parity fixtures (oracle/capture_fullsize.py): the residual of the step's last stage
         char nm[64];
         snprintf(nm, sizeof nm, "div_step%d", step);
-        put_arr(nm, E->div_tconf_upts(0));
+        for (size_t c = 0; c < Es.size(); c++) put_arr(pre(c) + nm, Es[c]->div_tconf_upts(0));
       }
     }
     FlowSol.time += run_input.dt;

@@ -1,0 +1,150 @@
+"""BASELINE.json configs[3]: a MIXED mesh -- a channel with a layer of triangular prisms on either wall and tetrahedra in
+the core (oracle/gen_neu_mesh.py write_neu_mixed), isothermal wall below, adiabatic wall above, periodic in x and z.
+Fixtures mixed_p3_channel (the configuration's order; every stage state) and mixed_p2_channel (every intermediate of
+one residual) come from the GENUINE reference.  What is new against the single-class fixtures: interior face blocks
+whose left and right sides belong to DIFFERENT element classes (/root/reference/src/int_inters.cpp:67-121, wired per
+(ctype(ic_l), ctype(ic_r)) in src/geometry.cpp:637-706) and CalcResidual over several element blocks
+(src/solver.cpp:50-223 loops every method over the classes)."""
+import os
+
+import numpy as np
+import pytest
+
+import mixed_util as MU
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MIXED = ["mixed_p2_channel", "mixed_p3_channel"]
+INTERMEDIATES = {  # hook name -> (fixture key, oracle array)
+    "disu_fpts": ("s0_disu_fpts", "disu_fpts"), "grad_disu_upts_ref": ("s0_grad_disu_upts_ref", "grad_disu_upts"),
+    "tdisf_upts_inv": ("s0_tdisf_upts_inv", "tdisf_upts"), "norm_tconf_fpts_inv": ("s0_norm_tconf_fpts_inv", "norm_tconf_fpts"),
+    "grad_disu_fpts": ("s0_grad_disu_fpts", "grad_disu_fpts"), "tdisf_upts": ("s0_tdisf_upts", "tdisf_upts"),
+    "norm_tdisf_fpts": ("s0_norm_tdisf_fpts", "norm_tdisf_fpts"), "div_tconf_upts_disc": ("s0_div_tconf_upts_disc", "div_tconf_upts"),
+    "norm_tconf_fpts": ("s0_norm_tconf_fpts", "norm_tconf_fpts"), "div_tconf_upts": ("s0_div_tconf_upts", "div_tconf_upts"),
+}
+
+
+def relerr(a, b):
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def test_fixture_has_faces_between_classes():
+    d = dict(np.load(os.path.join(GOLDEN, "mixed_p3_channel.npz")))
+    classes, per, faces, bdy = MU.split(d)
+    assert classes == [2, 3]
+    pairs = {(a, b) for a, b, _, _ in faces}
+    assert (2, 3) in pairs and (3, 2) in pairs and (2, 2) in pairs and (3, 3) in pairs  # left != right exists
+    assert {a for a, _, _ in bdy} == {3}  # the walls sit on prisms
+
+
+@pytest.mark.parametrize("name", MIXED)
+def test_oracle_on_mixed_mesh_vs_reference(name):
+    """the oracle with two element blocks and class-crossing face blocks reproduces the reference: every intermediate of
+    the first residual (level-2 fixture) and the state after every RK stage"""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    m = MU.MixedOracle(d)
+    nstage = int(d["c2_sizes"][7])
+    steps = sorted({int(k.split("_")[2][4:]) for k in d if k.startswith("c2_u_step")})
+    first = [True]
+
+    def hook(what):
+        key, arr = INTERMEDIATES[what]
+        for c in m.classes:
+            k = "c%d_%s" % (c, key)
+            if first[0] and k in d:
+                assert relerr(m.arr(c, arr), d[k]) < 1e-13, k
+
+    for st in steps:
+        for rk in range(nstage):
+            assert m.CalcResidual(hook) == -1
+            first[0] = False
+            m.AdvanceSolution(rk)
+            for c in m.classes:
+                k = "c%d_u_step%d_stage%d" % (c, st, rk)
+                if k in d:
+                    assert relerr(m.arr(c, "u0"), d[k]) < 1e-13, k
+
+
+# ---- the device path, through the C ABI -----------------------------------------------------------------------------
+def build_gpu(ctx, d):
+    """-> ({cls: hfx.Eles}, [face blocks]): one element block per class, one interior block per (left, right) class pair,
+    one boundary block per class"""
+    import hfx
+    classes, per, faces, bdy = MU.split(d)
+    ctx.set_params(hfx.params_from(per[classes[0]]))
+    ctx.set_contract_mode(hfx.CONTRACT_AUTO)
+    E = {}
+    for c in classes:
+        sz = [int(v) for v in per[c]["sizes"]]
+        E[c] = hfx.Eles(ctx, sz[:5], per[c], ele_type=sz[6], order=sz[5])
+        E[c].upload(hfx.DISU_UPTS0, per[c]["u_init"])
+    F = [hfx.IntInters(ctx, E[a], E[b], L, R) for a, b, L, R in faces]
+    for a, L, ids in bdy:
+        F.append(hfx.BdyInters(ctx, E[a], L, ids, hfx.bc_records(d["bc_flags"], d["bc_params"]), float(np.ravel(d["bc_R_ref"])[0]),
+                               int(np.ravel(d["ramp_counter"])[0])))
+    return classes, E, F
+
+
+GPU_ARRAYS = {"s0_disu_fpts": "DISU_FPTS", "s0_tdisf_upts": "TDISF_UPTS", "s0_norm_tdisf_fpts": "NORM_TDISF_FPTS",
+              "s0_delta_disu_fpts": "DELTA_DISU_FPTS", "s0_grad_disu_upts": "GRAD_DISU_UPTS",
+              "s0_grad_disu_fpts": "GRAD_DISU_FPTS", "s0_div_tconf_upts": "DIV_TCONF_UPTS"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MIXED)
+def test_stage_states_vs_reference(name):
+    """hfx_CalcResidual_blocks + AdvanceSolution per block on the mixed channel: what one residual leaves in the public
+    arrays of BOTH classes (level-2 fixture) and the state after every RK stage, against the genuine reference"""
+    import hfx
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    ctx = hfx.Context(0)
+    classes, E, F = build_gpu(ctx, d)
+    blocks = [E[c] for c in classes]
+    nstage = int(d["c2_sizes"][7])
+    adv = int(np.ravel(d["adv_type"])[0])
+    steps = sorted({int(k.split("_")[2][4:]) for k in d if k.startswith("c2_u_step")})
+    for st in steps:
+        for rk in range(nstage):
+            hfx.CalcResidual_blocks(blocks, F)
+            if st == 0 and rk == 0:
+                for key, arr in GPU_ARRAYS.items():
+                    for c in classes:
+                        k = "c%d_%s" % (c, key)
+                        if k in d:
+                            tol = 5e-11 if "div" in key else 1e-12
+                            assert relerr(E[c].download(getattr(hfx, arr)), d[k]) < tol, k
+                    for c in classes:  # calculate_corrected_divergence leaves norm_tconf - norm_tdisf in place (src/eles.cpp:1746)
+                        k = "c%d_s0_norm_tconf_fpts" % c
+                        if k in d:
+                            assert relerr(E[c].download(hfx.NORM_TCONF_FPTS), d[k] - d["c%d_s0_norm_tdisf_fpts" % c]) < 1e-11, k
+            for c in classes:
+                E[c].AdvanceSolution(rk, adv)
+            for c in classes:
+                k = "c%d_u_step%d_stage%d" % (c, st, rk)
+                if k in d:
+                    assert relerr(E[c].download(hfx.DISU_UPTS0), d[k]) < 1e-11, k
+    for c in classes:
+        assert E[c].check_nan() == -1
+    for f in F:
+        f.close()
+    for c in classes:
+        E[c].close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_run_steps_blocks_vs_reference():
+    """the whole RK loop over both element blocks inside the library (hfx_run_steps_blocks, per-method path)"""
+    import hfx
+    d = dict(np.load(os.path.join(GOLDEN, "mixed_p3_channel.npz")))
+    ctx = hfx.Context(0)
+    classes, E, F = build_gpu(ctx, d)
+    hfx.run_steps_blocks([E[c] for c in classes], F, 1, fused=0)
+    nstage = int(d["c2_sizes"][7])
+    for c in classes:
+        assert relerr(E[c].download(hfx.DISU_UPTS0), d["c%d_u_step0_stage%d" % (c, nstage - 1)]) < 1e-11
+    for f in F:
+        f.close()
+    for c in classes:
+        E[c].close()
+    ctx.close()
