@@ -1,0 +1,871 @@
+// general.hip -- the fused RK stage for GENERAL (non-tensor-product) element classes: tetrahedra, triangular prisms.
+//
+// Reference side: the same 17 calls of CalcResidual + AdvanceSolution as everywhere (/root/reference/src/solver.cpp:50-223,
+// src/HiFiLES.cpp:201-217); on these classes the seven operators (src/eles.cpp:3074-3596, built by src/eles_tets.cpp and
+// src/eles_pris.cpp) are DENSE -- P3: 40 x 20 / 20 x 20 / 20 x 40 doubles on tetrahedra, 68 x 40 / 40 x 40 / 40 x 68 on
+// prisms -- so the per-method path is a stream of 15+ dense GEMM and point kernels per stage (820 B per DOF-update).
+// Here the stage is cut at the two places where data must cross elements, exactly like the split stage of the
+// tensor-product classes (fused_hex.hip, fused = 3), and is FOUR launches per element block and stage:
+//
+//   gface_delta_kernel   thread per interior flux-point pair: LDG common solution -> delta_disu_fpts (both sides, which
+//                        may belong to different element blocks: prism | tetrahedron faces)
+//   general_flux_kernel  workgroup per batch of 16 elements: corrected gradient at the solution points
+//                        (opp_4, opp_5), its extrapolation to the flux points (opp_6), both point physics blocks, the
+//                        discontinuous divergence (opp_2) and normal flux (opp_1); leaves div_tdisf, norm_tdisf and
+//                        each side's viscous flux projected on its own normal (Fn, 5 instead of 15 doubles per point)
+//   gface_flux_kernel    thread per pair: Riemann + LDG common flux from u and Fn of both sides -> norm_tconf
+//   general_update_kernel  batch of 16 elements: opp_3 (norm_tconf - norm_tdisf), RK update, opp_0 of the new state
+//
+// Contractions run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).  A batch is 16 elements because 16 is the tile
+// edge: the MFMA's "row" index is the ELEMENT of the batch, its "column" index an operator row, so one instruction
+// applies 16 operator rows to 16 elements for 4 operator columns.  An accumulator register then holds 16 consecutive
+// operator rows of one element: results go to HBM as 128-byte runs straight from the registers, and the flux-point
+// physics is evaluated on the accumulators without a trip through LDS.  Operators are zero-padded on the host to
+// (16 m') x (4 k') so that no tile needs a bounds check on its loads; they are the same ~100-300 kB for every workgroup
+// and stay cache resident.  Element data sits in LDS as [operator column k][16 elements] planes (one per field /
+// field x dimension) with the element index XOR-swizzled by the row: operand reads, accumulator writes and the
+// point-wise passes are all bank-conflict free.
+#include "general.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "physics.hpp"
+
+namespace hfx
+{
+
+typedef double g_f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB = 16; // elements per batch = MFMA tile edge
+
+struct GeneralData
+{
+  int KU = 0, KF = 0, MU = 0, MF = 0; // n_upts / n_fpts padded to 4 (contraction length) and to 16 (output rows)
+  // zero-padded operators, column-major with leading dimension M*: o4/o5/o2 (MU rows), o6/o1/o0 (MF rows), o3 (MU rows)
+  double *o0 = nullptr, *o1[3] = {}, *o2[3] = {}, *o3 = nullptr, *o4[3] = {}, *o5[3] = {}, *o6 = nullptr;
+  unsigned char *meta = nullptr; // (n_fpts, n_eles): bit1 beta sign flipped (LEFT point of a pair), bit2 boundary point
+  double *disu_alt = nullptr;    // second disu_fpts buffer (the update kernel writes the new state's flux-point solution)
+  double *fn_fpts = nullptr;     // (n_fpts, n_eles, n_fields) viscous flux projected on the point's own normal
+  bool any_bdy = false;
+  bool built = false;
+};
+
+void general_invalidate(hfx_eles *e)
+{
+  if (e && e->general) ((GeneralData *)e->general)->built = false;
+}
+
+void general_destroy(hfx_eles *e)
+{
+  if (!e || !e->general) return;
+  GeneralData *g = (GeneralData *)e->general;
+  void *p[] = {g->o0, g->o1[0], g->o1[1], g->o1[2], g->o2[0], g->o2[1], g->o2[2], g->o3, g->o4[0], g->o4[1], g->o4[2],
+               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts};
+  for (void *q : p)
+    if (q) (void)hipFree(q);
+  delete g;
+  e->general = nullptr;
+}
+
+// LDS plane [row][16 elements], the element index swizzled by the row
+__device__ __forceinline__ int sw(int row, int col) { return row * GB + (col ^ (row & 15)); }
+
+// g_phys(d) = sum_l (inv_detjac * g_ref(l)) * JGinv(l,d)   (BLAS=NO branch of src/eles.cpp:1975-1979)
+__device__ __forceinline__ void g_to_physical(const double inv_detjac, const double (&JG)[9], const double (&tg)[3], double (&cg)[3])
+{
+#pragma unroll
+  for (int d = 0; d < 3; d++) cg[d] = 0.0;
+#pragma unroll
+  for (int l = 0; l < 3; l++)
+  {
+    const double temp = inv_detjac * tg[l];
+#pragma unroll
+    for (int d = 0; d < 3; d++) cg[d] += temp * JG[l + 3 * d];
+  }
+}
+
+struct GenArgs
+{
+  int n_eles, nu, nfp, KU, KF, MU, MF;
+  const double *o0, *o1[3], *o2[3], *o3, *o4[3], *o5[3], *o6;
+  const double *u0, *delta, *disu;
+  const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts, *norm_fpts;
+  const unsigned char *meta;
+  double *div, *ntd, *fn, *grad_fpts; // grad_fpts: boundary points only (NULL: no boundary faces / inviscid)
+  Phys P;
+  // update kernel
+  double *u0w, *u1;
+  const double *tconf, *div_in, *src, *dt_local;
+  double *disu_next;
+  unsigned long long *nan_flag;
+  int adv_type, in_step, dt_local_on, write_div, need_u1;
+  double dt, rk_a, rk_b;
+};
+
+// one 16 x 16 output tile: acc += op[rt*16 + (0..15)][k0 .. k0 + 4 ksteps) . plane[k][16 elements]
+// op: zero-padded operator, leading dimension M; plane: LDS plane of the data; lane: li = lane & 15, lk = lane >> 4
+__device__ __forceinline__ g_f64x4 tile_mac(g_f64x4 acc, const double *__restrict__ op, int M, int rt, const double *plane, int ksteps,
+                                            int li, int lk)
+{
+  const double *ap = op + rt * 16 + li + (long)M * lk;
+
+  for (int s = 0; s < ksteps; s++)
+  {
+    const double av = ap[(long)M * 4 * s];
+    const double bv = plane[sw(4 * s + lk, li)];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// flux kernel: u, delta -> div_tdisf, norm_tdisf, Fn   (steps 3-4, 8 (both halves), 10-12 of CalcResidual's sequence)
+// ---------------------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a)
+{
+  constexpr int NF = 5, ND = 3, T = 64 * W;
+  extern __shared__ double lds[];
+  const int nu = a.nu, nfp = a.nfp, KU = a.KU, KF = a.KF;
+  double *U = lds;                 // [NF][KU][16]      the state; later: nothing
+  double *D = U + NF * KU * GB;    // [NF][KF][16]      delta_disu_fpts
+  double *G = D + NF * KF * GB;    // [NF*ND][KU][16]   reference-space gradient, then the transformed total flux
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const long e0 = (long)blockIdx.x * GB;
+  const int nval = (int)min((long)GB, a.n_eles - e0);
+  const long plane_u = (long)nu * a.n_eles, plane_f = (long)nfp * a.n_eles;
+  const bool visc = a.P.viscous != 0;
+
+  // ---- P0: stage the state (and delta) of the batch: contiguous nu x 16 doubles per field in HBM -> [k][element]
+  for (int f = 0; f < NF; f++)
+  {
+    const double *src = a.u0 + e0 * nu + f * plane_u;
+    for (int q = tid; q < KU * GB; q += T)
+    {
+      const int el = q / nu, k = q - el * nu; // q < nu*16: a real entry; the rest of the plane: K padding
+      if (q < nu * GB)
+        U[f * KU * GB + sw(k, el)] = (el < nval) ? src[q] : 0.0;
+      else
+      {
+        const int p = q - nu * GB; // (KU - nu) * 16 padding entries
+        U[f * KU * GB + sw(nu + p / GB, p % GB)] = 0.0;
+      }
+    }
+    if (visc)
+    {
+      const double *sd = a.delta + e0 * nfp + f * plane_f;
+      for (int q = tid; q < KF * GB; q += T)
+      {
+        const int el = q / nfp, k = q - el * nfp;
+        if (q < nfp * GB)
+          D[f * KF * GB + sw(k, el)] = (el < nval) ? sd[q] : 0.0;
+        else
+        {
+          const int p = q - nfp * GB;
+          D[f * KF * GB + sw(nfp + p / GB, p % GB)] = 0.0;
+        }
+      }
+    }
+  }
+  // K padding rows of G (read as zero by the opp_6 / opp_1 / opp_2 tiles)
+  for (int q = tid; q < NF * ND * (KU - nu) * GB; q += T)
+  {
+    const int c = q / ((KU - nu) * GB), p = q - c * (KU - nu) * GB;
+    G[c * KU * GB + sw(nu + p / GB, p % GB)] = 0.0;
+  }
+  __syncthreads();
+
+  if (visc)
+  {
+    // ---- P1: reference-space corrected gradient at the solution points (calculate_gradient + first half of
+    //          correct_gradient, src/eles.cpp:1823,1900): G(f,d) = opp_4[d] U(f) + opp_5[d] D(f)
+    const int n_rt = a.MU / 16;
+    for (int it = wave; it < n_rt * ND * NF; it += W)
+    {
+      const int f = it % NF, d = (it / NF) % ND, rt = it / (NF * ND);
+      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      acc = tile_mac(acc, a.o4[d], a.MU, rt, U + f * KU * GB, KU / 4, li, lk);
+      acc = tile_mac(acc, a.o5[d], a.MU, rt, D + f * KF * GB, KF / 4, li, lk);
+      const int row = rt * 16 + li;
+      if (row < nu)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) G[(f + NF * d) * KU * GB + sw(row, lk + 4 * rg)] = acc[rg];
+    }
+    __syncthreads();
+
+    // ---- P2: gradient at the flux points (second half of correct_gradient: opp_6, then the transform with the flux
+    //          points' own metrics, src/eles.cpp:1930,1998) and the viscous flux there, projected on the point's normal
+    const int n_ft = a.MF / 16;
+    for (int rt = wave; rt < n_ft; rt += W)
+    {
+      g_f64x4 acc[NF * ND];
+#pragma unroll
+      for (int c = 0; c < NF * ND; c++) acc[c] = g_f64x4{0.0, 0.0, 0.0, 0.0};
+      const double *ap = a.o6 + rt * 16 + li + (long)a.MF * lk;
+      for (int s = 0; s < KU / 4; s++)
+      {
+        const double av = ap[(long)a.MF * 4 * s];
+        const int o = sw(4 * s + lk, li);
+#pragma unroll
+        for (int c = 0; c < NF * ND; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(G[c * KU * GB + o], av, acc[c], 0, 0, 0);
+      }
+      const int row = rt * 16 + li;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++)
+      {
+        const int el = lk + 4 * rg;
+        if (row < nfp && el < nval)
+        {
+          const long o = row + (long)nfp * (e0 + el);
+          double u[NF], g[NF * ND], JG[9], n[ND], fv[NF * ND];
+#pragma unroll
+          for (int k = 0; k < NF; k++) u[k] = a.disu[o + k * plane_f];
+#pragma unroll
+          for (int q = 0; q < 9; q++) JG[q] = a.JGinv_fpts[o * 9 + q];
+          const double idj = 1.0 / a.detjac_fpts[o];
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+          {
+            double tg[ND], cg[ND];
+#pragma unroll
+            for (int d = 0; d < ND; d++) tg[d] = acc[k + NF * d][rg];
+            g_to_physical(idj, JG, tg, cg);
+#pragma unroll
+            for (int d = 0; d < ND; d++) g[k + NF * d] = cg[d];
+          }
+          if (a.grad_fpts != nullptr && (a.meta[o] & 4)) // boundary point: the boundary kernel reads the gradient
+#pragma unroll
+            for (int c = 0; c < NF * ND; c++) a.grad_fpts[o + c * plane_f] = g[c];
+          calc_visf<ND, true>(a.P, u, g, fv);
+#pragma unroll
+          for (int m = 0; m < ND; m++) n[m] = a.norm_fpts[o + m * plane_f];
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+          {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += fv[k + NF * m] * n[m];
+            a.fn[o + k * plane_f] = s;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- P3: point physics at the solution points (evaluate_invFlux, the transform of correct_gradient, evaluate_viscFlux;
+  //          src/eles.cpp:1415,1973,2285): G(f,d) <- transformed total flux
+  for (int q = tid; q < nu * GB; q += T)
+  {
+    const int el = q / nu, pt = q - el * nu;
+    if (el < nval)
+    {
+      const long o = pt + (long)nu * (e0 + el);
+      const int so = sw(pt, el);
+      double u[NF], JG[9], F[NF * ND];
+#pragma unroll
+      for (int k = 0; k < NF; k++) u[k] = U[k * KU * GB + so];
+#pragma unroll
+      for (int c = 0; c < 9; c++) JG[c] = a.JGinv_upts[o * 9 + c];
+      calc_invf<ND, true>(a.P.gamma, u, F);
+      if (visc)
+      {
+        const double idj = 1.0 / a.detjac_upts[o];
+        double g[NF * ND], fv[NF * ND];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double tg[ND], cg[ND];
+#pragma unroll
+          for (int d = 0; d < ND; d++) tg[d] = G[(k + NF * d) * KU * GB + so];
+          g_to_physical(idj, JG, tg, cg);
+#pragma unroll
+          for (int d = 0; d < ND; d++) g[k + NF * d] = cg[d];
+        }
+        calc_visf<ND, true>(a.P, u, g, fv);
+#pragma unroll
+        for (int c = 0; c < NF * ND; c++) F[c] += fv[c];
+      }
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+        {
+          double t = 0.0;
+#pragma unroll
+          for (int m = 0; m < ND; m++) t += JG[l + ND * m] * F[k + NF * m];
+          G[(k + NF * l) * KU * GB + so] = t;
+        }
+    }
+    else
+    {
+      const int pt2 = q - el * nu, so = sw(pt2, el);
+#pragma unroll
+      for (int c = 0; c < NF * ND; c++) G[c * KU * GB + so] = 0.0;
+    }
+  }
+  __syncthreads();
+
+  // ---- P4: discontinuous divergence (opp_2) and normal flux at the flux points (opp_1), summed over the dimensions
+  //          (calculate_divergence, extrapolate_totalFlux; src/eles.cpp:1651,1549) -> HBM, 128-byte runs
+  {
+    const int n_ut = a.MU / 16, n_ft = a.MF / 16;
+    for (int it = wave; it < (n_ut + n_ft) * NF; it += W)
+    {
+      const int f = it % NF, t = it / NF;
+      const bool is_div = t < n_ut;
+      const int rt = is_div ? t : t - n_ut;
+      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int d = 0; d < ND; d++)
+        acc = tile_mac(acc, is_div ? a.o2[d] : a.o1[d], is_div ? a.MU : a.MF, rt, G + (f + NF * d) * KU * GB, KU / 4, li, lk);
+      const int row = rt * 16 + li, n = is_div ? nu : nfp;
+      double *out = is_div ? a.div + f * plane_u : a.ntd + f * plane_f;
+      if (row < n)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+        {
+          const int el = lk + 4 * rg;
+          if (el < nval) out[row + (long)n * (e0 + el)] = acc[rg];
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// update kernel: div_tdisf + opp_3 (norm_tconf - norm_tdisf) -> RK update -> disu_fpts of the new state
+// (calculate_corrected_divergence, AdvanceSolution, extrapolate_solution; src/eles.cpp:1738,1080,1360)
+// ---------------------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
+{
+  constexpr int NF = 5, T = 64 * W;
+  extern __shared__ double lds[];
+  const int nu = a.nu, nfp = a.nfp, KU = a.KU, KF = a.KF;
+  double *X = lds;               // [NF][KF][16]  norm_tconf - norm_tdisf
+  double *S = X + NF * KF * GB;  // [NF][KU][16]  the correction, then the new state
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const long e0 = (long)blockIdx.x * GB;
+  const int nval = (int)min((long)GB, a.n_eles - e0);
+  const long plane_u = (long)nu * a.n_eles, plane_f = (long)nfp * a.n_eles;
+
+  for (int f = 0; f < NF; f++)
+  {
+    const double *tc = a.tconf + e0 * nfp + f * plane_f, *nt = a.ntd + e0 * nfp + f * plane_f;
+    for (int q = tid; q < KF * GB; q += T)
+    {
+      const int el = q / nfp, k = q - el * nfp;
+      if (q < nfp * GB)
+        X[f * KF * GB + sw(k, el)] = (el < nval) ? tc[q] + -1.0 * nt[q] : 0.0; // the daxpy of src/eles.cpp:1746
+      else
+      {
+        const int p = q - nfp * GB;
+        X[f * KF * GB + sw(nfp + p / GB, p % GB)] = 0.0;
+      }
+    }
+    for (int q = tid; q < (KU - nu) * GB; q += T) S[f * KU * GB + sw(nu + q / GB, q % GB)] = 0.0;
+  }
+  __syncthreads();
+  {
+    const int n_rt = a.MU / 16;
+    for (int it = wave; it < n_rt * NF; it += W)
+    {
+      const int f = it % NF, rt = it / NF;
+      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      acc = tile_mac(acc, a.o3, a.MU, rt, X + f * KF * GB, KF / 4, li, lk);
+      const int row = rt * 16 + li;
+      if (row < nu)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) S[f * KU * GB + sw(row, lk + 4 * rg)] = acc[rg];
+    }
+  }
+  __syncthreads();
+  for (int f = 0; f < NF; f++)
+  {
+    for (int q = tid; q < nu * GB; q += T)
+    {
+      const int el = q / nu, pt = q - el * nu;
+      const int so = f * KU * GB + sw(pt, el);
+      if (el >= nval)
+      {
+        S[so] = 0.0;
+        continue;
+      }
+      const long p = e0 * nu + q, ok = p + f * plane_u;
+      const double dv = a.div_in[ok] + S[so];
+      if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)ok);
+      if (a.write_div) a.div[ok] = dv;
+      const double s = a.src ? a.src[ok] : 0.0;
+      const double dt = a.dt_local_on ? a.dt_local[e0 + el] : a.dt;
+      const double dd = dv / a.detjac_upts[p];
+      double un = a.u0w[ok];
+      const double u1v = a.need_u1 ? a.u1[ok] : 0.0;
+      if (a.adv_type == 0)
+        un -= dt * (dd - s);
+      else if (a.adv_type == 1)
+      {
+        if (a.in_step == 0) a.u1[ok] = un;
+        if (a.in_step < 3)
+          un -= dt / 3.0 * (dd - s);
+        else
+        {
+          const double rhs = -dd + s;
+          un = 3.0 / 4.0 * un + 1.0 / 4.0 * u1v + dt / 4.0 * rhs;
+        }
+      }
+      else if (a.adv_type == 2)
+      {
+        if (a.in_step == 0) a.u1[ok] = un;
+        if (a.in_step < 2 || a.in_step == 3)
+          un -= dt / 2.0 * (dd - s);
+        else if (a.in_step == 2)
+        {
+          const double rhs = -dd + s;
+          un = 1.0 / 3.0 * un + 2.0 / 3.0 * u1v + dt / 6.0 * rhs;
+        }
+      }
+      else
+      {
+        const double rhs = -dd + s;
+        const double r1 = a.rk_a * u1v + dt * rhs;
+        a.u1[ok] = r1;
+        un += a.rk_b * r1;
+      }
+      a.u0w[ok] = un;
+      S[so] = un;
+    }
+  }
+  __syncthreads();
+  {
+    const int n_ft = a.MF / 16;
+    for (int it = wave; it < n_ft * NF; it += W)
+    {
+      const int f = it % NF, rt = it / NF;
+      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      acc = tile_mac(acc, a.o0, a.MF, rt, S + f * KU * GB, KU / 4, li, lk);
+      const int row = rt * 16 + li;
+      if (row < nfp)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+        {
+          const int el = lk + 4 * rg;
+          if (el < nval) a.disu_next[row + (long)nfp * (e0 + el) + f * plane_f] = acc[rg];
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairwise face kernels; the two sides of a block may belong to different element blocks
+// ---------------------------------------------------------------------------------------------------------------
+struct GFaceArgs
+{
+  long npairs;
+  const int *L, *R;
+  const unsigned char *meta_l; // bit1 of the LEFT point: beta sign flipped (the switch of src/inters.cpp:568-581,620-633)
+  long plane_l, plane_r;
+  const double *disu_l, *disu_r, *fn_l, *fn_r, *norm_l, *tdA_l, *tdA_r;
+  double *delta_l, *delta_r, *tconf_l, *tconf_r;
+  Phys P;
+};
+
+__global__ __launch_bounds__(256) void gface_delta_kernel(const GFaceArgs a)
+{
+  constexpr int NF = 5;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long il = a.L[q], ir = a.R[q];
+  const double beta = (a.meta_l[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    const double ul = a.disu_l[il + k * a.plane_l], ur = a.disu_r[ir + k * a.plane_r];
+    const double uc = 0.5 * (ul + ur) - beta * (ul - ur); // src/inters.cpp:637
+    a.delta_l[il + k * a.plane_l] = uc - ul;
+    a.delta_r[ir + k * a.plane_r] = uc - ur;
+  }
+}
+
+template <int RS>
+__global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
+{
+  constexpr int NF = 5, ND = 3;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long il = a.L[q], ir = a.R[q];
+  double ul[NF], ur[NF], n[ND], fn[NF];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ul[k] = a.disu_l[il + k * a.plane_l];
+    ur[k] = a.disu_r[ir + k * a.plane_r];
+  }
+#pragma unroll
+  for (int m = 0; m < ND; m++) n[m] = a.norm_l[il + m * a.plane_l];
+  const double tl = a.tdA_l[il], tr = a.tdA_r[ir];
+  riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
+  if (a.P.viscous)
+  {
+    const double beta = (a.meta_l[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      // (1/2+b) F_L.n + (1/2-b) F_R.n - tau (u_R - u_L), n the left normal = -(right normal)
+      double fv = (0.5 + beta) * a.fn_l[il + k * a.plane_l] - (0.5 - beta) * a.fn_r[ir + k * a.plane_r];
+      fv -= a.P.ldg_tau * (ur[k] - ul[k]);
+      a.tconf_l[il + k * a.plane_l] = fn[k] * tl + fv * tl;
+      a.tconf_r[ir + k * a.plane_r] = -fn[k] * tr + -fv * tr;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      a.tconf_l[il + k * a.plane_l] = fn[k] * tl;
+      a.tconf_r[ir + k * a.plane_r] = -fn[k] * tr;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+// the consistent switch of src/inters.cpp:568-581 on the LEFT normal (exact zero tests), as physics.hpp's ldg_switch
+static double ldg_switch_host(double beta, const double (&n)[3])
+{
+  if (n[0] < 0.0)
+    beta = -beta;
+  else if (n[0] == 0.0)
+  {
+    if ((n[0] + n[1]) < 0.0)
+      beta = -beta;
+    else if ((n[0] + n[1]) == 0.0)
+    {
+      if ((n[0] + n[2]) < 0.0) beta = -beta;
+    }
+  }
+  return beta;
+}
+
+static int padded_operator(double **dst, const Operator &op, int M, int K)
+{
+  HFX_CHECK(op.present(), "general fused stage: an operator is missing");
+  std::vector<double> h((size_t)op.m * op.k), p((size_t)M * K, 0.0);
+  HFX_HIP(hipMemcpy(h.data(), op.dense, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+  for (int c = 0; c < op.k; c++)
+    for (int r = 0; r < op.m; r++) p[r + (size_t)M * c] = h[r + (size_t)op.m * c];
+  if (*dst) (void)hipFree(*dst);
+  HFX_HIP(hipMalloc((void **)dst, sizeof(double) * p.size()));
+  HFX_HIP(hipMemcpy(*dst, p.data(), sizeof(double) * p.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static size_t flux_lds_bytes(const GeneralData *g) { return sizeof(double) * GB * (5 * g->KU + 5 * g->KF + 15 * g->KU); }
+static size_t update_lds_bytes(const GeneralData *g) { return sizeof(double) * GB * (5 * g->KF + 5 * g->KU); }
+
+static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
+{
+  HFX_CHECK(e->n_dims == 3 && e->n_fields == 5, "general fused stage: three-dimensional Navier-Stokes / Euler blocks only");
+  HFX_CHECK(!e->les_ready && !e->over_int_ready && !e->shock_ready, "general fused stage: LES, over-integration and shock capturing run per method");
+  const bool visc = e->ctx->params.viscous != 0;
+  HFX_CHECK(!visc || e->viscous_ops, "general fused stage: viscous run but the block has no opp_4/5/6");
+  if (!e->general) e->general = new GeneralData();
+  GeneralData *g = (GeneralData *)e->general;
+  const int nu = e->n_upts, nfp = e->n_fpts;
+  g->KU = (nu + 3) & ~3; g->KF = (nfp + 3) & ~3; g->MU = (nu + 15) & ~15; g->MF = (nfp + 15) & ~15;
+  HFX_CHECK(flux_lds_bytes(g) <= 160 * 1024, "general fused stage: a batch of this element class (%d solution, %d flux points) does not fit LDS", nu, nfp);
+  if (padded_operator(&g->o0, e->opp_0, g->MF, g->KU) || padded_operator(&g->o3, e->opp_3, g->MU, g->KF)) return 1;
+  for (int d = 0; d < 3; d++)
+    if (padded_operator(&g->o1[d], e->opp_1[d], g->MF, g->KU) || padded_operator(&g->o2[d], e->opp_2[d], g->MU, g->KU)) return 1;
+  if (visc)
+  {
+    if (padded_operator(&g->o6, e->opp_6, g->MF, g->KU)) return 1;
+    for (int d = 0; d < 3; d++)
+      if (padded_operator(&g->o4[d], e->opp_4[d], g->MU, g->KU) || padded_operator(&g->o5[d], e->opp_5[d], g->MU, g->KF)) return 1;
+  }
+  // per flux point: the LDG switch of the pair it is the LEFT point of (exact tests on the left normal, decided once),
+  // and whether a boundary face owns it; every flux point must belong to exactly one registered face
+  const long plane_f = (long)nfp * e->n_eles;
+  std::vector<unsigned char> meta(plane_f, 0);
+  std::vector<char> owned(plane_f, 0);
+  std::vector<double> norm((size_t)plane_f * 3);
+  HFX_HIP(hipMemcpy(norm.data(), e->norm_fpts, sizeof(double) * norm.size(), hipMemcpyDeviceToHost));
+  g->any_bdy = false;
+  for (int b = 0; b < nfb; b++)
+  {
+    hfx_inters *f = faces[b];
+    HFX_CHECK(!f->is_mpi, "general fused stage: partition faces are not part of it (run per method)");
+    if (f->is_bdy)
+    {
+      if (f->left != e) continue;
+      g->any_bdy = true;
+      for (int o : f->hL) { meta[o] |= 4; owned[o] = 1; }
+      continue;
+    }
+    const long np = (long)f->n_inters * f->n_fpts_per_inter;
+    if (f->left == e)
+      for (long q = 0; q < np; q++)
+      {
+        const int il = f->hL[q];
+        owned[il] = 1;
+        const double n[3] = {norm[il], norm[il + plane_f], norm[il + 2 * plane_f]};
+        if (ldg_switch_host(1.0, n) < 0) meta[il] |= 2;
+      }
+    if (f->right == e)
+      for (long q = 0; q < np; q++) owned[f->hR[q]] = 1;
+  }
+  for (long o = 0; o < plane_f; o++) HFX_CHECK(owned[o], "general fused stage: flux point %ld belongs to no registered face", o);
+  if (g->meta) (void)hipFree(g->meta);
+  HFX_HIP(hipMalloc((void **)&g->meta, (size_t)plane_f));
+  HFX_HIP(hipMemcpy(g->meta, meta.data(), (size_t)plane_f, hipMemcpyHostToDevice));
+  if (!g->disu_alt) HFX_HIP(hipMalloc((void **)&g->disu_alt, sizeof(double) * plane_f * e->n_fields));
+  if (!g->fn_fpts) HFX_HIP(hipMalloc((void **)&g->fn_fpts, sizeof(double) * plane_f * e->n_fields));
+  g->built = true;
+  return 0;
+}
+
+static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
+{
+  GeneralData *g = (GeneralData *)e->general;
+  const hfx_params &p = e->ctx->params;
+  GenArgs a{};
+  a.n_eles = e->n_eles; a.nu = e->n_upts; a.nfp = e->n_fpts; a.KU = g->KU; a.KF = g->KF; a.MU = g->MU; a.MF = g->MF;
+  a.o0 = g->o0; a.o3 = g->o3; a.o6 = g->o6;
+  for (int d = 0; d < 3; d++) { a.o1[d] = g->o1[d]; a.o2[d] = g->o2[d]; a.o4[d] = g->o4[d]; a.o5[d] = g->o5[d]; }
+  a.u0 = e->arr[HFX_DISU_UPTS0]; a.delta = e->arr[HFX_DELTA_DISU_FPTS]; a.disu = e->arr[HFX_DISU_FPTS];
+  a.detjac_upts = e->detjac_upts; a.JGinv_upts = e->JGinv_upts; a.detjac_fpts = e->detjac_fpts; a.JGinv_fpts = e->JGinv_fpts;
+  a.norm_fpts = e->norm_fpts; a.meta = g->meta;
+  a.div = e->arr[HFX_DIV_TCONF_UPTS]; a.ntd = e->arr[HFX_NORM_TDISF_FPTS]; a.fn = g->fn_fpts;
+  a.grad_fpts = (g->any_bdy && p.viscous) ? e->arr[HFX_GRAD_DISU_FPTS] : nullptr;
+  a.P = e->ctx->phys();
+  a.u0w = e->arr[HFX_DISU_UPTS0]; a.u1 = e->arr[HFX_DISU_UPTS1];
+  a.tconf = e->arr[HFX_NORM_TCONF_FPTS]; a.div_in = e->arr[HFX_DIV_TCONF_UPTS];
+  a.src = e->src_nonzero ? e->arr[HFX_SRC_UPTS] : nullptr;
+  a.dt_local = e->arr[HFX_DT_LOCAL];
+  a.disu_next = g->disu_alt;
+  a.nan_flag = e->nan_flag;
+  a.adv_type = p.adv_type; a.in_step = in_step; a.dt_local_on = p.dt_type == 2; a.dt = p.dt;
+  a.rk_a = (p.adv_type >= 3) ? p.RK_a[in_step] : 0.0;
+  a.rk_b = (p.adv_type >= 3) ? p.RK_b[in_step] : 0.0;
+  a.need_u1 = (p.adv_type >= 3) || (p.adv_type == 1 && in_step == 3) || (p.adv_type == 2 && in_step == 2);
+  a.write_div = 1; // the flux kernel left the discontinuous part there: always complete it (the monitors read it)
+  (void)last_stage;
+  return a;
+}
+
+static GFaceArgs gface_args(hfx_inters *f)
+{
+  hfx_eles *l = f->left, *r = f->right;
+  GeneralData *gl = (GeneralData *)l->general, *gr = (GeneralData *)r->general;
+  GFaceArgs a{};
+  a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
+  a.L = f->L; a.R = f->R; a.meta_l = gl->meta;
+  a.plane_l = (long)l->n_fpts * l->n_eles; a.plane_r = (long)r->n_fpts * r->n_eles;
+  a.disu_l = l->arr[HFX_DISU_FPTS]; a.disu_r = r->arr[HFX_DISU_FPTS];
+  a.fn_l = gl->fn_fpts; a.fn_r = gr->fn_fpts;
+  a.norm_l = l->norm_fpts; a.tdA_l = l->tdA_fpts; a.tdA_r = r->tdA_fpts;
+  a.delta_l = l->arr[HFX_DELTA_DISU_FPTS]; a.delta_r = r->arr[HFX_DELTA_DISU_FPTS];
+  a.tconf_l = l->arr[HFX_NORM_TCONF_FPTS]; a.tconf_r = r->arr[HFX_NORM_TCONF_FPTS];
+  a.P = l->ctx->phys();
+  return a;
+}
+
+template <int W>
+static int launch_element_kernels(hfx_eles *e, const GenArgs &a, bool flux)
+{
+  GeneralData *g = (GeneralData *)e->general;
+  const unsigned grid = (unsigned)((e->n_eles + GB - 1) / GB);
+  hipStream_t st = e->ctx->stream;
+  if (flux)
+  {
+    const size_t lds = flux_lds_bytes(g);
+    static size_t configured = 0;
+    if (lds > configured)
+    {
+      HFX_HIP(hipFuncSetAttribute((const void *)general_flux_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+    hipLaunchKernelGGL(general_flux_kernel<W>, dim3(grid), dim3(64 * W), lds, st, a);
+  }
+  else
+  {
+    const size_t lds = update_lds_bytes(g);
+    static size_t configured = 0;
+    if (lds > configured)
+    {
+      HFX_HIP(hipFuncSetAttribute((const void *)general_update_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+    hipLaunchKernelGGL(general_update_kernel<W>, dim3(grid), dim3(64 * W), lds, st, a);
+  }
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+// which: 0 the whole stage, 1 .. 4 one of its four parts (for the per-kernel timing)
+static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool last_stage, int which)
+{
+  hfx_ctx *ctx = eles[0]->ctx;
+  const Phys P = ctx->phys();
+  hipStream_t st = ctx->stream;
+  if (P.viscous && (which == 0 || which == 1))
+    for (int b = 0; b < nfb; b++)
+    {
+      if (faces[b]->is_bdy)
+      {
+        if (hfx_bdy_launch_internal(faces[b], 0, 1)) return 1; // ghost state -> inviscid common flux, LDG common solution
+        continue;
+      }
+      const GFaceArgs a = gface_args(faces[b]);
+      if (a.npairs == 0) continue;
+      hipLaunchKernelGGL(gface_delta_kernel, dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
+    }
+  if (which == 0 || which == 2)
+    for (int i = 0; i < neb; i++)
+    {
+      const GenArgs a = gen_args(eles[i], in_step, last_stage);
+      // two workgroups per CU where the batch's LDS image allows it (4 waves each), otherwise one of 8 waves
+      if (flux_lds_bytes((GeneralData *)eles[i]->general) <= 80 * 1024 ? launch_element_kernels<4>(eles[i], a, true)
+                                                                        : launch_element_kernels<8>(eles[i], a, true))
+        return 1;
+    }
+  if (which == 0 || which == 3)
+    for (int b = 0; b < nfb; b++)
+    {
+      if (faces[b]->is_bdy)
+      {
+        if (hfx_bdy_launch_internal(faces[b], P.viscous ? 1 : 0, 1)) return 1;
+        continue;
+      }
+      const GFaceArgs a = gface_args(faces[b]);
+      if (a.npairs == 0) continue;
+      const dim3 grid((unsigned)((a.npairs + 255) / 256));
+      if (P.riemann == 0)
+        hipLaunchKernelGGL(gface_flux_kernel<0>, grid, dim3(256), 0, st, a);
+      else if (P.riemann == 2)
+        hipLaunchKernelGGL(gface_flux_kernel<2>, grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL(gface_flux_kernel<3>, grid, dim3(256), 0, st, a);
+    }
+  if (which == 0 || which == 4)
+  {
+    for (int i = 0; i < neb; i++)
+    {
+      const GenArgs a = gen_args(eles[i], in_step, last_stage);
+      if (launch_element_kernels<4>(eles[i], a, false)) return 1;
+    }
+    for (int i = 0; i < neb; i++) std::swap(eles[i]->arr[HFX_DISU_FPTS], ((GeneralData *)eles[i]->general)->disu_alt);
+  }
+  HFX_HIP(hipGetLastError());
+  return 0;
+}
+
+static int general_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb)
+{
+  hfx_ctx *ctx = eles[0]->ctx;
+  for (int i = 0; i < neb; i++)
+  {
+    HFX_CHECK(eles[i] && eles[i]->ctx == ctx, "element blocks of different contexts");
+    HFX_CHECK(eles[i]->n_eles > 0, "general fused stage: empty element block");
+  }
+  for (int b = 0; b < nfb; b++)
+  {
+    bool l = false, r = faces[b]->right == nullptr;
+    for (int i = 0; i < neb; i++)
+    {
+      l = l || faces[b]->left == eles[i];
+      r = r || faces[b]->right == eles[i];
+    }
+    HFX_CHECK(l && r, "face block %d refers to an element block that is not part of this call", b);
+  }
+  for (int i = 0; i < neb; i++)
+  {
+    GeneralData *g = (GeneralData *)eles[i]->general;
+    if (!g || !g->built)
+      if (general_build(eles[i], faces, nfb)) return 1;
+  }
+  return 0;
+}
+
+int general_run_steps(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int n_steps)
+{
+  if (general_prepare(eles, neb, faces, nfb)) return 1;
+  if (n_steps <= 0) return 0;
+  hfx_ctx *ctx = eles[0]->ctx;
+  const int adv = ctx->params.adv_type;
+  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
+  // disu_fpts of the current state (the caller may have changed disu_upts since the last call)
+  for (int i = 0; i < neb; i++)
+    if (hfx_eles_extrapolate_solution(eles[i])) return 1;
+  for (int s = 0; s < n_steps; s++)
+  {
+    if (ctx->params.dt_type != 0)
+    {
+      double dt_min = 1e12;
+      for (int i = 0; i < neb; i++)
+      {
+        if (calc_time_step(eles[i], nullptr)) return 1; /* src/HiFiLES.cpp:198 */
+        dt_min = std::min(dt_min, ctx->params.dt);
+      }
+      ctx->params.dt = dt_min;
+    }
+    for (int rk = 0; rk < nst; rk++)
+      if (general_stage(eles, neb, faces, nfb, rk, rk == nst - 1, 0)) return 1;
+    advance_ramp_counters(faces, nfb); /* src/HiFiLES.cpp:224-225 */
+  }
+  return 0;
+}
+
+int general_time_kernels(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int reps, double *ms)
+{
+  if (general_prepare(eles, neb, faces, nfb)) return 1;
+  hfx_ctx *ctx = eles[0]->ctx;
+  const int adv = ctx->params.adv_type;
+  const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
+  hipStream_t st = ctx->stream;
+  hipEvent_t ev[5];
+  for (auto &x : ev) HFX_HIP(hipEventCreate(&x));
+  for (int i = 0; i < neb; i++)
+    if (hfx_eles_extrapolate_solution(eles[i])) return 1;
+  double acc[4] = {0, 0, 0, 0};
+  for (int r = 0; r < reps; r++)
+  {
+    const int rk = r % nst;
+    for (int w = 1; w <= 4; w++)
+    {
+      HFX_HIP(hipEventRecord(ev[w - 1], st));
+      if (general_stage(eles, neb, faces, nfb, rk, rk == nst - 1, w)) return 1;
+    }
+    HFX_HIP(hipEventRecord(ev[4], st));
+    HFX_HIP(hipStreamSynchronize(st));
+    for (int w = 0; w < 4; w++)
+    {
+      float t = 0;
+      HFX_HIP(hipEventElapsedTime(&t, ev[w], ev[w + 1]));
+      acc[w] += t;
+    }
+  }
+  for (auto &x : ev) (void)hipEventDestroy(x);
+  for (int i = 0; i < 8; i++) ms[i] = (i < 4) ? acc[i] / reps : 0.0;
+  return 0;
+}
+
+// ALGORITHMIC HBM bytes per launch of the four kernels, summed over the element blocks (doubles listed per element)
+void general_kernel_bytes(hfx_eles *const *eles, int neb, double *bytes)
+{
+  for (int i = 0; i < 8; i++) bytes[i] = 0.0;
+  for (int i = 0; i < neb; i++)
+  {
+    const hfx_eles *e = eles[i];
+    const double nu = e->n_upts, nfp = e->n_fpts, nf = e->n_fields, nd = e->n_dims, ne = e->n_eles;
+    bytes[0] += ne * (8.0 * (2 * nfp * nf) + 4.0 * nfp + nfp * 0.5);                                        // disu r, delta w, index + meta
+    bytes[1] += ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nd + nfp * nf // u, delta, metrics, normals, disu r
+                            + nu * nf + 2 * nfp * nf);                                                       // div, norm_tdisf, Fn w
+    bytes[2] += ne * (8.0 * (nfp * nf + nfp * nf + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp);            // disu, Fn, normal(left), tdA r; tconf w
+    bytes[3] += ne * 8.0 * (3 * nu * nf + nu + 2 * nfp * nf + 3 * nu * nf + nfp * nf);                       // u0,u1,div,detjac,tconf,ntd r; u0,u1,div,disu w
+  }
+}
+
+} // namespace hfx

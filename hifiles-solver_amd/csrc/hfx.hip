@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "fused_hex.hpp"
+#include "general.hpp"
 #include "tensor_ops.hpp"
 #include "hfx_internal.hpp"
 #include "kernels_ops.hpp"
@@ -478,6 +479,7 @@ int hfx_eles_destroy(hfx_eles *e)
   if (e->nan_flag) (void)hipFree(e->nan_flag);
   if (e->red_buf) (void)hipFree(e->red_buf);
   fused_destroy(e);
+  general_destroy(e);
   delete e;
   return 0;
 }
@@ -749,6 +751,8 @@ int hfx_int_inters_create(hfx_ctx *ctx, hfx_eles *left, hfx_eles *right, int n_i
   if (right != left) right->faces_attached.push_back(f);
   fused_invalidate(left);
   fused_invalidate(right);
+  general_invalidate(left);
+  general_invalidate(right);
   *out = f;
   return 0;
 }
@@ -762,6 +766,7 @@ int hfx_inters_destroy(hfx_inters *f)
       auto &v = e->faces_attached;
       v.erase(std::remove(v.begin(), v.end(), f), v.end());
       fused_invalidate(e);
+      general_invalidate(e);
     }
   if (f->L) (void)hipFree(f->L);
   if (f->R) (void)hipFree(f->R);
@@ -1122,6 +1127,7 @@ int hfx_bdy_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, 
   HFX_HIP(hipMemcpy(f->bcs, bcs, sizeof(hfx_bc) * (size_t)n_bcs, hipMemcpyHostToDevice));
   left->faces_attached.push_back(f);
   fused_invalidate(left);
+  general_invalidate(left);
   *out = f;
   return 0;
 }
@@ -1407,7 +1413,7 @@ int hfx_run_steps_blocks(hfx_eles *const *eles, int neb, hfx_inters *const *face
   HFX_CHECK(ctx->have_params, "parameters not set");
   const int adv = ctx->params.adv_type;
   const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14; /* src/HiFiLES.cpp:143-150 */
-  HFX_CHECK(fused != 4, "the general fused stage (fused 4) is not part of this build");
+  if (fused == 4) return general_run_steps(eles, neb, faces, nfb, n_steps);
   HFX_CHECK(fused == 0 || neb == 1, "hfx_run_steps_blocks: the split fused stage (fused %d) takes one tensor-product element block; "
                                     "several blocks run per method (0) or through the general fused stage (4)", fused);
   HFX_CHECK(fused == 0 || fused == 2 || fused == 3, "hfx_run_steps: fused must be 0 (per-method), 2 or 3 (split fused stage), 4 (general fused "
@@ -1493,6 +1499,21 @@ int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int r
   HFX_CHECK(e && ms && names && reps > 0, "hfx_time_fused_kernels: bad argument");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   return split_time_kernels(e, faces, nfb, reps, ms, names, 256, e->ctx->fused_mode);
+}
+
+int hfx_time_general_kernels(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int reps, double ms[8], char names[256])
+{
+  HFX_CHECK(eles && neb > 0 && ms && names && reps > 0, "hfx_time_general_kernels: bad argument");
+  HFX_CHECK(eles[0]->ctx->have_params, "parameters not set");
+  snprintf(names, 256, "gface_delta_kernel,general_flux_kernel,gface_flux_kernel,general_update_kernel");
+  return general_time_kernels(eles, neb, faces, nfb, reps, ms);
+}
+
+int hfx_general_kernel_bytes(hfx_eles *const *eles, int neb, double bytes[8])
+{
+  HFX_CHECK(eles && neb > 0 && bytes, "hfx_general_kernel_bytes: bad argument");
+  general_kernel_bytes(eles, neb, bytes);
+  return 0;
 }
 
 int hfx_fused_kernel_bytes(hfx_eles *e, double bytes[8])

@@ -130,6 +130,7 @@ struct hfx_eles
   void *tensor_ops = nullptr; // hfx::TensorOps: 1-D factors of the over-integration / shock-capturing matrices
   // fused-path private data (built lazily)
   hfx::FusedData *fused = nullptr;
+  void *general = nullptr; // hfx::GeneralData: the general (non-tensor-product) fused stage (general.hip)
   std::vector<hfx_inters *> faces_attached;
 };
 

@@ -289,7 +289,11 @@ int hfx_CalcResidual_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters 
  * blocks whose groups ramp get run_input.ramp_counter advanced after every step (src/HiFiLES.cpp:224-225). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
 /* The RK loop over several element blocks (mixed meshes).  fused 0: the per-method path; fused 4: the fused stage for
- * general (non-tensor-product) element classes -- see hfx_general_* below. */
+ * general (non-tensor-product) element classes, three-dimensional Navier-Stokes / Euler blocks with interior and
+ * boundary faces (csrc/general.hip): four launches per element block and stage, the dense operator contractions on the
+ * FP64 matrix cores over batches of 16 elements; like fused 3 it keeps the corrected gradients on chip (only boundary
+ * points get grad_disu_fpts) and leaves disu_upts(0), disu_upts(1), disu_fpts of the new state and div_tconf_upts.
+ * A block with one element class may of course be passed alone (hfx_run_steps(e, ..., 4) is the same call). */
 int hfx_run_steps_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *faces, int n_face_blocks, int n_steps,
                          int fused);
 
@@ -373,6 +377,11 @@ int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, i
 int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int reps, double ms[8], char names[256]);
 /* ALGORITHMIC HBM bytes per launch of each fused kernel (same order), see DESIGN.md */
 int hfx_fused_kernel_bytes(hfx_eles *e, double bytes[8]);
+/* The same for the general fused stage (hfx_run_steps_blocks(..., fused = 4)): ms[0..3] = pairwise LDG kernels, flux
+ * kernels of all element blocks, pairwise common-flux kernels, update kernels of all blocks */
+int hfx_time_general_kernels(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *faces, int n_face_blocks, int reps,
+                             double ms[8], char names[256]);
+int hfx_general_kernel_bytes(hfx_eles *const *eles, int n_ele_blocks, double bytes[8]);
 
 #ifdef __cplusplus
 }

@@ -148,3 +148,57 @@ def test_run_steps_blocks_vs_reference():
     for c in classes:
         E[c].close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MIXED)
+def test_general_fused_stage_on_mixed_mesh_vs_reference(name):
+    """hfx_run_steps_blocks(..., fused = 4): the fused stage for general element classes (csrc/general.hip: four launches
+    per block and stage, FP64-MFMA contractions over batches of 16 elements) on the mixed channel -- prism | tetrahedron
+    face pairs, walls on the prisms -- against the genuine reference after every time step"""
+    import hfx
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    ctx = hfx.Context(0)
+    classes, E, F = build_gpu(ctx, d)
+    nstage = int(d["c2_sizes"][7])
+    steps = sorted({int(k.split("_")[2][4:]) for k in d if k.startswith("c2_u_step")})
+    for st in steps:
+        hfx.run_steps_blocks([E[c] for c in classes], F, 1, fused=4)
+        for c in classes:
+            assert relerr(E[c].download(hfx.DISU_UPTS0), d["c%d_u_step%d_stage%d" % (c, st, nstage - 1)]) < 1e-11, (c, st)
+    for c in classes:
+        assert E[c].check_nan() == -1
+    for f in F:
+        f.close()
+    for c in classes:
+        E[c].close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tet_p2_n2_deformed", "tet_p3_n2_deformed", "pri_p2_n2_deformed", "pri_p3_n2_deformed"])
+def test_general_fused_stage_single_class_vs_reference(name):
+    """the same on the periodic single-class tetrahedron and prism fixtures (a last batch of fewer than 16 elements
+    included), and what it leaves in the public arrays against the per-method path"""
+    import hfx
+    from test_gpu_methods_vs_golden import build
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    ctx = hfx.Context(0)
+    e, faces = build(ctx, d)
+    m, mfaces = build(ctx, d)
+    nstage = int(d["sizes"][7])
+    hfx.run_steps(e, faces, 1, fused=4)
+    assert relerr(e.download(hfx.DISU_UPTS0), d["u_step0_stage%d" % (nstage - 1)]) < 1e-11
+    hfx.run_steps(m, mfaces, 1, fused=0)
+    assert relerr(e.download(hfx.DISU_UPTS1), m.download(hfx.DISU_UPTS1)) < 1e-9
+    assert relerr(e.download(hfx.DIV_TCONF_UPTS), m.download(hfx.DIV_TCONF_UPTS)) < 5e-10
+    m.extrapolate_solution()
+    assert relerr(e.download(hfx.DISU_FPTS), m.download(hfx.DISU_FPTS)) < 1e-12
+    # a second step from the fused state, against the per-method path
+    hfx.run_steps(e, faces, 1, fused=4)
+    hfx.run_steps(m, mfaces, 1, fused=0)
+    assert relerr(e.download(hfx.DISU_UPTS0), m.download(hfx.DISU_UPTS0)) < 1e-11
+    for f in faces + mfaces:
+        f.close()
+    e.close(); m.close()
+    ctx.close()

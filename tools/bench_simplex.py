@@ -48,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiles", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--fused", type=int, default=4, help="4: the general fused stage (csrc/general.hip), 0: per method")
     args = ap.parse_args()
     ctx = hfx.Context(0)
     lib = hfx.lib()
@@ -59,19 +60,29 @@ def main():
         e = hfx.Eles(ctx, [ne] + sz[1:5], big, ele_type=sz[6], order=sz[5])
         faces = [hfx.IntInters(ctx, e, e, L, R) for L, R in face_tabs]
         e.upload(hfx.DISU_UPTS0, big["u_init"])
-        hfx.run_steps(e, faces, 1)
+        hfx.run_steps(e, faces, 1, fused=args.fused)
         ctx.synchronize()
         t0 = time.perf_counter()
-        hfx.run_steps(e, faces, args.steps)
+        hfx.run_steps(e, faces, args.steps, fused=args.fused)
         ctx.synchronize()
         dt = time.perf_counter() - t0
         assert e.check_nan() == -1
         n_stage = sz[7]
         dof = ne * sz[1] * sz[3]
-        ms = (C.c_double * 11)()
         fa = (C.c_void_p * len(faces))(*[f.h for f in faces])
-        hfx.check(lib.hfx_time_methods(e.h, fa, C.c_int(len(faces)), C.c_int(5), ms))
-        times = {n: round(ms[i], 4) for i, n in enumerate(METHOD_NAMES)}
+        if args.fused == 4:
+            ms = (C.c_double * 8)()
+            names = (C.c_char * 256)()
+            ea = (C.c_void_p * 1)(e.h)
+            hfx.check(lib.hfx_time_general_kernels(ea, C.c_int(1), fa, C.c_int(len(faces)), C.c_int(10), ms, names))
+            by = (C.c_double * 8)()
+            hfx.check(lib.hfx_general_kernel_bytes(ea, C.c_int(1), by))
+            times = {n: round(ms[i], 4) for i, n in enumerate(names.value.decode().split(","))}
+            times["GBps"] = {n: round(by[i] / (ms[i] * 1e-3) / 1e9, 1) for i, n in enumerate(names.value.decode().split(",")) if ms[i] > 0}
+        else:
+            ms = (C.c_double * 11)()
+            hfx.check(lib.hfx_time_methods(e.h, fa, C.c_int(len(faces)), C.c_int(5), ms))
+            times = {n: round(ms[i], 4) for i, n in enumerate(METHOD_NAMES)}
         print(json.dumps({"case": name, "n_eles": ne, "n_upts": sz[1], "n_fpts": sz[2], "dof": dof,
                           "ms_per_rk_stage": round(1e3 * dt / (args.steps * n_stage), 4),
                           "dof_updates_per_s": dof * n_stage * args.steps / dt, "methods_ms": times}))
