@@ -88,6 +88,7 @@ __device__ __forceinline__ void g_to_physical(const double inv_detjac, const dou
 struct GenArgs
 {
   int n_eles, nu, nfp, KU, KF, MU, MF;
+  unsigned inv_nu, inv_nfp; // floor(2^32 / n) + 1: q / n == __umulhi(q, inv) for the q < 2^16 of the staging loops
   const double *o0, *o1[3], *o2[3], *o3, *o4[3], *o5[3], *o6;
   const double *u0, *delta, *disu;
   const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts, *norm_fpts;
@@ -103,20 +104,40 @@ struct GenArgs
   double dt, rk_a, rk_b;
 };
 
-// one 16 x 16 output tile: acc += op[rt*16 + (0..15)][k0 .. k0 + 4 ksteps) . plane[k][16 elements]
-// op: zero-padded operator, leading dimension M; plane: LDS plane of the data; lane: li = lane & 15, lk = lane >> 4
-__device__ __forceinline__ g_f64x4 tile_mac(g_f64x4 acc, const double *__restrict__ op, int M, int rt, const double *plane, int ksteps,
-                                            int li, int lk)
+// NA output tiles at once, sharing the operator fragments: acc[j] += op[rt*16 + (0..15)][0 .. 4 ksteps) . plane_j[k][16 elements],
+// plane_j = plane + j * pstride.  op: zero-padded operator, leading dimension M; lane: li = lane & 15, lk = lane >> 4.
+// The operator fragments of UK k-steps are requested together (they come from L2 / L1: one latency per UK * NA MFMAs).
+template <int NA>
+__device__ __forceinline__ void tile_mac(g_f64x4 (&acc)[NA], const double *__restrict__ op, int M, int rt, const double *plane, int pstride,
+                                         int ksteps, int li, int lk)
 {
+  constexpr int UK = (NA > 5) ? 2 : 8; // k-steps whose operator fragments are requested together (15 tiles: their LDS operands fill the registers)
+  // sw(4 s + lk, li) = 64 s + 16 lk + ((li ^ lk) ^ 4 (s & 3)): four per-lane offsets, the rest is an immediate
+  const int lx = li ^ lk;
+  const int ob[4] = {16 * lk + lx, 16 * lk + (lx ^ 4), 16 * lk + (lx ^ 8), 16 * lk + (lx ^ 12)};
   const double *ap = op + rt * 16 + li + (long)M * lk;
-
-  for (int s = 0; s < ksteps; s++)
+  const long ast = (long)M * 4;
+  double av[UK], an[UK];
+#pragma unroll
+  for (int u = 0; u < UK; u++) av[u] = (u < ksteps) ? ap[ast * u] : 0.0;
+  for (int s0 = 0; s0 < ksteps; s0 += UK)
   {
-    const double av = ap[(long)M * 4 * s];
-    const double bv = plane[sw(4 * s + lk, li)];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+    // the next chunk's fragments are in flight while this chunk's MFMAs issue
+    const double *apn = ap + ast * (s0 + UK);
+#pragma unroll
+    for (int u = 0; u < UK; u++) an[u] = (s0 + UK + u < ksteps) ? apn[ast * u] : 0.0;
+    const double *pb = plane + 64 * s0;
+#pragma unroll
+    for (int u = 0; u < UK; u++)
+      if (s0 + u < ksteps)
+      {
+#pragma unroll
+        for (int j = 0; j < NA; j++)
+          acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[j * pstride + 64 * u + ob[(UK % 4 == 0) ? (u & 3) : ((s0 + u) & 3)]], av[u], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int u = 0; u < UK; u++) av[u] = an[u];
   }
-  return acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -143,7 +164,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
     const double *src = a.u0 + e0 * nu + f * plane_u;
     for (int q = tid; q < KU * GB; q += T)
     {
-      const int el = q / nu, k = q - el * nu; // q < nu*16: a real entry; the rest of the plane: K padding
+      const int el = (int)__umulhi((unsigned)q, a.inv_nu), k = q - el * nu; // q < nu*16: a real entry; the rest of the plane: K padding
       if (q < nu * GB)
         U[f * KU * GB + sw(k, el)] = (el < nval) ? src[q] : 0.0;
       else
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       const double *sd = a.delta + e0 * nfp + f * plane_f;
       for (int q = tid; q < KF * GB; q += T)
       {
-        const int el = q / nfp, k = q - el * nfp;
+        const int el = (int)__umulhi((unsigned)q, a.inv_nfp), k = q - el * nfp;
         if (q < nfp * GB)
           D[f * KF * GB + sw(k, el)] = (el < nval) ? sd[q] : 0.0;
         else
@@ -181,16 +202,20 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
     // ---- P1: reference-space corrected gradient at the solution points (calculate_gradient + first half of
     //          correct_gradient, src/eles.cpp:1823,1900): G(f,d) = opp_4[d] U(f) + opp_5[d] D(f)
     const int n_rt = a.MU / 16;
-    for (int it = wave; it < n_rt * ND * NF; it += W)
+    for (int it = wave; it < n_rt * ND; it += W)
     {
-      const int f = it % NF, d = (it / NF) % ND, rt = it / (NF * ND);
-      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-      acc = tile_mac(acc, a.o4[d], a.MU, rt, U + f * KU * GB, KU / 4, li, lk);
-      acc = tile_mac(acc, a.o5[d], a.MU, rt, D + f * KF * GB, KF / 4, li, lk);
+      const int d = it % ND, rt = it / ND;
+      g_f64x4 acc[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
+      tile_mac<NF>(acc, a.o4[d], a.MU, rt, U, KU * GB, KU / 4, li, lk);
+      tile_mac<NF>(acc, a.o5[d], a.MU, rt, D, KF * GB, KF / 4, li, lk);
       const int row = rt * 16 + li;
       if (row < nu)
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) G[(f + NF * d) * KU * GB + sw(row, lk + 4 * rg)] = acc[rg];
+        for (int f = 0; f < NF; f++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) G[(f + NF * d) * KU * GB + sw(row, lk + 4 * rg)] = acc[f][rg];
     }
     __syncthreads();
 
@@ -202,50 +227,53 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       g_f64x4 acc[NF * ND];
 #pragma unroll
       for (int c = 0; c < NF * ND; c++) acc[c] = g_f64x4{0.0, 0.0, 0.0, 0.0};
-      const double *ap = a.o6 + rt * 16 + li + (long)a.MF * lk;
-      for (int s = 0; s < KU / 4; s++)
-      {
-        const double av = ap[(long)a.MF * 4 * s];
-        const int o = sw(4 * s + lk, li);
-#pragma unroll
-        for (int c = 0; c < NF * ND; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(G[c * KU * GB + o], av, acc[c], 0, 0, 0);
-      }
+      // the point inputs of (row, element lk + 4 rg) are requested one point ahead: rg = 0 before the MFMA loop
       const int row = rt * 16 + li;
+      double pu[2][NF], pJ[2][9], pd[2], pn[2][ND];
+      auto request = [&](int slot, int rg) {
+        const int el = lk + 4 * rg;
+        const bool ok = row < nfp && el < nval;
+        const long o = ok ? row + (long)nfp * (e0 + el) : 0;
+#pragma unroll
+        for (int k = 0; k < NF; k++) pu[slot][k] = ok ? a.disu[o + k * plane_f] : 1.0;
+#pragma unroll
+        for (int q = 0; q < 9; q++) pJ[slot][q] = ok ? a.JGinv_fpts[o * 9 + q] : 0.0;
+        pd[slot] = ok ? a.detjac_fpts[o] : 1.0;
+#pragma unroll
+        for (int m = 0; m < ND; m++) pn[slot][m] = ok ? a.norm_fpts[o + m * plane_f] : 0.0;
+      };
+      request(0, 0);
+      tile_mac<NF * ND>(acc, a.o6, a.MF, rt, G, KU * GB, KU / 4, li, lk);
 #pragma unroll
       for (int rg = 0; rg < 4; rg++)
       {
-        const int el = lk + 4 * rg;
+        const int el = lk + 4 * rg, sl = rg & 1;
+        if (rg < 3) request(sl ^ 1, rg + 1);
         if (row < nfp && el < nval)
         {
           const long o = row + (long)nfp * (e0 + el);
-          double u[NF], g[NF * ND], JG[9], n[ND], fv[NF * ND];
-#pragma unroll
-          for (int k = 0; k < NF; k++) u[k] = a.disu[o + k * plane_f];
-#pragma unroll
-          for (int q = 0; q < 9; q++) JG[q] = a.JGinv_fpts[o * 9 + q];
-          const double idj = 1.0 / a.detjac_fpts[o];
+          double g[NF * ND], fv[NF * ND];
+          const double idj = 1.0 / pd[sl];
 #pragma unroll
           for (int k = 0; k < NF; k++)
           {
             double tg[ND], cg[ND];
 #pragma unroll
             for (int d = 0; d < ND; d++) tg[d] = acc[k + NF * d][rg];
-            g_to_physical(idj, JG, tg, cg);
+            g_to_physical(idj, pJ[sl], tg, cg);
 #pragma unroll
             for (int d = 0; d < ND; d++) g[k + NF * d] = cg[d];
           }
           if (a.grad_fpts != nullptr && (a.meta[o] & 4)) // boundary point: the boundary kernel reads the gradient
 #pragma unroll
             for (int c = 0; c < NF * ND; c++) a.grad_fpts[o + c * plane_f] = g[c];
-          calc_visf<ND, true>(a.P, u, g, fv);
-#pragma unroll
-          for (int m = 0; m < ND; m++) n[m] = a.norm_fpts[o + m * plane_f];
+          calc_visf<ND, true>(a.P, pu[sl], g, fv);
 #pragma unroll
           for (int k = 0; k < NF; k++)
           {
             double s = 0.0;
 #pragma unroll
-            for (int m = 0; m < ND; m++) s += fv[k + NF * m] * n[m];
+            for (int m = 0; m < ND; m++) s += fv[k + NF * m] * pn[sl][m];
             a.fn[o + k * plane_f] = s;
           }
         }
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
   //          src/eles.cpp:1415,1973,2285): G(f,d) <- transformed total flux
   for (int q = tid; q < nu * GB; q += T)
   {
-    const int el = q / nu, pt = q - el * nu;
+    const int el = (int)__umulhi((unsigned)q, a.inv_nu), pt = q - el * nu;
     if (el < nval)
     {
       const long o = pt + (long)nu * (e0 + el);
@@ -311,24 +339,28 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
   //          (calculate_divergence, extrapolate_totalFlux; src/eles.cpp:1651,1549) -> HBM, 128-byte runs
   {
     const int n_ut = a.MU / 16, n_ft = a.MF / 16;
-    for (int it = wave; it < (n_ut + n_ft) * NF; it += W)
+    for (int t = wave; t < n_ut + n_ft; t += W)
     {
-      const int f = it % NF, t = it / NF;
       const bool is_div = t < n_ut;
       const int rt = is_div ? t : t - n_ut;
-      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      g_f64x4 acc[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int d = 0; d < ND; d++)
-        acc = tile_mac(acc, is_div ? a.o2[d] : a.o1[d], is_div ? a.MU : a.MF, rt, G + (f + NF * d) * KU * GB, KU / 4, li, lk);
+        tile_mac<NF>(acc, is_div ? a.o2[d] : a.o1[d], is_div ? a.MU : a.MF, rt, G + NF * d * KU * GB, KU * GB, KU / 4, li, lk);
       const int row = rt * 16 + li, n = is_div ? nu : nfp;
-      double *out = is_div ? a.div + f * plane_u : a.ntd + f * plane_f;
+      double *out = is_div ? a.div : a.ntd;
+      const long plane = is_div ? plane_u : plane_f;
       if (row < n)
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++)
-        {
-          const int el = lk + 4 * rg;
-          if (el < nval) out[row + (long)n * (e0 + el)] = acc[rg];
-        }
+        for (int f = 0; f < NF; f++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++)
+          {
+            const int el = lk + 4 * rg;
+            if (el < nval) out[row + (long)n * (e0 + el) + f * plane] = acc[f][rg];
+          }
     }
   }
 }
@@ -355,7 +387,7 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
     const double *tc = a.tconf + e0 * nfp + f * plane_f, *nt = a.ntd + e0 * nfp + f * plane_f;
     for (int q = tid; q < KF * GB; q += T)
     {
-      const int el = q / nfp, k = q - el * nfp;
+      const int el = (int)__umulhi((unsigned)q, a.inv_nfp), k = q - el * nfp;
       if (q < nfp * GB)
         X[f * KF * GB + sw(k, el)] = (el < nval) ? tc[q] + -1.0 * nt[q] : 0.0; // the daxpy of src/eles.cpp:1746
       else
@@ -369,15 +401,18 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
   __syncthreads();
   {
     const int n_rt = a.MU / 16;
-    for (int it = wave; it < n_rt * NF; it += W)
+    for (int rt = wave; rt < n_rt; rt += W)
     {
-      const int f = it % NF, rt = it / NF;
-      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-      acc = tile_mac(acc, a.o3, a.MU, rt, X + f * KF * GB, KF / 4, li, lk);
+      g_f64x4 acc[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
+      tile_mac<NF>(acc, a.o3, a.MU, rt, X, KF * GB, KF / 4, li, lk);
       const int row = rt * 16 + li;
       if (row < nu)
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) S[f * KU * GB + sw(row, lk + 4 * rg)] = acc[rg];
+        for (int f = 0; f < NF; f++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) S[f * KU * GB + sw(row, lk + 4 * rg)] = acc[f][rg];
     }
   }
   __syncthreads();
@@ -385,7 +420,7 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
   {
     for (int q = tid; q < nu * GB; q += T)
     {
-      const int el = q / nu, pt = q - el * nu;
+      const int el = (int)__umulhi((unsigned)q, a.inv_nu), pt = q - el * nu;
       const int so = f * KU * GB + sw(pt, el);
       if (el >= nval)
       {
@@ -439,19 +474,22 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
   __syncthreads();
   {
     const int n_ft = a.MF / 16;
-    for (int it = wave; it < n_ft * NF; it += W)
+    for (int rt = wave; rt < n_ft; rt += W)
     {
-      const int f = it % NF, rt = it / NF;
-      g_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-      acc = tile_mac(acc, a.o0, a.MF, rt, S + f * KU * GB, KU / 4, li, lk);
+      g_f64x4 acc[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
+      tile_mac<NF>(acc, a.o0, a.MF, rt, S, KU * GB, KU / 4, li, lk);
       const int row = rt * 16 + li;
       if (row < nfp)
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++)
-        {
-          const int el = lk + 4 * rg;
-          if (el < nval) a.disu_next[row + (long)nfp * (e0 + el) + f * plane_f] = acc[rg];
-        }
+        for (int f = 0; f < NF; f++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++)
+          {
+            const int el = lk + 4 * rg;
+            if (el < nval) a.disu_next[row + (long)nfp * (e0 + el) + f * plane_f] = acc[f][rg];
+          }
     }
   }
 }
@@ -631,6 +669,7 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
   GeneralData *g = (GeneralData *)e->general;
   const hfx_params &p = e->ctx->params;
   GenArgs a{};
+  a.inv_nu = (unsigned)(4294967296ull / (unsigned)e->n_upts) + 1u; a.inv_nfp = (unsigned)(4294967296ull / (unsigned)e->n_fpts) + 1u;
   a.n_eles = e->n_eles; a.nu = e->n_upts; a.nfp = e->n_fpts; a.KU = g->KU; a.KF = g->KF; a.MU = g->MU; a.MF = g->MF;
   a.o0 = g->o0; a.o3 = g->o3; a.o6 = g->o6;
   for (int d = 0; d < 3; d++) { a.o1[d] = g->o1[d]; a.o2[d] = g->o2[d]; a.o4[d] = g->o4[d]; a.o5[d] = g->o5[d]; }
