@@ -2,7 +2,7 @@
 """bench.py -- DOF-updates/s and ms/RK-stage of the HiFiLES hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--cells CELLS] [--order P] [--mode split3|split|methods|dense]
-                    [--workload tgv|simplex]
+                    [--workload tgv|tets|prisms|mixed] [--tiles T]
 
 One "step" is one time step = 5 RK stages (RK45), each stage = CalcResidual + AdvanceSolution
 (/root/reference/src/HiFiLES.cpp:201-217) over the whole mesh.  Workload at N=1: BASELINE.json
@@ -162,6 +162,137 @@ def rocprof_kernel_ms(mode, kernel):
     return None, None
 
 
+def tile_arrays(d, tiles, prefix=""):
+    """element-wise arrays of one class of a fixture repeated `tiles` times along the element axis"""
+    ele_axis = {"detjac_upts": 1, "JGinv_upts": 3, "detjac_fpts": 1, "JGinv_fpts": 3, "tdA_fpts": 1, "norm_fpts": 1, "u_init": 1}
+    out = dict(d)
+    for k, ax in ele_axis.items():
+        out[k] = np.asfortranarray(np.concatenate([d[k]] * tiles, axis=ax))
+    return out
+
+
+def tile_table(T, plane, tiles):
+    """a face table (n_fpts_per_inter, n_inters) of offsets into one tile's (fpt, ele) plane, for `tiles` tiles"""
+    T = T.astype(np.int64)
+    off = (np.arange(tiles, dtype=np.int64) * plane)[None, None, :]
+    return np.asfortranarray((T[:, :, None] + off).transpose(0, 2, 1).reshape(T.shape[0], -1, order="F").astype(np.int32))
+
+
+def general_workload(args):
+    """BASELINE.json configs[3]'s element classes at bench size through the general fused stage (hfx_run_steps_blocks,
+    fused = 4): the reference's own fixture of a small mesh -- P3 tetrahedra, P3 prisms, or the MIXED channel (prism
+    layers on the walls, tetrahedra in the core, isothermal / adiabatic walls) -- with its operators, metrics and face
+    tables, tiled `--tiles` times: identical, mutually disconnected copies, i.e. the per-element and per-face work of one
+    large mesh with every array at full size in HBM.  The host mirror has no tetrahedron / prism setup yet, which is why
+    the mesh comes from a fixture."""
+    import torch  # noqa: F401  (maps torch's HIP runtime first, see tests/conftest.py)
+    import hfx
+    import mixed_util as MU
+    name = {"tets": "tet_p3_n2_deformed", "prisms": "pri_p3_n2_deformed", "mixed": "mixed_p3_channel"}[args.workload]
+    d = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
+    tiles = args.tiles
+    ctx = hfx.Context(0)
+    lib = hfx.lib()
+    if args.workload == "mixed":
+        classes, per, faces, bdy = MU.split(d)
+    else:
+        classes, per = [int(d["sizes"][6])], None
+        per = {classes[0]: d}
+        faces = [(classes[0], classes[0], d["int%d_L" % t], d["int%d_R" % t]) for t in range(3) if "int%d_L" % t in d]
+        bdy = []
+    ctx.set_params(hfx.params_from(per[classes[0]]))
+    E, plane = {}, {}
+    for c in classes:
+        sz = [int(v) for v in per[c]["sizes"]]
+        plane[c] = sz[0] * sz[2]
+        big = tile_arrays(per[c], tiles)
+        E[c] = hfx.Eles(ctx, [sz[0] * tiles] + sz[1:5], big, ele_type=sz[6], order=sz[5])
+        E[c].upload(hfx.DISU_UPTS0, big["u_init"])
+    F = [hfx.IntInters(ctx, E[a], E[b], tile_table(L, plane[a], tiles), tile_table(R, plane[b], tiles)) for a, b, L, R in faces]
+    for a, L, ids in bdy:
+        F.append(hfx.BdyInters(ctx, E[a], tile_table(L, plane[a], tiles), np.tile(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
+                               float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
+    blocks = [E[c] for c in classes]
+    fused = 4 if args.mode in ("auto", "general") else 0
+    n_stages = int(per[classes[0]]["sizes"][7])
+    hfx.run_steps_blocks(blocks, F, args.warmup, fused=fused)
+    samples = []
+    for _ in range(max(1, args.reps)):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        hfx.run_steps_blocks(blocks, F, args.steps, fused=fused)
+        ctx.synchronize()
+        samples.append(time.perf_counter() - t0)
+    elapsed = float(np.median(samples))
+    for c in classes:
+        assert E[c].check_nan() == -1
+    dof = sum(E[c].n_eles * E[c].n_upts * E[c].n_fields for c in classes)
+    value = dof * n_stages * args.steps / elapsed
+    roof = None
+    if fused:
+        ea = (C.c_void_p * len(blocks))(*[e.h for e in blocks])
+        fa = (C.c_void_p * max(1, len(F)))(*[f.h for f in F])
+        ms = (C.c_double * 8)()
+        by = (C.c_double * 8)()
+        names = (C.c_char * 256)()
+        hfx.check(lib.hfx_time_general_kernels(ea, C.c_int(len(blocks)), fa, C.c_int(len(F)), C.c_int(10), ms, names))
+        hfx.check(lib.hfx_general_kernel_bytes(ea, C.c_int(len(blocks)), by))
+        kn = names.value.decode().split(",")
+        times = {n: ms[i] for i, n in enumerate(kn)}
+        dom = max(times, key=times.get)
+        i = kn.index(dom)
+        achieved = by[i] / (ms[i] * 1e-3) / 1e9
+        k_prof, k_src = rocprof_kernel_ms("general_" + args.workload, dom)
+        roof = dict(bound="hbm", kernel=dom + " (all element blocks)", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                    traffic=None, algorithmic_bytes=by[i], kernel_ms=ms[i], kernel_ms_source="HIP events in this run",
+                    kernel_ms_rocprof=k_prof, kernel_ms_rocprof_source=k_src, kernels_ms=times,
+                    stage_algorithmic_bytes=sum(by[:4]), stage_hbm_frac=sum(by[:4]) / (1e-3 * sum(ms[:4])) / 1e9 / HBM_PEAK_GBS)
+    cpu = None
+    if not args.no_cpu:
+        # the oracle on ONE tile (the reference is a serial code; the fixture was produced by the genuine reference itself)
+        t0 = time.perf_counter()
+        reps = 0
+        if args.workload == "mixed":
+            m = MU.MixedOracle(d)
+            while time.perf_counter() - t0 < 10.0:
+                for rk in range(n_stages):
+                    assert m.CalcResidual() == -1
+                    m.AdvanceSolution(rk)
+                reps += 1
+            dof1 = sum(m.case[c].n_eles * m.case[c].n_upts * 5 for c in m.classes)
+        else:
+            import oracle_py as O
+            oc = O.Case(d)
+            e1, (f1, nb1) = oc.c_eles(), oc.c_faces()
+            O.load().orc_set_threads(1)
+            while time.perf_counter() - t0 < 10.0:
+                assert O.load().orc_rk_step(C.byref(e1), f1, nb1, C.byref(oc.params)) == -1
+                reps += 1
+            dof1 = oc.n_eles * oc.n_upts * oc.n_fields
+        secs = time.perf_counter() - t0
+        cpu = dict(value=dof1 * n_stages * reps / secs, unit="DOF-updates/s", cores=1, cpu_model=cpu_model(), kind="port",
+                   sample="oracle (C restatement of the reference CPU path, pinned bit-exactly by this very fixture of the genuine "
+                          "reference) on ONE tile of the workload (%d elements), %d time steps in %.1f s on 1 core" %
+                          (sum(int(per[c]["sizes"][0]) for c in classes), reps, secs))
+    desc = {"tets": "P3 tetrahedra, periodic box", "prisms": "P3 triangular prisms, periodic box",
+            "mixed": "MIXED tetrahedron / prism channel with isothermal + adiabatic walls, P3 (BASELINE.json configs[3])"}[args.workload]
+    line = {"metric": "DOF-updates/sec", "value": value, "unit": "DOF-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_rk_stage": 1e3 * elapsed / args.steps / n_stages, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "timing": {"reps": len(samples), "statistic": "median", "seconds_per_rep": samples, "stages_per_rep": n_stages * args.steps},
+            "config": {"workload": "%s: the reference's fixture %s tiled %d times, Navier-Stokes, HLLC+LDG, RK45" % (desc, name, tiles),
+                       "n_eles": {str(c): E[c].n_eles for c in classes}, "dof": dof,
+                       "path": "general fused stage (fused 4)" if fused else "per method", "multi_gpu": "none"},
+            "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(line))
+    for f in F:
+        f.close()
+    for c in classes:
+        E[c].close()
+    ctx.close()
+    return 0
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children of THIS process, which has not
     touched (and never touches) a GPU, and relay rank 0's JSON line.  Transports are tried in order: libhfx's own RCCL
@@ -203,7 +334,10 @@ def main():
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region; the median is reported")
     ap.add_argument("--cells", "--n", dest="n", type=int, default=32, help="cells per direction per GPU")
     ap.add_argument("--order", type=int, default=4)
-    ap.add_argument("--mode", default="auto", choices=["auto", "split", "split3", "methods", "dense"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "split", "split3", "methods", "dense", "general"])
+    ap.add_argument("--workload", default="tgv", choices=["tgv", "tets", "prisms", "mixed"],
+                    help="tgv: BASELINE.json configs[1] (default); tets / prisms / mixed: configs[3]'s element classes, see general_workload")
+    ap.add_argument("--tiles", type=int, default=2048, help="copies of the fixture mesh (workloads tets / prisms / mixed)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     # BASELINE.json configs[4]'s ingredients on the same mesh (not the default workload): polynomial de-aliasing of the
     # inviscid flux and shock capturing after every stage
@@ -215,6 +349,10 @@ def main():
                     "to the rank itself, i.e. the partitioned stage with its RCCL exchanges priced on one GPU")
     args = ap.parse_args()
 
+    if args.workload != "tgv":
+        if args.gpus != 1:
+            raise SystemExit("bench.py --workload %s runs on one GPU" % args.workload)
+        return general_workload(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
