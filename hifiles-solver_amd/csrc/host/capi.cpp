@@ -347,3 +347,81 @@ extern "C" int hfxh_case_calc_disu_ppts(hfxh_case *c, const double **out, int di
   dims[0] = E->n_ppts_per_ele; dims[1] = E->n_eles; dims[2] = E->n_fields;
   return 0;
 }
+
+
+// ---- tetrahedra / prisms as producers of operators and metrics -------------------------------------------------------
+struct hfxh_simplex
+{
+  input in;
+  eles *E = nullptr;
+  ~hfxh_simplex() { delete E; }
+};
+
+extern "C" int hfxh_simplex_create(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
+                                   hfxh_simplex **out)
+{
+  if (!out || !shape || n_eles <= 0) { g_err = "hfxh_simplex_create: bad argument"; return 1; }
+  if (ele_type != 2 && ele_type != 3) { g_err = "hfxh_simplex_create: ele_type must be 2 (tetrahedra) or 3 (prisms)"; return 1; }
+  hfxh_simplex *s = new hfxh_simplex();
+  s->in.equation = 0;
+  s->in.order = order;
+  s->in.viscous = viscous;
+  if (loc_1d_upts)
+  {
+    s->in.loc_1d_upts_override.setup(order + 1);
+    for (int i = 0; i <= order; i++) s->in.loc_1d_upts_override(i) = loc_1d_upts[i];
+  }
+  s->E = (ele_type == 2) ? (eles *)new eles_tets() : (eles *)new eles_pris();
+  const int ns = (ele_type == 2) ? 4 : 6;
+  if (s->E->setup(n_eles, ns, &s->in)) { g_err = s->E->last_error(); delete s; return 1; }
+  hf_array<double> pos(3);
+  for (int e = 0; e < n_eles; e++)
+    for (int k = 0; k < ns; k++)
+    {
+      for (int d = 0; d < 3; d++) pos(d) = shape[d + 3 * (k + (size_t)ns * e)];
+      s->E->set_shape_node(k, e, pos);
+    }
+  if (s->E->set_transforms()) { g_err = s->E->last_error(); delete s; return 1; }
+  *out = s;
+  return 0;
+}
+
+extern "C" int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const double **ptr, int dims[4])
+{
+  eles *E = s->E;
+  std::string n(name);
+  hf_array<double> *a = nullptr;
+  if (n == "opp_0") a = &E->opp_0;
+  else if (n == "opp_3") a = &E->opp_3;
+  else if (n == "opp_6" && E->viscous) a = &E->opp_6;
+  else if (n.rfind("opp_", 0) == 0 && n.size() == 7)
+  {
+    const int which = n[4] - '0', d = n[6] - '0';
+    if (d < 0 || d >= E->n_dims) { g_err = "bad operator dimension"; return 1; }
+    if (which == 1) a = &E->opp_1(d);
+    else if (which == 2) a = &E->opp_2(d);
+    else if (which == 4 && E->viscous) a = &E->opp_4(d);
+    else if (which == 5 && E->viscous) a = &E->opp_5(d);
+  }
+  else if (n == "loc_upts") a = &E->loc_upts;
+  else if (n == "tloc_fpts") a = &E->tloc_fpts;
+  else if (n == "tnorm_fpts") a = &E->tnorm_fpts;
+  else if (n == "detjac_upts") a = &E->detjac_upts;
+  else if (n == "JGinv_upts") a = &E->JGinv_upts;
+  else if (n == "detjac_fpts") a = &E->detjac_fpts;
+  else if (n == "JGinv_fpts") a = &E->JGinv_fpts;
+  else if (n == "tdA_fpts") a = &E->tdA_fpts;
+  else if (n == "norm_fpts") a = &E->norm_fpts;
+  else if (n == "pos_upts") a = &E->pos_upts;
+  else if (n == "pos_fpts") a = &E->pos_fpts;
+  if (!a) { g_err = "hfxh_simplex_get_array: unknown array " + n; return 1; }
+  *ptr = a->get_ptr_cpu();
+  for (int i = 0; i < 4; i++) dims[i] = a->get_dim(i);
+  return 0;
+}
+
+extern "C" int hfxh_simplex_destroy(hfxh_simplex *s)
+{
+  delete s;
+  return 0;
+}

@@ -9,6 +9,7 @@
 #pragma once
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "../../../include/hfx.h"
 #include "hf_array.hpp"
@@ -148,4 +149,37 @@ protected:
   void fill_opp_3(hf_array<double> &opp_3) override;
   double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
   void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
+};
+
+// Tetrahedra and triangular prisms (src/eles_tets.cpp, src/eles_pris.cpp) as producers of the dense operators and the
+// metrics: csrc/host/eles_simplex.cpp.  4-node / 6-node (straight-sided) shapes.
+class eles_tets : public eles
+{
+protected:
+  int setup_ele_type_specific() override;
+  double eval_nodal_basis(int in_index, const hf_array<double> &in_loc) override;
+  double eval_d_nodal_basis(int in_index, int in_cpnt, const hf_array<double> &in_loc) override;
+  void fill_opp_3(hf_array<double> &opp_3) override;
+  double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
+  void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
+  std::vector<int> mode_i, mode_j, mode_k; // the orthonormal modal basis the nodal one is computed through
+  std::vector<double> vinv;                // inverse Vandermonde matrix, row-major
+};
+
+class eles_pris : public eles
+{
+public:
+  eles_pris();
+  ~eles_pris() override;
+  int n_upts_tri = 0;
+
+protected:
+  int setup_ele_type_specific() override;
+  double eval_nodal_basis(int in_index, const hf_array<double> &in_loc) override;
+  double eval_d_nodal_basis(int in_index, int in_cpnt, const hf_array<double> &in_loc) override;
+  void fill_opp_3(hf_array<double> &opp_3) override;
+  double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
+  void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
+  struct Impl;
+  Impl *impl;
 };

@@ -43,6 +43,10 @@ struct input
   // ---- element parameters
   int upts_type_hexa = 0, vcjh_scheme_hexa = 1;
   double eta_hexa = 0.0;
+  // tetrahedra and prisms (src/input.cpp:264-300)
+  int upts_type_tet = 0, fpts_type_tet = 0, vcjh_scheme_tet = 1;
+  int upts_type_pri_tri = 0, upts_type_pri_1d = 0, vcjh_scheme_pri_1d = 1, vcjh_scheme_tri = 1;
+  double eta_pri = 0.0;
   int upts_type_quad = 0, vcjh_scheme_quad = 1;
   double eta_quad = 0.0;
   // ---- gas

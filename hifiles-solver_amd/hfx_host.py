@@ -317,3 +317,31 @@ class Case:
         if self.h:
             lib().hfxh_case_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class Simplex:
+    """eles_tets (ele_type 2) / eles_pris (3) of the host mirror as producers of operators and metrics for the given
+    straight-sided elements: shape (3, n_spts, n_eles)."""
+
+    def __init__(self, ele_type, order, shape, viscous=1, loc_1d_upts=None):
+        shp = np.asfortranarray(np.array(shape, dtype=np.float64))
+        assert shp.shape[0] == 3 and shp.shape[1] == (4 if ele_type == 2 else 6)
+        x1 = None if loc_1d_upts is None else np.ascontiguousarray(np.array(loc_1d_upts, dtype=np.float64))
+        self.h = C.c_void_p()
+        check(lib().hfxh_simplex_create(C.c_int(ele_type), C.c_int(order), C.c_int(viscous), C.c_int(shp.shape[2]),
+                                        shp.ctypes.data_as(dp), None if x1 is None else x1.ctypes.data_as(dp), C.byref(self.h)))
+
+    def array(self, name):
+        p = dp()
+        dims = (C.c_int * 4)()
+        check(lib().hfxh_simplex_get_array(self.h, name.encode(), C.byref(p), dims))
+        dims = list(dims)
+        while len(dims) > 1 and dims[-1] == 1:
+            dims.pop()
+        n = int(np.prod(dims))
+        return np.ctypeslib.as_array(p, shape=(n,)).copy().reshape(dims, order="F")
+
+    def close(self):
+        if self.h:
+            lib().hfxh_simplex_destroy(self.h)
+            self.h = C.c_void_p()

@@ -122,6 +122,18 @@ int hfxh_case_set_comm(hfxh_case *c, const char *unique_id);
 /* hfx_time_partitioned on this case's blocks: ms[0..3] phases 1-4, ms[4] solution exchange, ms[5] flux exchange, ms[6] stage */
 int hfxh_case_time_partitioned(hfxh_case *c, int reps, double ms[8]);
 
+/* ---- tetrahedra / prisms as producers of operators and metrics (row a17) ----------------------------------------------
+ * eles_tets / eles_pris of the host mirror (csrc/host/eles_simplex.cpp) set up for `order` and the given straight-sided
+ * elements: shape (3, n_spts, n_eles) column-major, n_spts 4 (tetrahedra, ele_type 2) or 6 (prisms, ele_type 3), the
+ * reference's eles::shape.  Builds loc_upts, tloc_fpts, tnorm_fpts, opp_0 .. opp_6 and the metrics (set_transforms);
+ * read them with hfxh_simplex_get_array (names as hfxh_case_get_array).  loc_1d_upts: optional 1-D abscissae of the
+ * prism's line direction (NULL: computed Gauss nodes). */
+typedef struct hfxh_simplex hfxh_simplex;
+int hfxh_simplex_create(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
+                        hfxh_simplex **out);
+int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const double **ptr, int dims[4]);
+int hfxh_simplex_destroy(hfxh_simplex *s);
+
 /* device */
 int hfxh_case_to_device(hfxh_case *c, int device);
 int hfxh_case_handles(hfxh_case *c, hfx_ctx **ctx, hfx_eles **e, hfx_inters ***faces, int *n_face_blocks);

@@ -188,3 +188,40 @@ def test_les_jacobian_vs_reference():
     c = H.Case(3, xv=d["xv"], order=2, LES=1, SGS_model=1, C_s=k["C_s"], filter_ratio=k["filter_ratio"], T_c_ic=k["T_c_ic"])
     assert rel(c.array("Jacobian_fpts"), d["Jacobian_fpts"]) < 1e-14
     c.close()
+
+
+# ---- tetrahedra and triangular prisms: operators and metrics ------------------------------------
+SIMPLEX = [("tet_p2_n2_deformed", ""), ("tet_p3_n2_deformed", ""), ("pri_p2_n2_deformed", ""), ("pri_p3_n2_deformed", ""),
+           ("mixed_p3_channel", "c2_"), ("mixed_p3_channel", "c3_"), ("mixed_p2_channel", "c2_"), ("mixed_p2_channel", "c3_")]
+
+
+@pytest.mark.parametrize("name,pre", SIMPLEX)
+def test_simplex_operators_and_metrics_vs_reference(name, pre):
+    """eles_tets / eles_pris of the host mirror (csrc/host/eles_simplex.cpp) from the mesh's shape nodes alone: point sets,
+    the seven operators and the metrics equal the genuine reference's.  The modal basis and the lifting integrals are
+    computed differently from the reference (three-term Jacobi recurrence, exact Gauss integration), so equality of the
+    matrices checks the DEFINITIONS: 1e-12 of each matrix's scale."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    g = lambda k: d[pre + k]
+    sz = [int(v) for v in g("sizes")]
+    ele_type, order, nu = sz[6], sz[5], sz[1]
+    x1 = None
+    if ele_type == 3:  # the prism's line direction: the reference's own Gauss abscissae (data/JacobiGQ.bin)
+        x1 = g("loc_upts")[2, ::(order + 1) * (order + 2) // 2]
+    shp = g("shape")[:, :(4 if ele_type == 2 else 6), :]
+    S = H.Simplex(ele_type, order, shp, viscous=1, loc_1d_upts=x1)
+    names = ["loc_upts", "tloc_fpts", "tnorm_fpts", "opp_0", "opp_3", "opp_6", "detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts",
+             "tdA_fpts", "norm_fpts", "pos_upts", "pos_fpts"]
+    for dd in range(3):
+        names += ["opp_1_%d" % dd, "opp_2_%d" % dd, "opp_4_%d" % dd, "opp_5_%d" % dd]
+    for k in names:
+        want, got = g(k), S.array(k)
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), (k, np.abs(got - want).max() / np.abs(want).max())
+    S.close()
+
+
+def test_simplex_classes_refuse_what_they_do_not_build():
+    d = dict(np.load(os.path.join(GOLDEN, "tet_p2_n2_deformed.npz")))
+    with pytest.raises(Exception):
+        H.Simplex(2, 9, d["shape"][:, :4, :])  # no point table for this order

@@ -202,3 +202,35 @@ def test_general_fused_stage_single_class_vs_reference(name):
         f.close()
     e.close(); m.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [0, 4])
+def test_mixed_channel_from_the_host_mirrors_own_operators(fused):
+    """BASELINE.json configs[3] with NOTHING numeric lifted from the reference but the mesh: operators and metrics of both
+    classes come from the host mirror's eles_tets / eles_pris (csrc/host/eles_simplex.cpp) built from the shape nodes, the
+    face tables from the mesh preprocessor's output (out of scope); the result still equals the genuine
+    reference's after every stage of a time step"""
+    import hfx
+    import hfx_host as H
+    d = dict(np.load(os.path.join(GOLDEN, "mixed_p3_channel.npz")))
+    classes, per, faces, bdy = MU.split(d)
+    for c in classes:
+        sz = [int(v) for v in per[c]["sizes"]]
+        x1 = per[c]["loc_upts"][2, ::(sz[5] + 1) * (sz[5] + 2) // 2] if sz[6] == 3 else None
+        S = H.Simplex(sz[6], sz[5], per[c]["shape"][:, :(4 if sz[6] == 2 else 6), :], viscous=1, loc_1d_upts=x1)
+        for k in ["opp_0", "opp_3", "opp_6", "detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts"] + \
+                 ["opp_%d_%d" % (w, dd) for w in (1, 2, 4, 5) for dd in range(3)]:
+            d["c%d_%s" % (c, k)] = S.array(k)
+        S.close()
+    ctx = hfx.Context(0)
+    classes, E, F = build_gpu(ctx, d)
+    nstage = int(d["c2_sizes"][7])
+    hfx.run_steps_blocks([E[c] for c in classes], F, 1, fused=fused)
+    for c in classes:
+        assert relerr(E[c].download(hfx.DISU_UPTS0), d["c%d_u_step0_stage%d" % (c, nstage - 1)]) < 1e-11, c
+    for f in F:
+        f.close()
+    for c in classes:
+        E[c].close()
+    ctx.close()
