@@ -345,6 +345,9 @@ def main():
     ap.add_argument("--shock-s0", type=float, default=-1.0, help="shock_cap 1 with this sensor threshold s0")
     ap.add_argument("--les-cs", type=float, default=-1.0, help="LES 1 with the WALE closure and this C_s (runs the split path that "
                     "keeps the corrected gradients, --mode split)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="hfx_ctx_set_option knob for A/B runs (split_grid_per_cu, xcd_order, dictionary_rows, flux_waves, "
+                         "buffer_addressing, loader_wave, flux_stamps, tensor_ops); echoed into config.options")
     ap.add_argument("--self-partition", action="store_true", help="N=1 only: the box's wrap-around faces become partition faces "
                     "to the rank itself, i.e. the partitioned stage with its RCCL exchanges priced on one GPU")
     args = ap.parse_args()
@@ -407,6 +410,11 @@ def main():
     case.to_device(local_rank)
     ctx, e, faces, nb = case.handles()
     lib = hfx.lib()
+    options = {}
+    for kv in args.opt:
+        k, v = kv.split("=")
+        hfx.check(lib.hfx_ctx_set_option(ctx, k.encode(), C.c_int(int(v))))
+        options[k] = int(v)
     ex = None
     partitioned = world > 1 or selfp is not None
     if partitioned:
@@ -641,7 +649,7 @@ def main():
                                    (", LES WALE C_s %g" % args.les_cs if args.les_cs >= 0 else ""),
                        "n_eles_per_gpu": case.n_eles, "dof_per_gpu": dof_per_rank, "path": mode,
                        "solution_points": "reference's data/JacobiGQ.bin row" if nodes is not None else "computed Gauss nodes",
-                       "multi_gpu": mg, "env_knobs": knobs},
+                       "multi_gpu": mg, "options": options, "env_knobs": knobs},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if phases is not None:

@@ -2114,7 +2114,8 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   hipStream_t st = e->ctx->stream;
   const Phys P = e->ctx->phys();
   const long plane_f = (long)e->n_fpts * e->n_eles;
-  static const int grid_per_cu = getenv("HFX_SPLIT_GRID_PER_CU") ? std::max(1, atoi(getenv("HFX_SPLIT_GRID_PER_CU"))) : 16;
+  const hfx_ctx::Options &opt = e->ctx->opt;
+  const int grid_per_cu = std::max(1, opt.split_grid_per_cu);
   const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * grid_per_cu);
   auto face_args = [&](hfx_inters *f) {
     SplitFaceArgs a{};
@@ -2130,15 +2131,14 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   Split2Args e2{};
   if (variant == 3)
   {
-    if (getenv("HFX_FLUX_STAMPS") && !F->stamps)
+    if (opt.flux_stamps && !F->stamps)
     {
       HFX_HIP(hipMalloc((void **)&F->stamps, sizeof(long long) * 64));
       HFX_HIP(hipMemset(F->stamps, 0, sizeof(long long) * 64));
     }
     if (!F->fn_fpts) HFX_HIP(hipMalloc((void **)&F->fn_fpts, sizeof(double) * (size_t)plane_f * e->n_fields));
     e2.n_eles = ea.n_eles;
-    static const bool no_xcd = getenv("HFX_NO_XCD_ORDER") != nullptr;
-    e2.xcd_order = no_xcd ? 0 : 1;
+    e2.xcd_order = opt.xcd_order ? 1 : 0;
     e2.pk_g = F->pk_g; e2.pk_r = F->pk_r; e2.tab_g = F->tab_g; e2.tab_r = F->tab_r; e2.o1m_dim = F->o1m_dim;
     e2.detjac_upts = ea.detjac_upts; e2.JGinv_upts = ea.JGinv_upts; e2.detjac_fpts = ea.detjac_fpts;
     e2.JGinv_fpts = ea.JGinv_fpts; e2.norm_fpts = e->norm_fpts;
@@ -2183,10 +2183,10 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
         if (hfx_eles_evaluate_invFlux_over_int(e)) return 1;
         e2.tdisf_in = e->arr[HFX_TDISF_UPTS];
       }
-      static const bool dict_only = getenv("HFX_SPLIT_DICT") != nullptr; // A/B switch for measurements
-      static const int waves = getenv("HFX_SPLIT2T_WAVES") ? atoi(getenv("HFX_SPLIT2T_WAVES")) : HFX_SPLIT2T_WAVES;
+      const bool dict_only = opt.dictionary_rows != 0;
+      const int waves = opt.flux_waves;
       // buffer-descriptor addressing needs 32-bit byte offsets into the largest array the kernel touches
-      static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
+      const bool nobuf = !opt.buffer_addressing;
       // (the largest array the launch really touches: the metric tensors at the flux points, and the n_fields * n_dims
       // component arrays only when they are in use -- gradients at boundary points, the de-aliased flux)
       // -- over BOTH point sets: quads with N >= 5 have more solution points than flux points
@@ -2199,7 +2199,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
 #define HFX_FLUX_LAUNCH(WV_, BUF_, OI_, LW_)                                                                                  \
   hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_, LW_>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2,   \
                      F->t_coef, F->t_idx)
-      static const bool no_lw = getenv("HFX_NO_LOADER_WAVE") != nullptr; // A/B switch
+      const bool no_lw = !opt.loader_wave;
       constexpr bool lw_fits = loader_wave_fits<ND, N>();
       const bool lw = lw_fits && buf && !no_lw && waves == 2;
       bool launched = false;
@@ -2278,7 +2278,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     if (variant == 3)
     {
       // buffer-descriptor addressing needs 32-bit byte offsets
-      static const bool nobuf = getenv("HFX_NOBUF") != nullptr;
+      const bool nobuf = !opt.buffer_addressing;
       const bool small = (double)std::max<long>(plane_f, (long)e->n_upts * e->n_eles) * e->n_fields * 8.0 < 4294967296.0;
       if (small && !nobuf)
         hipLaunchKernelGGL((split_update_kernel<ND, N, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
@@ -2413,7 +2413,7 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
       fprintf(stderr, "   (fill | bar1 | A | bar2 | B | bar3 | C | bar4 | D)  total %lld\n", h[w * 16 + 9] - h[w * 16]);
     }
   }
-  const bool tensor = e->fused->tensor_ok && getenv("HFX_SPLIT_DICT") == nullptr;
+  const bool tensor = e->fused->tensor_ok && !e->ctx->opt.dictionary_rows;
   snprintf(names, names_len, "%s",
            variant == 3 ? (tensor ? "face_delta_kernel,split_flux_tensor_kernel,face_flux2_kernel,split_update_kernel"
                                   : "face_delta_kernel,split_flux_kernel,face_flux2_kernel,split_update_kernel")

@@ -364,6 +364,23 @@ int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL)
   return 0;
 }
 
+int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
+{
+  HFX_CHECK(ctx && name, "hfx_ctx_set_option: NULL argument");
+  hfx_ctx::Options &o = ctx->opt;
+  const std::string n(name);
+  if (n == "split_grid_per_cu") { HFX_CHECK(value >= 1, "split_grid_per_cu must be >= 1"); o.split_grid_per_cu = value; }
+  else if (n == "xcd_order") o.xcd_order = value != 0;
+  else if (n == "dictionary_rows") o.dictionary_rows = value != 0;
+  else if (n == "flux_waves") { HFX_CHECK(value == 2 || value == 3, "flux_waves must be 2 or 3"); o.flux_waves = value; }
+  else if (n == "buffer_addressing") o.buffer_addressing = value != 0;
+  else if (n == "loader_wave") o.loader_wave = value != 0;
+  else if (n == "flux_stamps") o.flux_stamps = value != 0;
+  else if (n == "tensor_ops") o.tensor_ops = value != 0;
+  else HFX_CHECK(false, "hfx_ctx_set_option: unknown option %s", name);
+  return 0;
+}
+
 int hfx_ctx_get_dt(hfx_ctx *ctx, double *dt)
 {
   HFX_CHECK(ctx && dt, "hfx_ctx_get_dt: NULL argument");

@@ -68,6 +68,18 @@ struct hfx_ctx
   int contract_mode = HFX_CONTRACT_AUTO;
   int fused_mode = 3; // which split variant hfx_time_fused_kernels / hfx_fused_kernel_bytes / hfx_stage_partitioned use (2 or 3)
   int n_cu = 256;
+  // measurement knobs (hfx_ctx_set_option): kernel variants that give the same results; defaults are the product path
+  struct Options
+  {
+    int split_grid_per_cu = 16; // persistent workgroups per CU of the split element kernels
+    int xcd_order = 1;          // workgroups of one XCD walk one contiguous eighth of the elements
+    int dictionary_rows = 0;    // 1: the dictionary-row flux kernel even when the operators are tensor products
+    int flux_waves = 2;         // waves per SIMD the sum-factorised flux kernel is launched for (2 or 3)
+    int buffer_addressing = 1;  // buffer-descriptor addressing where every array is below 4 GiB
+    int loader_wave = 1;        // the LDS-DMA loader wave of the flux kernel where the element size fits
+    int flux_stamps = 0;        // 1: phase time stamps of one workgroup of the flux kernel (printed by hfx_time_fused_kernels)
+    int tensor_ops = 1;         // sum-factorised over-integration / shock capturing on tensor-product classes
+  } opt;
   double CFL = 0.0; // run_input.CFL (hfx_ctx_set_CFL); dt_type 1 / 2 only
   bool have_CFL = false;
   hfx::Phys phys() const

@@ -443,20 +443,20 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
     for (i = 0; i < FlowSol->n_ele_types; i++)
       if (FlowSol->mesh_eles(i)) (FlowSol->mesh_eles(i)->*m)();
   };
-  /*! Extrapolate the solution to the flux points. */
+  // 1: flux-point values of the state (every class)
   each_ele(&eles::extrapolate_solution);
-  /*! Send the solution at the flux points across the MPI interfaces. */
+  // 2: the packed flux-point solution leaves for the neighbour ranks while the element-local work below runs
   if (mpi)
     for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_solution();
   if (FlowSol->run_input.viscous)
-    /*! Compute the uncorrected transformed gradient of the solution at the solution points. */
+    // 3: reference-space gradient before the interface correction
     each_ele(&eles::calculate_gradient);
-  /*! Compute the transformed inviscid flux at the solution points. */
+  // 4: inviscid part of the transformed flux (de-aliased through the cubature points when over_int is set)
   if (FlowSol->run_input.over_int) /* src/solver.cpp:82-91 */
     each_ele(&eles::evaluate_invFlux_over_int);
   else
     each_ele(&eles::evaluate_invFlux);
-  /*! Compute the transformed normal inviscid numerical fluxes, common solution and corrections. */
+  // 5-7: Riemann flux and LDG common solution on interior, boundary and -- once their data has arrived -- partition faces
   for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_invFlux();
   for (i = 0; i < FlowSol->n_bdy_inter_types; i++)
     FlowSol->mesh_bdy_inters(i).evaluate_boundaryConditions_invFlux(FlowSol, FlowSol->time);
@@ -467,33 +467,32 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
   }
   if (FlowSol->run_input.viscous)
   {
-    /*! Compute physical corrected gradient of the solution at the solution and flux points. */
+    // 8: interface correction of the gradient, extrapolation to the flux points, transform to physical space
     each_ele(&eles::correct_gradient);
-    /*! Send the corrected physical gradients across the MPI interface. */
+    // 9: the corrected gradients leave for the neighbour ranks
     if (mpi)
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_corrected_gradient();
-    /*! Compute discontinuous transformed viscous flux at upts and add to total transformed flux. */
+    // 10: viscous part added to the transformed flux
     each_ele(&eles::evaluate_viscFlux);
-    /*! If using LES, extrapolate the transformed SGS flux to the flux points and take it back to physical space (src/solver.cpp:162-167). */
+    // LES: the SGS flux at the flux points, back in physical space (src/solver.cpp:162-167)
     if (FlowSol->run_input.LES) each_ele(&eles::extrapolate_sgsFlux);
   }
-  /*! Compute the transformed normal discontinuous total flux at flux points. */
+  // 11: normal component of the discontinuous flux at the flux points
   each_ele(&eles::extrapolate_totalFlux);
-  /*! Compute the transformed divergence of total flux at solution points. */
+  // 12: divergence of the discontinuous flux
   each_ele(&eles::calculate_divergence);
   if (FlowSol->run_input.viscous)
   {
-    /*! Compute transformed normal interface viscous flux and add to transformed normal inviscid flux. */
+    // 13-15: LDG viscous common flux added on interior, boundary and partition faces
     for (i = 0; i < FlowSol->n_int_inter_types; i++) FlowSol->mesh_int_inters(i).calculate_common_viscFlux();
     for (i = 0; i < FlowSol->n_bdy_inter_types; i++) FlowSol->mesh_bdy_inters(i).evaluate_boundaryConditions_viscFlux(FlowSol->time);
-    /*! Evaluate the MPI interfaces. */
     if (mpi)
     {
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_corrected_gradient();
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).calculate_common_viscFlux();
     }
   }
-  /*! Compute the transformed divergence of the continuous flux. */
+  // 16: correction by the flux jump: the divergence of the continuous flux
   each_ele(&eles::calculate_corrected_divergence);
 }
 

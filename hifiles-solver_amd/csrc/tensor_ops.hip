@@ -163,14 +163,13 @@ static int upload_d(double **dst, const std::vector<double> &v)
 }
 
 static const double KRON_TOL = 1e-12;
-static bool disabled() { static const bool off = getenv("HFX_NO_TENSOR_OPS") != nullptr; return off; }
 
 int tensor_over_int_setup(hfx_eles *e, int n_cubpts, const double *opp_cub, const double *filter)
 {
   TensorOps *T = ops_of(e);
   T->over_int = false;
   const int N = tensor_n1(e);
-  if (!N || disabled()) return 0;
+  if (!N) return 0;
   int Nc = 0;
   for (int c = 1; c <= 64; c++)
     if (ipow_i(c, e->n_dims) == n_cubpts) Nc = c;
@@ -194,7 +193,7 @@ int tensor_shock_setup(hfx_eles *e, const double *inv_vandermonde, const double 
   TensorOps *T = ops_of(e);
   T->shock = false;
   const int N = tensor_n1(e);
-  if (!N || N > 6 || disabled()) return 0; // instantiated: P1..P5
+  if (!N || N > 6) return 0; // instantiated: P1..P5
   const int nu = e->n_upts, nd = e->n_dims;
   std::vector<int> t_of_h;
   hierarchical_to_tensor(nd, N, t_of_h);
@@ -216,8 +215,8 @@ int tensor_shock_setup(hfx_eles *e, const double *inv_vandermonde, const double 
   return 0;
 }
 
-bool tensor_over_int_available(const hfx_eles *e) { return e->tensor_ops && ((TensorOps *)e->tensor_ops)->over_int; }
-bool tensor_shock_available(const hfx_eles *e) { return e->tensor_ops && ((TensorOps *)e->tensor_ops)->shock; }
+bool tensor_over_int_available(const hfx_eles *e) { return e->ctx->opt.tensor_ops && e->tensor_ops && ((TensorOps *)e->tensor_ops)->over_int; }
+bool tensor_shock_available(const hfx_eles *e) { return e->ctx->opt.tensor_ops && e->tensor_ops && ((TensorOps *)e->tensor_ops)->shock; }
 
 // ---- device ---------------------------------------------------------------------------------------------------
 

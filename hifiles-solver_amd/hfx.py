@@ -124,6 +124,9 @@ class Context:
     def set_contract_mode(self, mode):
         check(lib().hfx_ctx_set_contract_mode(self.h, C.c_int(mode)))
 
+    def set_option(self, name, value):
+        check(lib().hfx_ctx_set_option(self.h, name.encode(), C.c_int(int(value))))
+
     def set_CFL(self, CFL):
         check(lib().hfx_ctx_set_CFL(self.h, C.c_double(CFL)))
 
