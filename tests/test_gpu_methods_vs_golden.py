@@ -20,9 +20,10 @@ pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # the restart fixtures hold a state file only (tests/test_restart_io.py), the long run and the plot-point fixtures states
-# only (test_gpu_host_mirror.py), the full-size fixtures norms and sample elements (test_fullsize_vs_reference.py)
+# only (test_gpu_host_mirror.py), the full-size fixtures norms and sample elements (test_fullsize_vs_reference.py), the
+# mixed-mesh fixtures several element classes (test_mixed_mesh.py)
 ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-             if "restart" not in p and "_long" not in p and "_plot" not in p and "_tgv" not in p)
+             if "restart" not in p and "_long" not in p and "_plot" not in p and "_tgv" not in p and "mixed_" not in p)
 BDY = [n for n in ALL if "bdy" in n]
 RTOL1 = 1e-12
 # div_tconf is a difference of terms ~1e3 times larger than itself (pressure-dominated energy

@@ -17,7 +17,8 @@ import oracle_py as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # the full-size fixtures (hex_p4_n*_tgv) hold norms and sample elements only: tests/test_fullsize_vs_reference.py
-ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "_tgv" not in p)
+# the mixed-mesh fixtures several element classes: tests/test_mixed_mesh.py
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "_tgv" not in p and "mixed_" not in p)
 
 # The oracle repeats the reference's operation order; remaining differences are compiler-level
 # (x87-free SSE2 both sides, no FMA) so the tolerance is a few ulps of the array's scale.
