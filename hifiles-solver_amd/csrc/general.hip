@@ -143,12 +143,17 @@ __device__ __forceinline__ void tile_mac(g_f64x4 (&acc)[NA], const double *__res
 // ---------------------------------------------------------------------------------------------------------------
 // flux kernel: u, delta -> div_tdisf, norm_tdisf, Fn   (steps 3-4, 8 (both halves), 10-12 of CalcResidual's sequence)
 // ---------------------------------------------------------------------------------------------------------------
-template <int W>
+// NUc, NFPc: the element class's point counts as compile-time constants (0: read from the arguments); the common sizes
+// are instantiated so that trip counts, LDS offsets and the index divisions fold
+template <int W, int NUc, int NFPc>
 __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a)
 {
   constexpr int NF = 5, ND = 3, T = 64 * W;
   extern __shared__ double lds[];
-  const int nu = a.nu, nfp = a.nfp, KU = a.KU, KF = a.KF;
+  const int nu = NUc ? NUc : a.nu, nfp = NFPc ? NFPc : a.nfp;
+  const int KU = (nu + 3) & ~3, KF = (nfp + 3) & ~3, MU = (nu + 15) & ~15, MF = (nfp + 15) & ~15;
+  const unsigned inv_nu = NUc ? (unsigned)(4294967296ull / (unsigned)(NUc ? NUc : 1)) + 1u : a.inv_nu;
+  const unsigned inv_nfp = NFPc ? (unsigned)(4294967296ull / (unsigned)(NFPc ? NFPc : 1)) + 1u : a.inv_nfp;
   double *U = lds;                 // [NF][KU][16]      the state; later: nothing
   double *D = U + NF * KU * GB;    // [NF][KF][16]      delta_disu_fpts
   double *G = D + NF * KF * GB;    // [NF*ND][KU][16]   reference-space gradient, then the transformed total flux
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
     const double *src = a.u0 + e0 * nu + f * plane_u;
     for (int q = tid; q < KU * GB; q += T)
     {
-      const int el = (int)__umulhi((unsigned)q, a.inv_nu), k = q - el * nu; // q < nu*16: a real entry; the rest of the plane: K padding
+      const int el = (int)__umulhi((unsigned)q, inv_nu), k = q - el * nu; // q < nu*16: a real entry; the rest of the plane: K padding
       if (q < nu * GB)
         U[f * KU * GB + sw(k, el)] = (el < nval) ? src[q] : 0.0;
       else
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       const double *sd = a.delta + e0 * nfp + f * plane_f;
       for (int q = tid; q < KF * GB; q += T)
       {
-        const int el = (int)__umulhi((unsigned)q, a.inv_nfp), k = q - el * nfp;
+        const int el = (int)__umulhi((unsigned)q, inv_nfp), k = q - el * nfp;
         if (q < nfp * GB)
           D[f * KF * GB + sw(k, el)] = (el < nval) ? sd[q] : 0.0;
         else
@@ -201,15 +206,15 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
   {
     // ---- P1: reference-space corrected gradient at the solution points (calculate_gradient + first half of
     //          correct_gradient, src/eles.cpp:1823,1900): G(f,d) = opp_4[d] U(f) + opp_5[d] D(f)
-    const int n_rt = a.MU / 16;
+    const int n_rt = MU / 16;
     for (int it = wave; it < n_rt * ND; it += W)
     {
       const int d = it % ND, rt = it / ND;
       g_f64x4 acc[NF];
 #pragma unroll
       for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
-      tile_mac<NF>(acc, a.o4[d], a.MU, rt, U, KU * GB, KU / 4, li, lk);
-      tile_mac<NF>(acc, a.o5[d], a.MU, rt, D, KF * GB, KF / 4, li, lk);
+      tile_mac<NF>(acc, a.o4[d], MU, rt, U, KU * GB, KU / 4, li, lk);
+      tile_mac<NF>(acc, a.o5[d], MU, rt, D, KF * GB, KF / 4, li, lk);
       const int row = rt * 16 + li;
       if (row < nu)
 #pragma unroll
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
 
     // ---- P2: gradient at the flux points (second half of correct_gradient: opp_6, then the transform with the flux
     //          points' own metrics, src/eles.cpp:1930,1998) and the viscous flux there, projected on the point's normal
-    const int n_ft = a.MF / 16;
+    const int n_ft = MF / 16;
     for (int rt = wave; rt < n_ft; rt += W)
     {
       g_f64x4 acc[NF * ND];
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
         for (int m = 0; m < ND; m++) pn[slot][m] = ok ? a.norm_fpts[o + m * plane_f] : 0.0;
       };
       request(0, 0);
-      tile_mac<NF * ND>(acc, a.o6, a.MF, rt, G, KU * GB, KU / 4, li, lk);
+      tile_mac<NF * ND>(acc, a.o6, MF, rt, G, KU * GB, KU / 4, li, lk);
 #pragma unroll
       for (int rg = 0; rg < 4; rg++)
       {
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
   //          src/eles.cpp:1415,1973,2285): G(f,d) <- transformed total flux
   for (int q = tid; q < nu * GB; q += T)
   {
-    const int el = (int)__umulhi((unsigned)q, a.inv_nu), pt = q - el * nu;
+    const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
     if (el < nval)
     {
       const long o = pt + (long)nu * (e0 + el);
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
   // ---- P4: discontinuous divergence (opp_2) and normal flux at the flux points (opp_1), summed over the dimensions
   //          (calculate_divergence, extrapolate_totalFlux; src/eles.cpp:1651,1549) -> HBM, 128-byte runs
   {
-    const int n_ut = a.MU / 16, n_ft = a.MF / 16;
+    const int n_ut = MU / 16, n_ft = MF / 16;
     for (int t = wave; t < n_ut + n_ft; t += W)
     {
       const bool is_div = t < n_ut;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int d = 0; d < ND; d++)
-        tile_mac<NF>(acc, is_div ? a.o2[d] : a.o1[d], is_div ? a.MU : a.MF, rt, G + NF * d * KU * GB, KU * GB, KU / 4, li, lk);
+        tile_mac<NF>(acc, is_div ? a.o2[d] : a.o1[d], is_div ? MU : MF, rt, G + NF * d * KU * GB, KU * GB, KU / 4, li, lk);
       const int row = rt * 16 + li, n = is_div ? nu : nfp;
       double *out = is_div ? a.div : a.ntd;
       const long plane = is_div ? plane_u : plane_f;
@@ -369,12 +374,15 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
 // update kernel: div_tdisf + opp_3 (norm_tconf - norm_tdisf) -> RK update -> disu_fpts of the new state
 // (calculate_corrected_divergence, AdvanceSolution, extrapolate_solution; src/eles.cpp:1738,1080,1360)
 // ---------------------------------------------------------------------------------------------------------------
-template <int W>
+template <int W, int NUc, int NFPc>
 __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
 {
   constexpr int NF = 5, T = 64 * W;
   extern __shared__ double lds[];
-  const int nu = a.nu, nfp = a.nfp, KU = a.KU, KF = a.KF;
+  const int nu = NUc ? NUc : a.nu, nfp = NFPc ? NFPc : a.nfp;
+  const int KU = (nu + 3) & ~3, KF = (nfp + 3) & ~3, MU = (nu + 15) & ~15, MF = (nfp + 15) & ~15;
+  const unsigned inv_nu = NUc ? (unsigned)(4294967296ull / (unsigned)(NUc ? NUc : 1)) + 1u : a.inv_nu;
+  const unsigned inv_nfp = NFPc ? (unsigned)(4294967296ull / (unsigned)(NFPc ? NFPc : 1)) + 1u : a.inv_nfp;
   double *X = lds;               // [NF][KF][16]  norm_tconf - norm_tdisf
   double *S = X + NF * KF * GB;  // [NF][KU][16]  the correction, then the new state
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
     const double *tc = a.tconf + e0 * nfp + f * plane_f, *nt = a.ntd + e0 * nfp + f * plane_f;
     for (int q = tid; q < KF * GB; q += T)
     {
-      const int el = (int)__umulhi((unsigned)q, a.inv_nfp), k = q - el * nfp;
+      const int el = (int)__umulhi((unsigned)q, inv_nfp), k = q - el * nfp;
       if (q < nfp * GB)
         X[f * KF * GB + sw(k, el)] = (el < nval) ? tc[q] + -1.0 * nt[q] : 0.0; // the daxpy of src/eles.cpp:1746
       else
@@ -400,13 +408,13 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
   }
   __syncthreads();
   {
-    const int n_rt = a.MU / 16;
+    const int n_rt = MU / 16;
     for (int rt = wave; rt < n_rt; rt += W)
     {
       g_f64x4 acc[NF];
 #pragma unroll
       for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
-      tile_mac<NF>(acc, a.o3, a.MU, rt, X, KF * GB, KF / 4, li, lk);
+      tile_mac<NF>(acc, a.o3, MU, rt, X, KF * GB, KF / 4, li, lk);
       const int row = rt * 16 + li;
       if (row < nu)
 #pragma unroll
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
   {
     for (int q = tid; q < nu * GB; q += T)
     {
-      const int el = (int)__umulhi((unsigned)q, a.inv_nu), pt = q - el * nu;
+      const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
       const int so = f * KU * GB + sw(pt, el);
       if (el >= nval)
       {
@@ -473,13 +481,13 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
   }
   __syncthreads();
   {
-    const int n_ft = a.MF / 16;
+    const int n_ft = MF / 16;
     for (int rt = wave; rt < n_ft; rt += W)
     {
       g_f64x4 acc[NF];
 #pragma unroll
       for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
-      tile_mac<NF>(acc, a.o0, a.MF, rt, S, KU * GB, KU / 4, li, lk);
+      tile_mac<NF>(acc, a.o0, MF, rt, S, KU * GB, KU / 4, li, lk);
       const int row = rt * 16 + li;
       if (row < nfp)
 #pragma unroll
@@ -711,8 +719,8 @@ static GFaceArgs gface_args(hfx_inters *f)
   return a;
 }
 
-template <int W>
-static int launch_element_kernels(hfx_eles *e, const GenArgs &a, bool flux)
+template <int W, int NUc, int NFPc>
+static int launch_element_kernels_t(hfx_eles *e, const GenArgs &a, bool flux)
 {
   GeneralData *g = (GeneralData *)e->general;
   const unsigned grid = (unsigned)((e->n_eles + GB - 1) / GB);
@@ -723,10 +731,10 @@ static int launch_element_kernels(hfx_eles *e, const GenArgs &a, bool flux)
     static size_t configured = 0;
     if (lds > configured)
     {
-      HFX_HIP(hipFuncSetAttribute((const void *)general_flux_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HFX_HIP(hipFuncSetAttribute((const void *)general_flux_kernel<W, NUc, NFPc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       configured = lds;
     }
-    hipLaunchKernelGGL(general_flux_kernel<W>, dim3(grid), dim3(64 * W), lds, st, a);
+    hipLaunchKernelGGL((general_flux_kernel<W, NUc, NFPc>), dim3(grid), dim3(64 * W), lds, st, a);
   }
   else
   {
@@ -734,13 +742,25 @@ static int launch_element_kernels(hfx_eles *e, const GenArgs &a, bool flux)
     static size_t configured = 0;
     if (lds > configured)
     {
-      HFX_HIP(hipFuncSetAttribute((const void *)general_update_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HFX_HIP(hipFuncSetAttribute((const void *)general_update_kernel<W, NUc, NFPc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       configured = lds;
     }
-    hipLaunchKernelGGL(general_update_kernel<W>, dim3(grid), dim3(64 * W), lds, st, a);
+    hipLaunchKernelGGL((general_update_kernel<W, NUc, NFPc>), dim3(grid), dim3(64 * W), lds, st, a);
   }
   HFX_HIP(hipGetLastError());
   return 0;
+}
+
+// the element classes of the reference's orders 1..3 (tetrahedra 4/12, 10/24, 20/40; prisms 6/18, 18/39, 40/68 solution /
+// flux points) get instantiations with compile-time sizes; anything else runs the size-generic form
+template <int W>
+static int launch_element_kernels(hfx_eles *e, const GenArgs &a, bool flux)
+{
+#define HFX_GEN_CASE(NU_, NFP_) \
+  if (a.nu == NU_ && a.nfp == NFP_) return launch_element_kernels_t<W, NU_, NFP_>(e, a, flux);
+  HFX_GEN_CASE(4, 12) HFX_GEN_CASE(10, 24) HFX_GEN_CASE(20, 40) HFX_GEN_CASE(6, 18) HFX_GEN_CASE(18, 39) HFX_GEN_CASE(40, 68)
+#undef HFX_GEN_CASE
+  return launch_element_kernels_t<W, 0, 0>(e, a, flux);
 }
 
 // which: 0 the whole stage, 1 .. 4 one of its four parts (for the per-kernel timing)
@@ -766,8 +786,10 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
     {
       const GenArgs a = gen_args(eles[i], in_step, last_stage);
       // two workgroups per CU where the batch's LDS image allows it (4 waves each), otherwise one of 8 waves
-      if (flux_lds_bytes((GeneralData *)eles[i]->general) <= 80 * 1024 ? launch_element_kernels<4>(eles[i], a, true)
-                                                                        : launch_element_kernels<8>(eles[i], a, true))
+      int w = ctx->opt.general_waves;
+      if (w == 0) w = flux_lds_bytes((GeneralData *)eles[i]->general) <= 80 * 1024 ? 4 : 8;
+      if (w == 3 ? launch_element_kernels<3>(eles[i], a, true) : w == 4 ? launch_element_kernels<4>(eles[i], a, true)
+                                                                         : launch_element_kernels<8>(eles[i], a, true))
         return 1;
     }
   if (which == 0 || which == 3)

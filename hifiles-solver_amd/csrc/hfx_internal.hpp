@@ -79,6 +79,7 @@ struct hfx_ctx
     int loader_wave = 1;        // the LDS-DMA loader wave of the flux kernel where the element size fits
     int flux_stamps = 0;        // 1: phase time stamps of one workgroup of the flux kernel (printed by hfx_time_fused_kernels)
     int tensor_ops = 1;         // sum-factorised over-integration / shock capturing on tensor-product classes
+    int general_waves = 0;      // waves per workgroup of the general flux kernel: 0 by the LDS image (4 or 8), else 3, 4 or 8
   } opt;
   double CFL = 0.0; // run_input.CFL (hfx_ctx_set_CFL); dt_type 1 / 2 only
   bool have_CFL = false;

@@ -49,8 +49,11 @@ def main():
     ap.add_argument("--tiles", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--fused", type=int, default=4, help="4: the general fused stage (csrc/general.hip), 0: per method")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE")
     args = ap.parse_args()
     ctx = hfx.Context(0)
+    for kv in args.opt:
+        ctx.set_option(*kv.split("="))
     lib = hfx.lib()
     for name in ("tet_p3_n2_deformed", "pri_p3_n2_deformed"):
         d = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
