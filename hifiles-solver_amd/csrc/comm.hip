@@ -77,7 +77,7 @@ static int rccl_load()
     }                                                                                                        \
   } while (0)
 
-// which buffers an exchange moves and how long a face record is.  kind 0: the flux-point solution; kind 1: the
+// which buffers an exchange moves and how long a face record is.  kind 0: the flux-point solution; kind 2: the SGS flux; kind 1: the
 // corrected gradient (per-method path and fused mode 2, as the reference sends it) or, with `projected`, each side's
 // viscous flux projected on its own normal (fused mode 3: n_fields instead of n_fields * n_dims doubles per flux point)
 static void exchange_buffers(const hfx_inters *f, int kind, bool projected, double *&out, double *&in, long &rec)
@@ -88,6 +88,13 @@ static void exchange_buffers(const hfx_inters *f, int kind, bool projected, doub
   {
     out = f->out_disu;
     in = f->in_disu;
+    return;
+  }
+  if (kind == 2) // LES: the physical SGS flux, laid out like the gradient (src/mpi_inters.cpp:65-66)
+  {
+    out = f->out_sgsf;
+    in = f->in_sgsf;
+    rec *= l->n_dims;
     return;
   }
   out = f->out_grad;
@@ -191,7 +198,8 @@ static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int,
   }
   const int nst = n_rk_stages(ctx->params);
   const bool visc = ctx->params.viscous != 0;
-  const bool projected = ctx->fused_mode != 2; // fused mode 3 sends the projected viscous flux
+  const bool projected = split_variant(e) == 3; // variant 3 sends the projected viscous flux
+  const bool les = e->les_ready;                // third message: the SGS flux (src/solver.cpp:168-178,203-206)
   hipStream_t st = ctx->stream, cs = comm->stream;
   auto phase = [&](int ph, int stage, int first) {
     return split_stage_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, ph, stage, first);
@@ -218,12 +226,14 @@ static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int,
       {
         if (T) HFX_HIP(hipEventRecord(T->x1[0], st));
         if (start_exchange(comm, mpi_faces, n_mpi, 1, projected)) return 1;
+        if (les && start_exchange(comm, mpi_faces, n_mpi, 2, false)) return 1;
         if (T) HFX_HIP(hipEventRecord(T->x1[1], cs));
       }
       if (T) HFX_HIP(hipEventRecord(T->ph[2], st));
       if (phase(3, rk, 0)) return 1;
       if (T) HFX_HIP(hipEventRecord(T->ph[3], st));
       if (visc && wait_exchange(comm, 1)) return 1;
+      if (visc && les && wait_exchange(comm, 2)) return 1;
       if (phase(4, rk, 0)) return 1;
       if (T) HFX_HIP(hipEventRecord(T->x0[0], st));
       if (start_exchange(comm, mpi_faces, n_mpi, 0, false)) return 1;
@@ -296,7 +306,7 @@ int hfx_comm_create(hfx_ctx *ctx, const char id[HFX_COMM_ID_BYTES], int nranks, 
   }
   c->nccl = comm;
   HFX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 3; k++)
   {
     HFX_HIP(hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming));
     HFX_HIP(hipEventCreateWithFlags(&c->received[k], hipEventDisableTiming));
@@ -311,7 +321,7 @@ int hfx_comm_destroy(hfx_comm *c)
   if (!c) return 0;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 3; k++)
   {
     if (c->packed[k]) (void)hipEventDestroy(c->packed[k]);
     if (c->received[k]) (void)hipEventDestroy(c->received[k]);
@@ -382,6 +392,19 @@ int hfx_mpi_inters_receive_corrected_gradient(hfx_inters *f, hfx_comm *c)
 {
   HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_receive_corrected_gradient: bad argument");
   return wait_exchange(c, 1);
+}
+
+int hfx_mpi_inters_send_sgsf_fpts(hfx_inters *f, hfx_comm *c)
+{
+  HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_send_sgsf_fpts: bad argument");
+  if (hfx_mpi_inters_pack_sgsf(f)) return 1;
+  return start_exchange(c, &f, 1, 2, false);
+}
+
+int hfx_mpi_inters_receive_sgsf_fpts(hfx_inters *f, hfx_comm *c)
+{
+  HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_receive_sgsf_fpts: bad argument");
+  return wait_exchange(c, 2);
 }
 
 int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,

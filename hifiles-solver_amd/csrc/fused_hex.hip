@@ -583,35 +583,6 @@ __global__ __launch_bounds__(256) void face_delta_kernel(const SplitFaceArgs a)
   }
 }
 
-// f(k, i) += sum_l (|J|^-1 ts(k, l)) J(i, l): the reference-space SGS flux of flux point `o`, taken to physical space in
-// the operation order of the reference's dgemm (alpha = 1/detjac, l outer; src/funcs.cpp:110-117)
-template <int ND>
-__device__ __forceinline__ void add_sgs_flux(const double *sgsf, const double *jac, const double *detjac, long o, long plane,
-                                             double (&f)[(ND + 2) * ND])
-{
-  constexpr int NF = ND + 2;
-  double J[ND * ND];
-#pragma unroll
-  for (int q = 0; q < ND * ND; q++) J[q] = jac[o * (ND * ND) + q];
-  const double inv_detjac = 1.0 / detjac[o];
-#pragma unroll
-  for (int k = 0; k < NF; k++)
-  {
-    double ps[ND];
-#pragma unroll
-    for (int i = 0; i < ND; i++) ps[i] = 0.0;
-#pragma unroll
-    for (int l = 0; l < ND; l++)
-    {
-      const double temp = inv_detjac * sgsf[o + (k + NF * l) * plane];
-#pragma unroll
-      for (int i = 0; i < ND; i++) ps[i] += temp * J[i + ND * l];
-    }
-#pragma unroll
-    for (int i = 0; i < ND; i++) f[k + NF * i] += ps[i];
-  }
-}
-
 template <int ND, int RS>
 __global__ __launch_bounds__(256) void face_flux_kernel(const SplitFaceArgs a)
 {
@@ -2345,8 +2316,9 @@ static int shock_capture_keep_fpts(hfx_eles *e)
 int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int variant)
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
-  HFX_CHECK(!e->over_int_ready || variant == 3, "fused=2 has no over-integration: use fused=3");
-  HFX_CHECK(!e->les_ready || variant == 2, "fused=3 has no LES closure (its flux kernel keeps the gradients in registers): use fused=2");
+  // an LES closure reads the corrected gradients, which variant 3 keeps in registers: such a block runs variant 2
+  if (e->les_ready && variant == 3) variant = 2;
+  HFX_CHECK(!e->over_int_ready || variant == 3, "the split variant that keeps the gradients (fused 2, which LES selects) has no over-integration");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
   if (n_steps <= 0) return 0;
@@ -2460,6 +2432,13 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
   a.out_disu = f->out_disu; a.out_grad = f->out_grad; a.in_disu = f->in_disu; a.in_grad = f->in_grad;
   a.fn = e->fused ? e->fused->fn_fpts : nullptr;
   a.P = e->ctx->phys();
+  if (e->les_ready)
+  {
+    // the split path (variant 2) keeps sgsf_fpts in reference space: the partition-face kernels take it to physical space
+    if (hfx_mpi_sgsf_buffers_internal(f)) return 1;
+    a.sgsf = e->arr[HFX_SGSF_FPTS]; a.jac_fpts = e->Jacobian_fpts; a.detjac_fpts = e->detjac_fpts;
+    a.out_sgsf = f->out_sgsf; a.in_sgsf = f->in_sgsf; a.sgs_ref = 1;
+  }
   const dim3 g((unsigned)((a.npairs + 255) / 256)), b(256);
   hipStream_t st = e->ctx->stream;
   switch (what)
@@ -2471,10 +2450,13 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
   case 4: hipLaunchKernelGGL((mpi_common_viscflux_kernel<ND, true>), g, b, 0, st, a); break;
   case 5: hipLaunchKernelGGL(mpi_pack_fn_kernel<ND>, g, b, 0, st, a); break;
   case 6: hipLaunchKernelGGL(mpi_common_flux2_kernel<ND>, g, b, 0, st, a); break;
+  case 7: hipLaunchKernelGGL(mpi_pack_sgsf_kernel<ND>, g, b, 0, st, a); break;
   }
   HFX_HIP(hipGetLastError());
   return 0;
 }
+
+int split_variant(const hfx_eles *e) { return (e->ctx->fused_mode == 2 || e->les_ready) ? 2 : 3; }
 
 int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                             int phase, int in_step, int first)
@@ -2492,9 +2474,8 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     return 0;
   };
   const bool last = in_step == nst - 1;
-  const int variant = (e->ctx->fused_mode == 2) ? 2 : 3; // 3: fluxes in the gradient kernel, Fn on the wire
-  HFX_CHECK(!e->les_ready, "hfx_stage_partitioned: LES needs the third partition-face exchange (sgsf_fpts), which is not built");
-  HFX_CHECK(!e->over_int_ready || variant == 3, "fused=2 has no over-integration: use fused=3");
+  const int variant = split_variant(e); // 3: fluxes in the gradient kernel, Fn on the wire; 2 with an LES closure
+  HFX_CHECK(!e->over_int_ready || variant == 3, "the split variant that keeps the gradients (fused 2, which LES selects) has no over-integration");
   switch (phase)
   {
   case 0:
@@ -2512,8 +2493,9 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     }
     if (!p.viscous) return 0;
     if (mpi_all(1)) return 1;
-    if (split_stage(e, int_faces, n_int, in_step, false, 2, 2)) return 1; // corrected gradients
-    return mpi_all(2);
+    if (split_stage(e, int_faces, n_int, in_step, false, 2, 2)) return 1; // corrected gradients (+ the SGS chain with LES)
+    if (mpi_all(2)) return 1;
+    return e->les_ready ? mpi_all(7) : 0; // third message: the physical SGS flux (src/solver.cpp:168-178)
   case 3:
     if (split_stage(e, int_faces, n_int, in_step, last, 3, variant)) return 1; // interior common fluxes
     return variant == 3 ? 0 : mpi_all(3);

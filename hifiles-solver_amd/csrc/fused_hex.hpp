@@ -15,6 +15,9 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
                        int variant = 2);
 // algorithmic HBM bytes per launch of each kernel, same order
 void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant = 2);
+// which split variant a partitioned block runs: 2 (the reference's gradient arrays kept) when the context asks for it or the
+// block has an LES closure, else 3
+int split_variant(const hfx_eles *e);
 // one phase of a split-path stage on a partitioned block (see hfx_stage_partitioned)
 int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                             int phase, int in_step, int first);

@@ -788,7 +788,7 @@ int hfx_inters_destroy(hfx_inters *f)
     }
   if (f->L) (void)hipFree(f->L);
   if (f->R) (void)hipFree(f->R);
-  for (double *b : {f->out_disu, f->in_disu, f->out_grad, f->in_grad})
+  for (double *b : {f->out_disu, f->in_disu, f->out_grad, f->in_grad, f->out_sgsf, f->in_sgsf})
     if (b) (void)hipFree(b);
   if (f->boundary_id) (void)hipFree(f->boundary_id);
   if (f->bcs) (void)hipFree(f->bcs);
@@ -1253,7 +1253,23 @@ static MpiArgs mpi_args(hfx_inters *f)
   a.tconf = l->arr[HFX_NORM_TCONF_FPTS]; a.delta = l->arr[HFX_DELTA_DISU_FPTS];
   a.out_disu = f->out_disu; a.out_grad = f->out_grad; a.in_disu = f->in_disu; a.in_grad = f->in_grad;
   a.P = f->ctx->phys();
+  if (l->les_ready && f->out_sgsf) // per-method path: sgsf_fpts is physical (hfx_eles_extrapolate_sgsFlux took it back)
+  {
+    a.sgsf = l->arr[HFX_SGSF_FPTS]; a.jac_fpts = l->Jacobian_fpts; a.detjac_fpts = l->detjac_fpts;
+    a.out_sgsf = f->out_sgsf; a.in_sgsf = f->in_sgsf; a.sgs_ref = 0;
+  }
   return a;
+}
+
+// the SGS-flux buffers of a partition-face block whose left block carries an LES closure (allocated on first use)
+extern "C" int hfx_mpi_sgsf_buffers_internal(hfx_inters *f)
+{
+  if (f->out_sgsf || !f->left->les_ready) return 0;
+  const size_t ng = (size_t)std::max<long>((long)f->n_inters * f->n_fpts_per_inter, 1) * f->left->n_fields * f->left->n_dims;
+  HFX_HIP(hipMalloc((void **)&f->out_sgsf, sizeof(double) * ng));
+  HFX_HIP(hipMalloc((void **)&f->in_sgsf, sizeof(double) * ng));
+  HFX_HIP(hipMemset(f->in_sgsf, 0, sizeof(double) * ng));
+  return 0;
 }
 
 #define HFX_MPI_LAUNCH(KERNEL2, KERNEL3)                                                                    \
@@ -1262,6 +1278,7 @@ static MpiArgs mpi_args(hfx_inters *f)
     HFX_CHECK(f && f->is_mpi, "not a partition-face block");                                                \
     if (f->n_inters == 0) return 0;                                                                         \
     HFX_CHECK(f->ctx->have_params, "parameters not set");                                                   \
+    if (hfx_mpi_sgsf_buffers_internal(f)) return 1;                                                         \
     const MpiArgs a = mpi_args(f);                                                                          \
     if (f->left->n_dims == 2)                                                                               \
       hipLaunchKernelGGL(KERNEL2, dim3(nblocks(a.npairs, 256)), dim3(256), 0, f->ctx->stream, a);           \
@@ -1273,6 +1290,11 @@ static MpiArgs mpi_args(hfx_inters *f)
 
 int hfx_mpi_inters_pack_solution(hfx_inters *f) { HFX_MPI_LAUNCH(mpi_pack_disu_kernel<2>, mpi_pack_disu_kernel<3>); }
 int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f) { HFX_MPI_LAUNCH(mpi_pack_grad_kernel<2>, mpi_pack_grad_kernel<3>); }
+int hfx_mpi_inters_pack_sgsf(hfx_inters *f)
+{
+  HFX_CHECK(f && f->is_mpi && f->left->les_ready, "hfx_mpi_inters_pack_sgsf: the left block has no LES closure (hfx_eles_set_les)");
+  HFX_MPI_LAUNCH(mpi_pack_sgsf_kernel<2>, mpi_pack_sgsf_kernel<3>);
+}
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f)
 {
   HFX_MPI_LAUNCH((mpi_common_invflux_kernel<2, false>), (mpi_common_invflux_kernel<3, false>));
@@ -1285,11 +1307,16 @@ int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f)
 int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n)
 {
   HFX_CHECK(f && f->is_mpi && dev && n, "hfx_mpi_inters_buffer: bad argument");
-  HFX_CHECK(which >= 0 && which <= 5, "hfx_mpi_inters_buffer: which must be 0..5");
+  HFX_CHECK(which >= 0 && which <= 7, "hfx_mpi_inters_buffer: which must be 0..7");
+  if (which >= 6)
+  {
+    HFX_CHECK(f->left->les_ready, "hfx_mpi_inters_buffer: the SGS-flux buffers exist only with an LES closure on the left block");
+    if (hfx_mpi_sgsf_buffers_internal(f)) return 1;
+  }
   const long nd = (long)f->n_inters * f->n_fpts_per_inter * f->left->n_fields;
-  double *b[6] = {f->out_disu, f->in_disu, f->out_grad, f->in_grad, f->out_grad, f->in_grad};
+  double *b[8] = {f->out_disu, f->in_disu, f->out_grad, f->in_grad, f->out_grad, f->in_grad, f->out_sgsf, f->in_sgsf};
   *dev = b[which];
-  *n = (which == 2 || which == 3) ? nd * f->left->n_dims : nd;
+  *n = (which == 2 || which == 3 || which >= 6) ? nd * f->left->n_dims : nd;
   return 0;
 }
 

@@ -157,6 +157,7 @@ struct hfx_inters
   // partition faces (is_mpi): R holds the received-record slot lut(j); buffers are owned here
   bool is_mpi = false;
   double *out_disu = nullptr, *in_disu = nullptr, *out_grad = nullptr, *in_grad = nullptr;
+  double *out_sgsf = nullptr, *in_sgsf = nullptr; // LES: physical SGS flux records (allocated when the left block has a closure)
   // neighbour segments (hfx_mpi_inters_set_neighbours): faces [send[s], send[s]+count[s]) go to peer[s], its faces arrive at recv[s]
   std::vector<int> seg_peer, seg_send, seg_recv, seg_count;
   // boundary faces (is_bdy): left side only
@@ -175,8 +176,8 @@ struct hfx_comm
   void *nccl = nullptr;         // ncclComm_t
   hipStream_t stream = nullptr; // communication stream
   int nranks = 1, rank = 0;
-  hipEvent_t packed[2] = {nullptr, nullptr};   // compute -> comm: buffers of kind 0 / 1 are packed
-  hipEvent_t received[2] = {nullptr, nullptr}; // comm -> compute: exchange of kind 0 / 1 complete
+  hipEvent_t packed[3] = {nullptr, nullptr, nullptr};   // compute -> comm: buffers of kind 0 / 1 / 2 are packed
+  hipEvent_t received[3] = {nullptr, nullptr, nullptr}; // comm -> compute: exchange of kind 0 / 1 / 2 complete
   double *scratch = nullptr;                   // device scratch of the small all-reduces
 };
 
@@ -193,5 +194,6 @@ void advance_ramp_counters(hfx_inters *const *faces, int nfb);
 // fast: the fused paths' reciprocal-multiply physics
 extern "C" int hfx_bdy_launch_internal(hfx_inters *f, int visc, int fast);
 // LES: sgsf_upts = JGinv * F_sgs from disu_upts(0) and grad_disu_upts (hfx.hip)
+extern "C" int hfx_mpi_sgsf_buffers_internal(hfx_inters *f); // allocates out / in_sgsf when the left block has a closure
 extern "C" int hfx_les_sgsf_upts_internal(hfx_eles *e);
 extern "C" int hfx_les_extrapolate_reference_internal(hfx_eles *e); // sgsf_fpts = opp_0 * sgsf_upts, not yet back-transformed

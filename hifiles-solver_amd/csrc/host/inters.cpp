@@ -235,6 +235,17 @@ void mpi_inters::receive_corrected_gradient()
   if (comm) { HFX_MPI_CALL(hfx_mpi_inters_receive_corrected_gradient(dev, comm)); return; }
   if (n_inters != 0 && exchange) exchange(exchange_user, 1, 1);
 }
+void mpi_inters::send_sgsf_fpts()
+{
+  if (comm) { HFX_MPI_CALL(hfx_mpi_inters_send_sgsf_fpts(dev, comm)); return; }
+  HFX_MPI_CALL(hfx_mpi_inters_pack_sgsf(dev));
+  if (n_inters != 0 && exchange) exchange(exchange_user, 2, 0);
+}
+void mpi_inters::receive_sgsf_fpts()
+{
+  if (comm) { HFX_MPI_CALL(hfx_mpi_inters_receive_sgsf_fpts(dev, comm)); return; }
+  if (n_inters != 0 && exchange) exchange(exchange_user, 2, 1);
+}
 void mpi_inters::calculate_common_invFlux() { HFX_MPI_CALL(hfx_mpi_inters_calculate_common_invFlux(dev)); }
 void mpi_inters::calculate_common_viscFlux() { HFX_MPI_CALL(hfx_mpi_inters_calculate_common_viscFlux(dev)); }
 

@@ -46,7 +46,7 @@ private:
 
 // exchange hook: the reference calls MPI_Isend/Irecv + MPI_Waitall inside send_* / receive_*
 // (src/mpi_inters.cpp:244-270); here the transport is pluggable (RCCL through torch.distributed in
-// the bench, gloo in the CPU tests).  kind: 0 solution, 1 corrected gradient; phase: 0 start, 1 wait.
+// the bench, gloo in the CPU tests).  kind: 0 solution, 1 corrected gradient, 2 SGS flux (LES); phase: 0 start, 1 wait.
 typedef void (*hfxh_exchange_fn)(void *user, int kind, int phase);
 
 // Host-side mirror of the reference's partition-face class (include/mpi_inters.h:40-105).
@@ -64,6 +64,8 @@ public:
   void receive_solution();           // :261 wait
   void send_corrected_gradient();    // :278
   void receive_corrected_gradient(); // :323
+  void send_sgsf_fpts();             // :339 (LES)
+  void receive_sgsf_fpts();          // :384
   void calculate_common_invFlux();   // :400
   void calculate_common_viscFlux();  // :485
   void set_exchange(hfxh_exchange_fn fn, void *user) { exchange = fn; exchange_user = user; }

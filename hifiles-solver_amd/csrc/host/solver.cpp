@@ -475,7 +475,13 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
     // 10: viscous part added to the transformed flux
     each_ele(&eles::evaluate_viscFlux);
     // LES: the SGS flux at the flux points, back in physical space (src/solver.cpp:162-167)
-    if (FlowSol->run_input.LES) each_ele(&eles::extrapolate_sgsFlux);
+    if (FlowSol->run_input.LES)
+    {
+      each_ele(&eles::extrapolate_sgsFlux);
+      // the physical SGS flux leaves for the neighbour ranks (src/solver.cpp:168-178)
+      if (mpi)
+        for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).send_sgsf_fpts();
+    }
   }
   // 11: normal component of the discontinuous flux at the flux points
   each_ele(&eles::extrapolate_totalFlux);
@@ -489,6 +495,8 @@ void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
     if (mpi)
     {
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_corrected_gradient();
+      if (FlowSol->run_input.LES) /* src/solver.cpp:203-206 */
+        for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).receive_sgsf_fpts();
       for (i = 0; i < FlowSol->n_mpi_inter_types; i++) FlowSol->mesh_mpi_inters(i).calculate_common_viscFlux();
     }
   }
@@ -703,8 +711,10 @@ int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
       xch(0, 1);
       if (phase(2, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
       if (visc) xch(1, 0);
+      if (visc && in.LES) xch(2, 0); // third message: the SGS flux
       if (phase(3, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
       if (visc) xch(1, 1);
+      if (visc && in.LES) xch(2, 1);
       if (phase(4, i, 0)) { FlowSol->err = hfx_last_error(); return 1; }
       xch(0, 0);
     }

@@ -23,7 +23,42 @@ struct MpiArgs
   const double *in_disu, *in_grad;
   Phys P;
   int accumulate; // split path: 0 write the total common flux, per-method viscous call: 1 (+=)
+  // LES (mpi_inters::send_sgsf_fpts, src/mpi_inters.cpp:339-397): the left block's SGS flux at the flux points -- physical
+  // (per-method path: extrapolate_sgsFlux has taken it back) or, sgs_ref != 0, still in reference space (split path,
+  // fused mode 2: the consumer applies |J|^-1 J) -- and the exchanged PHYSICAL records; NULL: no closure
+  const double *sgsf, *jac_fpts, *detjac_fpts, *in_sgsf;
+  double *out_sgsf;
+  int sgs_ref;
 };
+
+// the left side's physical SGS flux at flux point `o`: f(k, m) = f[k + NF*m]
+template <int ND>
+__device__ __forceinline__ void mpi_own_sgs(const MpiArgs &a, long o, double (&f)[(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+#pragma unroll
+  for (int s = 0; s < NF * ND; s++) f[s] = 0.0;
+  if (a.sgs_ref)
+    add_sgs_flux<ND>(a.sgsf, a.jac_fpts, a.detjac_fpts, o, a.plane, f);
+  else
+#pragma unroll
+    for (int s = 0; s < NF * ND; s++) f[s] = a.sgsf[o + s * a.plane];
+}
+
+// out_buffer_sgsf(fpt, field, dim, inter) = sgsf_fpts_l   (src/mpi_inters.cpp:344-350)
+template <int ND>
+__global__ __launch_bounds__(256) void mpi_pack_sgsf_kernel(const MpiArgs a)
+{
+  constexpr int NF = ND + 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.npairs) return;
+  const long i = q / a.nfpi;
+  const int j = (int)(q - i * a.nfpi);
+  double f[NF * ND];
+  mpi_own_sgs<ND>(a, a.L[q], f);
+#pragma unroll
+  for (int s = 0; s < NF * ND; s++) a.out_sgsf[j + (long)a.nfpi * (s + NF * ND * i)] = f[s];
+}
 
 // out_buffer_disu(fpt, field, inter) = disu_fpts_l   (src/mpi_inters.cpp:225-229)
 template <int ND>
@@ -149,6 +184,17 @@ __global__ __launch_bounds__(256) void mpi_common_viscflux_kernel(const MpiArgs 
   for (int m = 0; m < ND; m++) n[m] = a.norm[il + m * a.plane];
   calc_visf<ND, FAST>(a.P, ul, gl, fl);
   calc_visf<ND, FAST>(a.P, ur, gr, fr);
+  if (a.sgsf != nullptr) // src/mpi_inters.cpp:536-551: the physical SGS flux of both sides joins the viscous flux
+  {
+    double sl[NG];
+    mpi_own_sgs<ND>(a, il, sl);
+#pragma unroll
+    for (int s = 0; s < NG; s++)
+    {
+      fl[s] += sl[s];
+      fr[s] += a.in_sgsf[jr + (long)a.nfpi * (s + NG * i)];
+    }
+  }
   const double beta = ldg_switch<ND>(a.P.ldg_beta, n);
   const double tl = a.tdA[il];
 #pragma unroll

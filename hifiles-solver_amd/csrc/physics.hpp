@@ -489,4 +489,34 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
   }
 }
 
+// f(k, i) += sum_l (|J|^-1 ts(k, l)) J(i, l): the reference-space SGS flux of flux point `o`, taken to physical space in
+// the operation order of the reference's dgemm (alpha = 1/detjac, l outer; src/funcs.cpp:110-117)
+template <int ND>
+__device__ __forceinline__ void add_sgs_flux(const double *sgsf, const double *jac, const double *detjac, long o, long plane,
+                                             double (&f)[(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+  double J[ND * ND];
+#pragma unroll
+  for (int q = 0; q < ND * ND; q++) J[q] = jac[o * (ND * ND) + q];
+  const double inv_detjac = 1.0 / detjac[o];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    double ps[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) ps[i] = 0.0;
+#pragma unroll
+    for (int l = 0; l < ND; l++)
+    {
+      const double temp = inv_detjac * sgsf[o + (k + NF * l) * plane];
+#pragma unroll
+      for (int i = 0; i < ND; i++) ps[i] += temp * J[i + ND * l];
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) f[k + NF * i] += ps[i];
+  }
+}
+
+
 } // namespace hfx

@@ -37,7 +37,7 @@ def segments(nout_proc, rank, allow_self=False):
 
 
 class Exchange:
-    """out/in tensor pairs per kind (0 solution, 1 corrected gradient); tensors are flat float64.
+    """out/in tensor pairs per kind (0 solution, 1 corrected gradient, 2 SGS flux); tensors are flat float64.
 
     CPU tensors go straight through the process group.  Device tensors go through the group directly
     when it is RCCL, and through pinned host staging when it is gloo."""
@@ -133,10 +133,15 @@ def for_case(case, group=None, device=None, projected_flux=False):
     if not h:
         return None
     device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    les = bool(case.cfg.get("LES", 0))
+    if les:
+        projected_flux = False  # a block with an LES closure runs the split variant that sends the gradient
     t = [device_tensor(*hfx.mpi_buffer(h, w), device) for w in ((0, 1, 4, 5) if projected_flux else (0, 1, 2, 3))]
     stream = torch.cuda.ExternalStream(case.stream(), device=device)
     p = case.params()
     bufs = {0: (t[0], t[1])}
     if p.viscous:
         bufs[1] = (t[2], t[3])
+        if les:  # third message: the physical SGS flux (mpi_inters::send_sgsf_fpts)
+            bufs[2] = tuple(device_tensor(*hfx.mpi_buffer(h, w), device) for w in (6, 7))
     return Exchange(nout, case.rank, bufs, group=group, stream=stream, seg=case.mpi_segments())

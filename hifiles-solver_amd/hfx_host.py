@@ -105,6 +105,7 @@ class Case:
             for i in range(3):
                 d.pgrid[i] = pgrid[i] if i < len(pgrid) else 1
         self.nproc = max(1, d.nproc)
+        self.cfg = cfg
         for i, v in enumerate(self_partition or ()):
             d.self_partition[i] = int(v)
         for k, v in cfg.items():
@@ -260,6 +261,16 @@ class Case:
         d["RK_a"] = np.array(list(p.RK_a)[:p.n_rk])
         d["RK_b"] = np.array(list(p.RK_b)[:p.n_rk])
         d["u_init"] = self.array("disu_upts0")
+        if self.cfg.get("LES", 0):
+            # the closure's keys in the fixtures' form (oracle_py.Case, hfx.Eles.set_les); Kappa and prandtl_t: the
+            # reference's defaults (src/input.cpp:176-180) unless given
+            d["LES"] = np.array([1.0])
+            d["SGS_model"] = np.array([float(self.cfg.get("SGS_model", 0))])
+            d["C_s"] = np.array([float(self.cfg.get("C_s", 0.0))])
+            d["filter_ratio"] = np.array([float(self.cfg.get("filter_ratio", 1.0))])
+            d["Kappa"] = np.array([0.41])
+            d["prandtl_t"] = np.array([float(self.cfg.get("prandtl_t", 0.0)) or 0.9])
+            d["Jacobian_fpts"] = self.array("Jacobian_fpts")
         return d
 
     def to_device(self, device=0):

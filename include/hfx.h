@@ -178,9 +178,13 @@ int hfx_mpi_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int n_fpts
 /* the packing half of mpi_inters::send_solution / send_corrected_gradient (src/mpi_inters.cpp:218-229,278-289) */
 int hfx_mpi_inters_pack_solution(hfx_inters *f);
 int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f);
+/* LES, the packing half of mpi_inters::send_sgsf_fpts (src/mpi_inters.cpp:339-351): out_buffer_sgsf = the left block's
+ * physical SGS flux at the partition faces' flux points (after hfx_eles_extrapolate_sgsFlux) */
+int hfx_mpi_inters_pack_sgsf(hfx_inters *f);
 /* device pointers and lengths (doubles) of the buffers: which = 0 out_disu, 1 in_disu, 2 out_grad, 3 in_grad;
  * 4 / 5 = the leading n_fpts_per_inter*n_fields*n_inters doubles of out_grad / in_grad, which is what
- * hfx_stage_partitioned sends in fused mode 3 (the projected viscous flux instead of the gradient) */
+ * hfx_stage_partitioned sends in fused mode 3 (the projected viscous flux instead of the gradient);
+ * 6 / 7 = out / in_buffer_sgsf (LES only; (fpt, field, dim, inter) like the gradient) */
 int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n);
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f);  /* mpi_inters::calculate_common_invFlux  src/mpi_inters.cpp:400 */
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calculate_common_viscFlux src/mpi_inters.cpp:485 */
@@ -191,8 +195,10 @@ int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calc
  * (n_dims,n_dims,n_fpts,n_eles) is what extrapolate_sgsFlux uses to take the flux back to physical space
  * (src/eles.cpp:2862-2893).  Once set, evaluate_viscFlux adds the SGS flux, hfx_CalcResidual calls
  * extrapolate_sgsFlux (src/solver.cpp:162-167) and interior faces add sgsf_fpts to both sides' viscous flux
- * (src/int_inters.cpp:302-318); hfx_run_steps(..., fused=2) does the same inside its split stage.  Similarity / SVV
- * models (2-4), the wall model, partition faces with LES and LES in fused modes 1 / 3 are not built and are refused. */
+ * (src/int_inters.cpp:302-318), partition faces after the third exchange (hfx_mpi_inters_send / receive_sgsf_fpts);
+ * hfx_run_steps(..., fused=2) does the same inside its split stage, and a block with a closure runs that variant when
+ * fused=3 is asked for (variant 3 keeps the gradients the closure reads in registers), also on partitioned blocks
+ * (hfx_stage_partitioned / hfx_run_steps_partitioned: the SGS flux is the third message of the stage). */
 typedef struct hfx_les
 {
   int sgs_model, pad;
@@ -352,6 +358,10 @@ int hfx_mpi_inters_send_solution(hfx_inters *f, hfx_comm *c);
 int hfx_mpi_inters_receive_solution(hfx_inters *f, hfx_comm *c);
 int hfx_mpi_inters_send_corrected_gradient(hfx_inters *f, hfx_comm *c);
 int hfx_mpi_inters_receive_corrected_gradient(hfx_inters *f, hfx_comm *c);
+/* LES: mpi_inters::send_sgsf_fpts / receive_sgsf_fpts (src/mpi_inters.cpp:339-397), called by CalcResidual after
+ * extrapolate_sgsFlux and before the partition faces' viscous flux (src/solver.cpp:168-178,203-206) */
+int hfx_mpi_inters_send_sgsf_fpts(hfx_inters *f, hfx_comm *c);
+int hfx_mpi_inters_receive_sgsf_fpts(hfx_inters *f, hfx_comm *c);
 /* n_steps time steps of the split fused path on a partitioned block: the five phases of hfx_stage_partitioned with
  * the two exchanges of every stage started and awaited from inside the library in CalcResidual's order
  * (src/solver.cpp:68-72,131-139,148-155,197-210): solution exchange in flight during the interior LDG sweep, flux /

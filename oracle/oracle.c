@@ -1513,6 +1513,19 @@ void orc_mpi_pack_corrected_gradient(const orc_mpi_inters *F, const orc_eles *e)
           F->out_grad[counter++] = e->grad_disu_fpts[F->L[j + (long)nfi * i] + (k + (long)nf * m) * plane];
 }
 
+/* mpi_inters::send_sgsf_fpts, the packing half (src/mpi_inters.cpp:339-351): out_buffer_sgsf(fpt, field, dim, inter) */
+void orc_mpi_pack_sgsf(const orc_mpi_inters *F, const orc_eles *e)
+{
+  const int nf = e->n_fields, nd = e->n_dims, nfi = F->n_fpts_per_inter;
+  const long plane = (long)e->n_fpts * e->n_eles;
+  long counter = 0;
+  for (int i = 0; i < F->n_inters; i++)
+    for (int m = 0; m < nd; m++)
+      for (int k = 0; k < nf; k++)
+        for (int j = 0; j < nfi; j++)
+          F->out_sgsf[counter++] = e->sgsf_fpts[F->L[j + (long)nfi * i] + (k + (long)nf * m) * plane];
+}
+
 /* src/mpi_inters.cpp:400-483 */
 void orc_mpi_calculate_common_invFlux(const orc_mpi_inters *F, orc_eles *e, const orc_params *P)
 {
@@ -1574,6 +1587,13 @@ void orc_mpi_calculate_common_viscFlux(const orc_mpi_inters *F, orc_eles *e, con
         }
       orc_calc_visf(nd, P, ul, gl, fl);
       orc_calc_visf(nd, P, ur, gr, fr);
+      if (e->sgs_model >= 0 && e->sgsf_fpts && F->in_sgsf) /* src/mpi_inters.cpp:536-551: physical SGS flux of both sides */
+        for (int k = 0; k < nd; k++)
+          for (int l = 0; l < nf; l++)
+          {
+            fl[l + nf * k] += e->sgsf_fpts[il + (l + (long)nf * k) * plane];
+            fr[l + nf * k] += F->in_sgsf[jr + (long)nfi * (l + (long)nf * (k + (long)nd * i))];
+          }
       orc_ldg_flux(0, nd, ul, ur, fl, fr, norm, fn, P->ldg_tau, P->ldg_beta);
       for (int k = 0; k < nf; k++) e->norm_tconf_fpts[il + k * plane] += fn[k] * e->tdA_fpts[il];
     }

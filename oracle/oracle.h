@@ -100,6 +100,7 @@ typedef struct orc_mpi_inters
   const int *Rlut; /* (n_fpts_per_inter,n_inters) flux-point slot in the received face record */
   double *out_disu, *in_disu; /* (n_fpts_per_inter,n_fields,n_inters) */
   double *out_grad, *in_grad; /* (n_fpts_per_inter,n_fields,n_dims,n_inters) */
+  double *out_sgsf, *in_sgsf; /* LES: the physical SGS flux at the flux points, same layout (src/mpi_inters.cpp:65-66); NULL: off */
 } orc_mpi_inters;
 
 /* boundary faces (reference class bdy_inters, src/bdy_inters.cpp).  One record per entry of
@@ -209,6 +210,7 @@ void orc_bdy_evaluate_boundaryConditions_viscFlux(const orc_bdy_inters *f, orc_e
 
 void orc_mpi_pack_solution(const orc_mpi_inters *f, const orc_eles *e);           /* :218-229 */
 void orc_mpi_pack_corrected_gradient(const orc_mpi_inters *f, const orc_eles *e); /* :278-289 */
+void orc_mpi_pack_sgsf(const orc_mpi_inters *f, const orc_eles *e);               /* :339-351 (LES) */
 void orc_mpi_calculate_common_invFlux(const orc_mpi_inters *f, orc_eles *e, const orc_params *p);  /* :400 */
 void orc_mpi_calculate_common_viscFlux(const orc_mpi_inters *f, orc_eles *e, const orc_params *p); /* :485 */
 

@@ -273,7 +273,7 @@ Case.c_bdy = _c_bdy
 
 class MpiInters(C.Structure):
     _fields_ = [("n_inters", C.c_int), ("n_fpts_per_inter", C.c_int), ("L", ip), ("Rlut", ip),
-                ("out_disu", dp), ("in_disu", dp), ("out_grad", dp), ("in_grad", dp)]
+                ("out_disu", dp), ("in_disu", dp), ("out_grad", dp), ("in_grad", dp), ("out_sgsf", dp), ("in_sgsf", dp)]
 
 
 class PartitionedCase(Case):
@@ -288,8 +288,8 @@ class PartitionedCase(Case):
         nfpi, ni = self.mL.shape
         nf, nd = self.n_fields, self.n_dims
         # flat buffers: the exchange slices them by face record
-        self.buf = {k: np.zeros(nfpi * nf * ni * (nd if "grad" in k else 1)) for k in
-                    ("out_disu", "in_disu", "out_grad", "in_grad")}
+        self.buf = {k: np.zeros(nfpi * nf * ni * (1 if "disu" in k else nd)) for k in
+                    ("out_disu", "in_disu", "out_grad", "in_grad") + (("out_sgsf", "in_sgsf") if self.les else ())}
         self.exchange = exchange or (lambda kind, phase: None)
 
     def c_mpi(self):
@@ -300,6 +300,8 @@ class PartitionedCase(Case):
             setattr(m, k, v.ctypes.data_as(dp))
         self._m = m
         return m
+
+    # kinds of exchange: 0 solution, 1 corrected gradient, 2 SGS flux (LES; src/mpi_inters.cpp:339-397)
 
     def CalcResidual(self):
         o = load()
@@ -324,6 +326,11 @@ class PartitionedCase(Case):
                 o.orc_mpi_pack_corrected_gradient(M, E)
                 self.exchange(1, 0)
             o.orc_evaluate_viscFlux(E, P)
+            if self.les:  # src/solver.cpp:162-178
+                o.orc_extrapolate_sgsFlux(E)
+                if have:
+                    o.orc_mpi_pack_sgsf(M, E)
+                    self.exchange(2, 0)
         o.orc_extrapolate_totalFlux(E)
         o.orc_calculate_divergence(E)
         if p.viscous:
@@ -331,6 +338,8 @@ class PartitionedCase(Case):
                 o.orc_int_calculate_common_viscFlux(C.byref(f[b]), E, P)
             if have:
                 self.exchange(1, 1)
+                if self.les:  # src/solver.cpp:203-206
+                    self.exchange(2, 1)
                 o.orc_mpi_calculate_common_viscFlux(M, E, P)
         return o.orc_calculate_corrected_divergence(E)
 

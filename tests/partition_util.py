@@ -85,6 +85,8 @@ def oracle_worker(rank, world, port, n_local, pgrid, cfg, n_steps, outdir):
         bufs = {0: (t["out_disu"], t["in_disu"])}
         if pc.viscous:
             bufs[1] = (t["out_grad"], t["in_grad"])
+        if pc.les:
+            bufs[2] = (t["out_sgsf"], t["in_sgsf"])
         pc.exchange = Exchange(nout, rank, bufs, seg=c.mpi_segments())
         for _ in range(n_steps):
             pc.rk_step()
@@ -197,9 +199,12 @@ class ThreadTransport:
         import exchange
         h = case.mpi_handle()
         dev = torch.device("cuda", torch.cuda.current_device())
-        t = [exchange.device_tensor(*hfx.mpi_buffer(h, w), dev) for w in ((0, 1, 4, 5) if projected_flux else (0, 1, 2, 3))]
+        les = bool(case.cfg.get("LES", 0))
+        t = [exchange.device_tensor(*hfx.mpi_buffer(h, w), dev) for w in ((0, 1, 4, 5) if (projected_flux and not les) else (0, 1, 2, 3))]
         self.out[rank] = {0: t[0], 1: t[2]}
         self.inn[rank] = {0: t[1], 1: t[3]}
+        if les:
+            self.out[rank][2], self.inn[rank][2] = (exchange.device_tensor(*hfx.mpi_buffer(h, w), dev) for w in (6, 7))
         self.seg[rank] = case.mpi_segments()
         self.sync[rank] = case.synchronize
 

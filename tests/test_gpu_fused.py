@@ -37,8 +37,8 @@ def test_fused_vs_reference(ctx, name, mode):
     # what a fused path does not do, it refuses (over-integration: mode 3 only -- the de-aliased inviscid flux is
     # evaluated ahead of the flux kernel, which then takes it instead of computing the collocated one)
     over_int = "over_int" in d and int(np.ravel(d["over_int"])[0]) != 0
-    # LES closures: mode 2 only (it keeps the corrected gradients in HBM, which the SGS flux is computed from)
-    if (over_int and mode != 3) or ("_les_" in name and mode != 2) or name.startswith(("tet_", "pri_")):
+    # LES closures need the corrected gradients in HBM: a block with a closure runs the kernels of mode 2 whichever is asked for
+    if (over_int and mode != 3) or name.startswith(("tet_", "pri_")):
         with pytest.raises(hfx.HfxError):
             hfx.run_steps(e, faces, 1, fused=mode)
         steps = []

@@ -136,6 +136,35 @@ def test_gpu_rccl_transport_self_partition(tmp_path, mode, n_local, kw):
     assert rel(div, div1) < 5e-10
 
 
+LES = dict(riemann_solve_type=3, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0)
+
+
+@pytest.mark.parametrize("mode", ["methods", "fused"])
+def test_gpu_partition_les_third_exchange(tmp_path, mode):
+    """LES (WALE) on a partitioned box: the SGS flux at the partition faces is the third message of the stage
+    (mpi_inters::send_sgsf_fpts / receive_sgsf_fpts, src/mpi_inters.cpp:339-397, src/solver.cpp:168-178,203-206).  Two ranks
+    over the hook transport -- the mirrored CalcResidual, and hfx_stage_partitioned (a block with a closure runs the
+    split variant that keeps the gradients) -- against the 1-rank oracle, which the LES fixtures pin against the reference."""
+    n_local, pgrid = [2, 4, 4], [2, 1, 1]
+    cfg = dict(CFG, **LES)
+    PU.spawn(PU.gpu_worker, 2, (n_local, pgrid, cfg, 2, str(tmp_path), mode))
+    u1, div1 = PU.single_rank_oracle([4, 4, 4], cfg, 2)
+    u = PU.assemble(str(tmp_path), "u", n_local, pgrid, u1.shape)
+    assert rel(u, u1) < 1e-11
+
+
+@pytest.mark.parametrize("mode", ["methods", "fused"])
+def test_gpu_rccl_les_self_partition(tmp_path, mode):
+    """the same through the library's RCCL transport (hfx_mpi_inters_send / receive_sgsf_fpts; hfx_run_steps_partitioned
+    with three messages per stage) on a self-partitioned rank"""
+    n_local = [3, 4, 3]
+    cfg = dict(CFG, self_partition=[1, 0, 1], **LES)
+    PU.spawn(PU.gpu_worker, 1, (n_local, [1, 1, 1], cfg, 2, str(tmp_path), mode, "gloo", "rccl"))
+    u1, div1 = PU.single_rank_oracle(n_local, cfg, 2)
+    u = PU.assemble(str(tmp_path), "u", n_local, [1, 1, 1], u1.shape)
+    assert rel(u, u1) < 1e-11
+
+
 @pytest.mark.parametrize("transport", ["rccl", "torch"])
 def test_gpu_partitioned_cfl_time_step(tmp_path, transport):
     """dt_type 1 on the partitioned fused path: calc_time_step at the top of every step (src/HiFiLES.cpp:198), the MIN

@@ -22,6 +22,9 @@ def rel(a, b):
     ([2, 2, 2], [2, 2, 2], dict(riemann_solve_type=3)),                   # 8 ranks, BASELINE.json configs[2]'s 2x2x2 grid
     ([3, 4, 3], [1, 1, 1], dict(riemann_solve_type=3, self_partition=[1, 0, 1])),  # one rank that is its own neighbour in x and z
     ([2, 3, 3], [2, 1, 1], dict(riemann_solve_type=0, self_partition=[0, 1, 0])),  # a real neighbour in x, itself in y
+    # LES (WALE): the third exchange, the physical SGS flux at the partition faces (src/mpi_inters.cpp:339-397)
+    ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=3, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0)),
+    ([3, 4, 3], [1, 1, 1], dict(riemann_solve_type=0, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0, self_partition=[1, 0, 1])),
     ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=0, viscous=0, ic_form=1, u_c_ic=30.0, v_c_ic=10.0, w_c_ic=5.0,
                                 p_c_ic=101325.0, rho_c_ic=1.2)),          # inviscid: solution exchange only
 ])
