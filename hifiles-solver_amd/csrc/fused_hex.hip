@@ -2330,6 +2330,13 @@ int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps,
     if (calc_time_step(e, nullptr)) return 1; /* src/HiFiLES.cpp:198 */
     for (int rk = 0; rk < nst; rk++)
     {
+      if (rk == 0 && e->les_ready && e->les.sgs_model >= 2)
+      {
+        // first stage of a step: filtered solution / Leonard terms (src/solver.cpp:55-62); the SVV closure replaces the
+        // state, whose flux-point values the previous stage's update kernel has already written: redo them
+        if (hfx_eles_calc_sgs_terms(e)) return 1;
+        if (e->les.sgs_model == 3 && hfx_eles_extrapolate_solution(e)) return 1;
+      }
       if (split_stage(e, faces, nfb, rk, rk == nst - 1, 0, variant)) return 1;
       if (e->shock_ready)
       {
@@ -2483,6 +2490,12 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     return first ? mpi_all(0) : 0;
   case 1:
     if (!p.viscous) return 0;
+    if (in_step == 0 && e->les_ready && e->les.sgs_model >= 2)
+    {
+      HFX_CHECK(e->les.sgs_model != 3, "hfx_stage_partitioned: the SVV closure filters the state at the first stage, after its flux-point "
+                                       "values have left for the neighbours: run it per method");
+      if (hfx_eles_calc_sgs_terms(e)) return 1; // Leonard terms of this step (src/solver.cpp:55-62)
+    }
     return split_stage(e, int_faces, n_int, in_step, false, 1, variant); // interior LDG common solution
   case 2:
     if (variant == 3)

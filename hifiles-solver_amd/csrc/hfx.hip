@@ -449,11 +449,13 @@ int hfx_eles_create(hfx_ctx *ctx, const hfx_eles_desc *d, hfx_eles **out)
   len[HFX_GRAD_DISU_UPTS] = pu * nf * nd; len[HFX_GRAD_DISU_FPTS] = pf * nf * nd;
   len[HFX_SRC_UPTS] = pu * nf; len[HFX_DT_LOCAL] = ne; len[HFX_SENSOR] = ne;
   len[HFX_SGSF_UPTS] = pu * nf * nd; len[HFX_SGSF_FPTS] = pf * nf * nd;
+  len[HFX_DISUF_UPTS] = pu * nf; len[HFX_LU] = pu * (nd == 2 ? 3 : 6); len[HFX_LE] = pu * nd;
   for (int i = 0; i < HFX_N_ARRAYS; i++)
   {
     e->arr_len[i] = len[i];
     if (i == HFX_SRC_UPTS || i == HFX_DT_LOCAL) continue;       // allocated on first upload
     if (i == HFX_SGSF_UPTS || i == HFX_SGSF_FPTS) continue;     // allocated by hfx_eles_set_les
+    if (i == HFX_DISUF_UPTS || i == HFX_LU || i == HFX_LE) continue; // allocated by hfx_eles_set_les_filter
     HFX_HIP(hipMalloc((void **)&e->arr[i], sizeof(double) * (size_t)std::max<long>(len[i], 1)));
     // the reference zero-initialises its arrays (hf_array::setup + initialize_to_zero, src/eles.cpp:100-215)
     HFX_HIP(hipMemset(e->arr[i], 0, sizeof(double) * (size_t)std::max<long>(len[i], 1)));
@@ -474,6 +476,9 @@ int hfx_eles_destroy(hfx_eles *e)
   free_operator(e->opp_over_int_cubpts); free_operator(e->over_int_filter);
   free_operator(e->opp_volume_cubpts);
   free_operator(e->opp_p);
+  free_operator(e->filter_upts);
+  for (double *p : {e->sgs_uu, e->sgs_ue})
+    if (p) (void)hipFree(p);
   if (e->disu_ppts) (void)hipFree(e->disu_ppts);
   for (double *p : {e->weight_volume_cubpts, e->vol_detjac_vol_cubpts, e->iq_u, e->iq_g})
     if (p) (void)hipFree(p);
@@ -800,11 +805,12 @@ int hfx_inters_destroy(hfx_inters *f)
 int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distance, const double *Jacobian_fpts)
 {
   HFX_CHECK(e && les && Jacobian_fpts, "hfx_eles_set_les: NULL argument");
-  HFX_CHECK(les->sgs_model == 0 || les->sgs_model == 1, "SGS model not implemented"); /* src/eles.cpp:2461 (models 2-4: not built) */
+  HFX_CHECK(les->sgs_model >= 0 && les->sgs_model <= 4, "SGS model not implemented"); /* src/eles.cpp:2461 */
   HFX_CHECK(les->sgs_model != 0 || wall_distance, "hfx_eles_set_les: the Smagorinsky model needs wall_distance");
   HFX_CHECK(e->viscous_ops, "LES not supported with inviscid flow"); /* src/input.cpp:570 */
   e->les.sgs_model = les->sgs_model; e->les.order = e->order;
   e->les.C_s = les->C_s; e->les.filter_ratio = les->filter_ratio; e->les.Kappa = les->Kappa; e->les.prandtl_t = les->prandtl_t;
+  e->les.Lu = e->arr[HFX_LU]; e->les.Le = e->arr[HFX_LE]; // NULL until hfx_eles_set_les_filter
   for (double **p : {&e->wall_distance, &e->Jacobian_fpts})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (wall_distance && dev_alloc_copy(&e->wall_distance, wall_distance, (long)e->n_upts * e->n_eles * e->n_dims)) return 1;
@@ -817,6 +823,67 @@ int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distanc
     }
   e->les_ready = true;
   fused_invalidate(e);
+  return 0;
+}
+
+int hfx_eles_set_les_filter(hfx_eles *e, const double *filter_upts)
+{
+  HFX_CHECK(e && filter_upts, "hfx_eles_set_les_filter: NULL argument");
+  free_operator(e->filter_upts);
+  if (make_operator(e->filter_upts, filter_upts, e->n_upts, e->n_upts)) return 1;
+  for (int id : {HFX_DISUF_UPTS, HFX_LU, HFX_LE})
+    if (!e->arr[id])
+    {
+      HFX_HIP(hipMalloc((void **)&e->arr[id], sizeof(double) * (size_t)std::max<long>(e->arr_len[id], 1)));
+      HFX_HIP(hipMemset(e->arr[id], 0, sizeof(double) * (size_t)std::max<long>(e->arr_len[id], 1)));
+    }
+  if (!e->sgs_uu) HFX_HIP(hipMalloc((void **)&e->sgs_uu, sizeof(double) * (size_t)std::max<long>(e->arr_len[HFX_LU], 1)));
+  if (!e->sgs_ue) HFX_HIP(hipMalloc((void **)&e->sgs_ue, sizeof(double) * (size_t)std::max<long>(e->arr_len[HFX_LE], 1)));
+  e->les.Lu = e->arr[HFX_LU];
+  e->les.Le = e->arr[HFX_LE];
+  return 0;
+}
+
+int hfx_eles_calc_sgs_terms(hfx_eles *e)
+{
+  HFX_CHECK(e, "NULL eles");
+  if (e->n_eles == 0) return 0;
+  HFX_CHECK(e->les_ready, "calc_sgs_terms: hfx_eles_set_les was not called");
+  const int model = e->les.sgs_model;
+  if (model < 2) return 0; /* src/solver.cpp:57 */
+  HFX_CHECK(e->filter_upts.present(), "calc_sgs_terms: SGS model %d filters the solution: register filter_upts (hfx_eles_set_les_filter)", model);
+  hfx_ctx *ctx = e->ctx;
+  hipStream_t st = ctx->stream;
+  const long plane = (long)e->n_upts * e->n_eles;
+  const Operator *ops[1] = {&e->filter_upts};
+  const double *in_u[1] = {e->arr[HFX_DISU_UPTS0]};
+  if (contract_multi_in(ctx, ops, 1, in_u, e->arr[HFX_DISUF_UPTS], (long)e->n_eles * e->n_fields, 0)) return 1;
+  const bool sim = model == 2 || model == 4;
+  // products of the unfiltered solution (similarity models) and the NaN scan of the filtered one
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(sgs_products_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, st, plane, e->arr[HFX_DISU_UPTS0],
+                       e->arr[HFX_DISUF_UPTS], sim ? e->sgs_uu : nullptr, sim ? e->sgs_ue : nullptr, e->nan_flag);
+  else
+    hipLaunchKernelGGL(sgs_products_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, st, plane, e->arr[HFX_DISU_UPTS0],
+                       e->arr[HFX_DISUF_UPTS], sim ? e->sgs_uu : nullptr, sim ? e->sgs_ue : nullptr, e->nan_flag);
+  HFX_HIP(hipGetLastError());
+  if (model == 3)
+  {
+    // spectral vanishing viscosity: the filtered solution replaces the solution (src/eles.cpp:2088-2090)
+    HFX_HIP(hipMemcpyAsync(e->arr[HFX_DISU_UPTS0], e->arr[HFX_DISUF_UPTS], sizeof(double) * (size_t)e->arr_len[HFX_DISU_UPTS0],
+                           hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  const double *in_uu[1] = {e->sgs_uu}, *in_ue[1] = {e->sgs_ue};
+  if (contract_multi_in(ctx, ops, 1, in_uu, e->arr[HFX_LU], (long)e->n_eles * (e->n_dims == 2 ? 3 : 6), 0)) return 1;
+  if (contract_multi_in(ctx, ops, 1, in_ue, e->arr[HFX_LE], (long)e->n_eles * e->n_dims, 0)) return 1;
+  if (e->n_dims == 2)
+    hipLaunchKernelGGL(sgs_leonard_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, st, plane, e->arr[HFX_DISUF_UPTS],
+                       e->arr[HFX_LU], e->arr[HFX_LE]);
+  else
+    hipLaunchKernelGGL(sgs_leonard_kernel<3>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, st, plane, e->arr[HFX_DISUF_UPTS],
+                       e->arr[HFX_LU], e->arr[HFX_LE]);
+  HFX_HIP(hipGetLastError());
   return 0;
 }
 
@@ -1469,6 +1536,9 @@ int hfx_run_steps_blocks(hfx_eles *const *eles, int neb, hfx_inters *const *face
     if (calc_time_step_blocks(eles, neb)) return 1; /* src/HiFiLES.cpp:198 */
     for (int rk = 0; rk < nst; rk++)
     {
+      if (rk == 0) /* src/solver.cpp:55-62 */
+        for (int i = 0; i < neb; i++)
+          if (eles[i]->les_ready && hfx_eles_calc_sgs_terms(eles[i])) return 1;
       if (hfx_CalcResidual_blocks(eles, neb, faces, nfb)) return 1;
       for (int i = 0; i < neb; i++)
         if (hfx_eles_AdvanceSolution(eles[i], rk, adv)) return 1;

@@ -110,6 +110,9 @@ struct hfx_eles
   bool les_ready = false;
   hfx::LesParams les{};
   double *wall_distance = nullptr, *Jacobian_fpts = nullptr;
+  // similarity-type closures (sgs_model 2, 3, 4): the filter matrix and the work arrays of calc_sgs_terms
+  hfx::Operator filter_upts;
+  double *sgs_uu = nullptr, *sgs_ue = nullptr;
   // integral diagnostics (hfx_eles_set_volume_cubpts)
   int n_vol_cubpts = 0;
   hfx::Operator opp_volume_cubpts;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(PT_BLOCK) void viscflux_les_kernel(long plane, cons
     }
     y = sqrt(y);
   }
-  calc_sgsf<ND>(P, Lp, u, g, detjac[p], y, sg);
+  calc_sgsf<ND>(P, Lp, u, g, detjac[p], y, p, plane, sg);
 #pragma unroll
   for (int q = 0; q < NF * ND; q++) f[q] += 1.0 * sg[q];
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(PT_BLOCK) void sgsf_upts_kernel(long plane, const P
     }
     y = sqrt(y);
   }
-  calc_sgsf<ND>(P, Lp, u, g, detjac[p], y, sg);
+  calc_sgsf<ND>(P, Lp, u, g, detjac[p], y, p, plane, sg);
 #pragma unroll
   for (int k = 0; k < NF; k++)
 #pragma unroll
@@ -338,6 +338,89 @@ __global__ __launch_bounds__(PT_BLOCK) void common_viscflux_kernel(const FaceArg
     a.tconf_l[il + k * a.plane_l] += fn * tl;
     a.tconf_r[ir + k * a.plane_r] += -fn * tr;
   }
+}
+
+// ---- eles::calc_sgs_terms (src/eles.cpp:2058-2283), the two point-wise parts ----------------------------
+// products of the UNFILTERED solution: uu (3|6 components), ue (n_dims); and the NaN scan of the filtered solution
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void sgs_products_kernel(long plane, const double *__restrict__ U, const double *__restrict__ Uf,
+                                                                double *__restrict__ uu, double *__restrict__ ue,
+                                                                unsigned long long *nan_flag)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double ut[NF];
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    ut[k] = U[p + k * plane];
+    const double f = Uf[p + k * plane];
+    if (f != f) atomicMin(nan_flag, (unsigned long long)(p + k * plane)); // "nan in filtered solution"
+  }
+  if (uu == nullptr) return;
+  const double rsq = ut[0] * ut[0];
+  if (ND == 2)
+  {
+    uu[p + 0 * plane] = ut[1] * ut[1] / rsq;
+    uu[p + 1 * plane] = ut[2] * ut[2] / rsq;
+    uu[p + 2 * plane] = ut[1] * ut[2] / rsq;
+    ut[3] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2]) / ut[0];
+    ue[p + 0 * plane] = ut[1] * ut[3] / rsq;
+    ue[p + 1 * plane] = ut[2] * ut[3] / rsq;
+  }
+  else
+  {
+    uu[p + 0 * plane] = ut[1] * ut[1] / rsq;
+    uu[p + 1 * plane] = ut[2] * ut[2] / rsq;
+    uu[p + 2 * plane] = ut[ND] * ut[ND] / rsq;
+    uu[p + 3 * plane] = ut[1] * ut[2] / rsq;
+    uu[p + 4 * plane] = ut[1] * ut[ND] / rsq;
+    uu[p + 5 * plane] = ut[2] * ut[ND] / rsq;
+    ut[NF - 1] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2] + ut[ND] * ut[ND]) / ut[0];
+    ue[p + 0 * plane] = ut[1] * ut[NF - 1] / rsq;
+    ue[p + 1 * plane] = ut[2] * ut[NF - 1] / rsq;
+    ue[p + (ND - 1) * plane] = ut[ND] * ut[NF - 1] / rsq;
+  }
+}
+
+// Leonard terms: the filtered products minus the products of the FILTERED solution, Lu made traceless
+template <int ND>
+__global__ __launch_bounds__(PT_BLOCK) void sgs_leonard_kernel(long plane, const double *__restrict__ Uf, double *Lu, double *Le)
+{
+  constexpr int NF = ND + 2;
+  const long p = (long)blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (p >= plane) return;
+  double ut[NF], diag;
+#pragma unroll
+  for (int k = 0; k < NF; k++) ut[k] = Uf[p + k * plane];
+  const double rsq = ut[0] * ut[0];
+  if (ND == 2)
+  {
+    Lu[p + 0 * plane] -= (ut[1] * ut[1]) / rsq;
+    Lu[p + 1 * plane] -= (ut[2] * ut[2]) / rsq;
+    Lu[p + 2 * plane] -= (ut[1] * ut[2]) / rsq;
+    diag = (Lu[p + 0 * plane] + Lu[p + 1 * plane]) / 3.0;
+    ut[3] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2]) / ut[0];
+    Le[p + 0 * plane] = (Le[p + 0 * plane] - ut[1] * ut[3]) / rsq;
+    Le[p + 1 * plane] = (Le[p + 1 * plane] - ut[2] * ut[3]) / rsq;
+  }
+  else
+  {
+    Lu[p + 0 * plane] -= (ut[1] * ut[1]) / rsq;
+    Lu[p + 1 * plane] -= (ut[2] * ut[2]) / rsq;
+    Lu[p + 2 * plane] -= (ut[ND] * ut[ND]) / rsq;
+    Lu[p + 3 * plane] -= (ut[1] * ut[2]) / rsq;
+    Lu[p + 4 * plane] -= (ut[1] * ut[ND]) / rsq;
+    Lu[p + 5 * plane] -= (ut[2] * ut[ND]) / rsq;
+    diag = (Lu[p + 0 * plane] + Lu[p + 1 * plane] + Lu[p + 2 * plane]) / 3.0;
+    ut[NF - 1] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2] + ut[ND] * ut[ND]) / ut[0];
+    Le[p + 0 * plane] = (Le[p + 0 * plane] - ut[1] * ut[NF - 1]) / rsq;
+    Le[p + 1 * plane] = (Le[p + 1 * plane] - ut[2] * ut[NF - 1]) / rsq;
+    Le[p + (ND - 1) * plane] = (Le[p + (ND - 1) * plane] - ut[ND] * ut[NF - 1]) / rsq;
+  }
+#pragma unroll
+  for (int k = 0; k < ND; ++k) Lu[p + k * plane] -= diag;
 }
 
 // ---- eles::AdvanceSolution ------------------------------------------------------

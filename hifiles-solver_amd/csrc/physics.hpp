@@ -373,16 +373,20 @@ __device__ __forceinline__ double ldg_switch(double beta, const double (&n)[ND])
 
 // LES eddy-viscosity closure, eles::calc_sgsf_upts (src/eles.cpp:2395-2650): sgs_model 0 Smagorinsky with
 // near-wall damping (y = distance to the nearest no-slip wall), 1 WALE.  f(k,m) = f[k + NF*m].
+// 2 WALE + similarity, 4 similarity: the Leonard terms Lu (n_upts,n_eles,3|6), Le (n_upts,n_eles,n_dims) of the step's
+// calc_sgs_terms join the flux; 3 (spectral vanishing viscosity): no SGS flux, the solution itself is filtered.
 struct LesParams
 {
   int sgs_model, order;
   double C_s, filter_ratio, Kappa, prandtl_t;
+  const double *Lu, *Le;
 };
 
+// p, plane: the point's offset and the (point, element) plane size of Lu / Le (similarity terms only)
 template <int ND>
 __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, const double (&tu)[ND + 2],
-                                          const double (&g)[(ND + 2) * ND], const double detjac, const double y,
-                                          double (&sg)[(ND + 2) * ND])
+                                          const double (&g)[(ND + 2) * ND], const double detjac, const double y, const long p,
+                                          const long plane, double (&sg)[(ND + 2) * ND])
 {
   constexpr int NF = ND + 2;
   double u[ND], drho[ND], dene[ND], dke[ND], de[ND], dmom[ND][ND], du[ND][ND], S[ND][ND];
@@ -421,8 +425,11 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
   for (int i = 0; i < ND; i++)
 #pragma unroll
     for (int j = 0; j < ND; j++) S[i][j] = (du[i][j] + du[j][i]) / 2.0;
-  double mu_t;
-  if (Lp.sgs_model == 0)
+  const bool eddy = Lp.sgs_model <= 2, sim = Lp.sgs_model == 2 || Lp.sgs_model == 4; /* src/eles.cpp:2436-2465 */
+  double mu_t = 0.0;
+  if (!eddy)
+    ;
+  else if (Lp.sgs_model == 0)
   {
     double Smod = 0.0;
 #pragma unroll
@@ -471,21 +478,52 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
     num = pow(num, 1.5);
     mu_t = rho * Lp.C_s * Lp.C_s * delta * delta * num / (denom + 1.e-12);
   }
-  double diag = 0.;
 #pragma unroll
-  for (int i = 0; i < ND; i++) diag += S[i][i] / 3.0;
-#pragma unroll
-  for (int i = 0; i < ND; i++) S[i][i] -= diag;
-#pragma unroll
-  for (int j = 0; j < ND; j++)
+  for (int q = 0; q < NF * ND; q++) sg[q] = 0.0;
+  if (eddy)
   {
-    sg[0 + NF * j] = 0.0;
-    double ef = -1.0 * P.gamma * mu_t / Lp.prandtl_t * de[j];
+    double diag = 0.;
 #pragma unroll
-    for (int k = 0; k < ND; k++) ef -= u[k] * 2.0 * mu_t * S[k][j];
-    sg[(NF - 1) + NF * j] = ef;
+    for (int i = 0; i < ND; i++) diag += S[i][i] / 3.0;
 #pragma unroll
-    for (int i = 1; i < NF - 1; i++) sg[i + NF * j] = -2.0 * mu_t * S[i - 1][j];
+    for (int i = 0; i < ND; i++) S[i][i] -= diag;
+#pragma unroll
+    for (int j = 0; j < ND; j++)
+    {
+      sg[0 + NF * j] = 0.0;
+      double ef = -1.0 * P.gamma * mu_t / Lp.prandtl_t * de[j];
+#pragma unroll
+      for (int k = 0; k < ND; k++) ef -= u[k] * 2.0 * mu_t * S[k][j];
+      sg[(NF - 1) + NF * j] = ef;
+#pragma unroll
+      for (int i = 1; i < NF - 1; i++) sg[i + NF * j] = -2.0 * mu_t * S[i - 1][j];
+    }
+  }
+  if (sim)
+  {
+    // src/eles.cpp:2602-2634; the off-diagonal momentum entries are filled from their transposes AFTER those received
+    // their own term (and the eddy part), as the reference does
+#pragma unroll
+    for (int j = 0; j < ND; j++) sg[(NF - 1) + NF * j] += P.gamma * rho * Lp.Le[p + j * plane];
+    if (ND == 2)
+    {
+      sg[1 + NF * 0] += rho * Lp.Lu[p + 0 * plane];
+      sg[1 + NF * 1] += rho * Lp.Lu[p + 2 * plane];
+      sg[2 + NF * 0] += sg[1 + NF * 1];
+      sg[2 + NF * 1] += rho * Lp.Lu[p + 1 * plane];
+    }
+    else
+    {
+      sg[1 + NF * 0] += rho * Lp.Lu[p + 0 * plane];
+      sg[1 + NF * 1] += rho * Lp.Lu[p + 3 * plane];
+      sg[1 + NF * (ND - 1)] += rho * Lp.Lu[p + 4 * plane];
+      sg[2 + NF * 0] += sg[1 + NF * 1];
+      sg[2 + NF * 1] += rho * Lp.Lu[p + 1 * plane];
+      sg[2 + NF * (ND - 1)] += rho * Lp.Lu[p + 5 * plane];
+      sg[(NF - 2) + NF * 0] += sg[1 + NF * (ND - 1)];
+      sg[(NF - 2) + NF * 1] += sg[2 + NF * (ND - 1)];
+      sg[(NF - 2) + NF * (ND - 1)] += rho * Lp.Lu[p + 2 * plane];
+    }
   }
 }
 

@@ -18,7 +18,8 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 
 (DISU_UPTS0, DISU_UPTS1, DISU_FPTS, TDISF_UPTS, NORM_TDISF_FPTS, NORM_TCONF_FPTS, DIV_TCONF_UPTS,
- DELTA_DISU_FPTS, GRAD_DISU_UPTS, GRAD_DISU_FPTS, SRC_UPTS, DT_LOCAL, SENSOR, SGSF_UPTS, SGSF_FPTS) = range(15)
+ DELTA_DISU_FPTS, GRAD_DISU_UPTS, GRAD_DISU_FPTS, SRC_UPTS, DT_LOCAL, SENSOR, SGSF_UPTS, SGSF_FPTS,
+ DISUF_UPTS, LU, LE) = range(18)
 
 
 class Les(C.Structure):
@@ -180,7 +181,8 @@ class Eles:
             TDISF_UPTS: (nu, ne, nf, nd), NORM_TDISF_FPTS: (nfp, ne, nf), NORM_TCONF_FPTS: (nfp, ne, nf),
             DIV_TCONF_UPTS: (nu, ne, nf), DELTA_DISU_FPTS: (nfp, ne, nf), GRAD_DISU_UPTS: (nu, ne, nf, nd),
             GRAD_DISU_FPTS: (nfp, ne, nf, nd), SRC_UPTS: (nu, ne, nf), DT_LOCAL: (ne,), SENSOR: (ne,),
-            SGSF_UPTS: (nu, ne, nf, nd), SGSF_FPTS: (nfp, ne, nf, nd)}
+            SGSF_UPTS: (nu, ne, nf, nd), SGSF_FPTS: (nfp, ne, nf, nd),
+            DISUF_UPTS: (nu, ne, nf), LU: (nu, ne, 3 if nd == 2 else 6), LE: (nu, ne, nd)}
 
     def upload(self, array_id, a):
         a = _f(a)
@@ -231,11 +233,17 @@ class Eles:
 
     def shock_capture(self): self._call("hfx_eles_shock_capture")
 
-    def set_les(self, sgs_model, C_s, filter_ratio, Kappa, prandtl_t, Jacobian_fpts, wall_distance=None):
+    def set_les(self, sgs_model, C_s, filter_ratio, Kappa, prandtl_t, Jacobian_fpts, wall_distance=None, filter_upts=None):
         les = Les(sgs_model, 0, C_s, filter_ratio, Kappa, prandtl_t)
         J = _f(Jacobian_fpts)
         w = _f(wall_distance) if wall_distance is not None else None
         check(lib().hfx_eles_set_les(self.h, C.byref(les), w.ctypes.data_as(dp) if w is not None else None, J.ctypes.data_as(dp)))
+        if filter_upts is not None:
+            F = _f(filter_upts)
+            assert F.shape == (self.n_upts, self.n_upts)
+            check(lib().hfx_eles_set_les_filter(self.h, F.ctypes.data_as(dp)))
+
+    def calc_sgs_terms(self): self._call("hfx_eles_calc_sgs_terms")
 
     def extrapolate_sgsFlux(self): self._call("hfx_eles_extrapolate_sgsFlux")
 

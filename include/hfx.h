@@ -88,7 +88,10 @@ enum hfx_array_id
   HFX_SENSOR = 12,        /* (n_eles) eles::sensor, written by hfx_eles_shock_capture */
   HFX_SGSF_UPTS = 13,     /* (n_upts,n_eles,n_fields,n_dims) LES: transformed SGS flux (allocated by hfx_eles_set_les) */
   HFX_SGSF_FPTS = 14,     /* (n_fpts,n_eles,n_fields,n_dims) LES: physical SGS flux at the flux points */
-  HFX_N_ARRAYS = 15
+  HFX_DISUF_UPTS = 15,    /* (n_upts,n_eles,n_fields) LES closures 2-4: filtered solution (hfx_eles_set_les_filter allocates 15-17) */
+  HFX_LU = 16,            /* (n_upts,n_eles,3|6) Leonard tensor of the similarity term */
+  HFX_LE = 17,            /* (n_upts,n_eles,n_dims) Leonard vector */
+  HFX_N_ARRAYS = 18
 };
 
 /* which implementation the operator contractions use */
@@ -201,10 +204,20 @@ int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calc
  * (hfx_stage_partitioned / hfx_run_steps_partitioned: the SGS flux is the third message of the stage). */
 typedef struct hfx_les
 {
-  int sgs_model, pad;
+  int sgs_model, pad; /* 0 Smagorinsky, 1 WALE, 2 WALE + similarity, 3 spectral vanishing viscosity, 4 similarity */
   double C_s, filter_ratio, Kappa, prandtl_t;
 } hfx_les;
 int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distance, const double *Jacobian_fpts);
+/* Closures 2, 3, 4 filter the solution: filter_upts (n_upts,n_upts) is what the element class builds in
+ * compute_filter_upts (src/eles_hexas.cpp:583, src/eles.cpp:138) -- registered like the operators.  Required before the
+ * first stage with such a model. */
+int hfx_eles_set_les_filter(hfx_eles *e, const double *filter_upts);
+/* eles::calc_sgs_terms (src/eles.cpp:2058-2283), which CalcResidual calls at the FIRST RK stage of a time step for the
+ * closures 2, 3, 4 (src/solver.cpp:55-62): filtered solution -> HFX_DISUF_UPTS; model 3: it replaces disu_upts(0);
+ * models 2 / 4: products, their filtered values and the Leonard terms -> HFX_LU, HFX_LE, which calc_sgsf_upts reads for
+ * the rest of the step.  A NaN in the filtered solution is reported through hfx_eles_check_nan.  The hfx_run_steps*
+ * loops call it themselves. */
+int hfx_eles_calc_sgs_terms(hfx_eles *e);
 int hfx_eles_extrapolate_sgsFlux(hfx_eles *e); /* eles::extrapolate_sgsFlux, src/eles.cpp:2817 */
 
 /* ---- integral diagnostics (8f-1: the TGV monitors) ------------------------ */

@@ -140,6 +140,11 @@ CASES = [
     case("hex_p2_les_smag", amp=0.1, level=2, order=2, steps=1, LES=1, SGS_model=0, C_s=0.17, filter_ratio=1.5,
          bcs={"y-": "WallT", "y+": "WallQ"}, **BC_KEYS),
     case("quad_p3_les_wale", dims=2, n=4, amp=0.1, level=2, order=3, steps=1, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0),
+    # similarity-type closures: filtered solution and Leonard tensors at the first stage of every step (calc_sgs_terms):
+    # 2 WALE + similarity, 4 similarity alone, 3 spectral vanishing viscosity (the state itself is filtered)
+    case("hex_p2_les_wsm", amp=0.15, level=2, order=2, steps=2, LES=1, SGS_model=2, C_s=0.325, filter_ratio=2.0, filter_type=0),
+    case("hex_p2_les_sim", amp=0.15, level=2, order=2, steps=2, LES=1, SGS_model=4, C_s=0.325, filter_ratio=2.0, filter_type=1),
+    case("hex_p2_les_svv", amp=0.15, level=1, order=2, steps=2, LES=1, SGS_model=3, C_s=0.325, filter_ratio=2.0, filter_type=0),
     # the ASCII restart file of the final state (on-disk format either side of the path)
     case("hex_p2_restart", amp=0.15, level=0, order=2, steps=1, restart=True),
     case("quad_p3_restart", dims=2, n=4, amp=0.1, level=0, order=3, steps=1, restart=True),

@@ -603,7 +603,11 @@ void orc_calc_sgsf_upts(const orc_eles *e, const orc_params *P, const double *te
   }
   for (int i = 0; i < nd; i++)
     for (int j = 0; j < nd; j++) S[i][j] = (du[i][j] + du[j][i]) / 2.0;
-  if (e->sgs_model == 0)
+  /* 0 Smagorinsky, 1 WALE, 2 WALE + similarity, 3 SVV (no SGS flux), 4 similarity (src/eles.cpp:2436-2465) */
+  const int eddy = e->sgs_model <= 2, sim = e->sgs_model == 2 || e->sgs_model == 4;
+  if (!eddy)
+    ;
+  else if (e->sgs_model == 0)
   {
     double Smod = 0.0;
     for (int i = 0; i < nd; i++)
@@ -644,16 +648,138 @@ void orc_calc_sgsf_upts(const orc_eles *e, const orc_params *P, const double *te
     num = pow(num, 1.5);
     mu_t = rho * e->C_s * e->C_s * delta * delta * num / (denom + eps);
   }
-  diag = 0.;
-  for (int i = 0; i < nd; i++) diag += S[i][i] / 3.0;
-  for (int i = 0; i < nd; i++) S[i][i] -= diag;
-  for (int j = 0; j < nd; j++)
+  if (eddy)
   {
-    temp_sgsf[0 + nf * j] = 0.0;
-    temp_sgsf[(nf - 1) + nf * j] = -1.0 * P->gamma * mu_t / e->prandtl_t * de[j];
-    for (int k = 0; k < nd; k++) temp_sgsf[(nf - 1) + nf * j] -= u[k] * 2.0 * mu_t * S[k][j];
-    for (int i = 1; i < nf - 1; i++) temp_sgsf[i + nf * j] = -2.0 * mu_t * S[i - 1][j];
+    diag = 0.;
+    for (int i = 0; i < nd; i++) diag += S[i][i] / 3.0;
+    for (int i = 0; i < nd; i++) S[i][i] -= diag;
+    for (int j = 0; j < nd; j++)
+    {
+      temp_sgsf[0 + nf * j] = 0.0;
+      temp_sgsf[(nf - 1) + nf * j] = -1.0 * P->gamma * mu_t / e->prandtl_t * de[j];
+      for (int k = 0; k < nd; k++) temp_sgsf[(nf - 1) + nf * j] -= u[k] * 2.0 * mu_t * S[k][j];
+      for (int i = 1; i < nf - 1; i++) temp_sgsf[i + nf * j] = -2.0 * mu_t * S[i - 1][j];
+    }
   }
+  if (sim)
+  {
+    /* src/eles.cpp:2602-2634: the Leonard terms of this step's calc_sgs_terms; note that the off-diagonal momentum
+     * entries are filled from their transposes AFTER those received their own term (and the eddy part) */
+    const long pl = (long)nu * ne, o = upt + (long)nu * ele;
+#define SG(i, j) temp_sgsf[(i) + nf * (j)]
+    for (int j = 0; j < nd; j++)
+    {
+      SG(0, j) += 0.0;
+      SG(nf - 1, j) += P->gamma * rho * e->Le[o + j * pl];
+    }
+    if (nd == 2)
+    {
+      SG(1, 0) += rho * e->Lu[o + 0 * pl];
+      SG(1, 1) += rho * e->Lu[o + 2 * pl];
+      SG(2, 0) += SG(1, 1);
+      SG(2, 1) += rho * e->Lu[o + 1 * pl];
+    }
+    else
+    {
+      SG(1, 0) += rho * e->Lu[o + 0 * pl];
+      SG(1, 1) += rho * e->Lu[o + 3 * pl];
+      SG(1, 2) += rho * e->Lu[o + 4 * pl];
+      SG(2, 0) += SG(1, 1);
+      SG(2, 1) += rho * e->Lu[o + 1 * pl];
+      SG(2, 2) += rho * e->Lu[o + 5 * pl];
+      SG(3, 0) += SG(1, 2);
+      SG(3, 1) += SG(2, 2);
+      SG(3, 2) += rho * e->Lu[o + 2 * pl];
+    }
+#undef SG
+  }
+}
+
+/* eles::calc_sgs_terms (src/eles.cpp:2058-2283), called at the first RK stage of a step for the closures 2, 3, 4
+ * (src/solver.cpp:55-62): filtered solution; 3 (SVV): it replaces the solution; 2 / 4: products, their filtered values and
+ * the Leonard tensors Lu (n_upts,n_eles,3|6), Le (n_upts,n_eles,n_dims).  Returns -1 or the index of a NaN in disuf_upts. */
+long orc_calc_sgs_terms(orc_eles *e)
+{
+  const int nu = e->n_upts, ne = e->n_eles, nf = e->n_fields, nd = e->n_dims;
+  const long pl = (long)nu * ne;
+  orc_dgemm(nu, nf * ne, nu, 1.0, 0.0, e->filter_upts, e->disu_upts[0], e->disuf_upts);
+  for (long q = 0; q < pl * nf; q++)
+    if (isnan(e->disuf_upts[q])) return q;
+  if (e->sgs_model == 3)
+  {
+    for (long q = 0; q < pl * nf; q++) e->disu_upts[0][q] = e->disuf_upts[q];
+    return -1;
+  }
+  if (e->sgs_model != 2 && e->sgs_model != 4) return -1;
+  const int dim3 = (nd == 2) ? 3 : 6;
+  for (int i = 0; i < nu; i++)
+    for (int j = 0; j < ne; j++)
+    {
+      const long o = i + (long)nu * j;
+      double ut[MAXF];
+      for (int k = 0; k < nf; k++) ut[k] = e->disu_upts[0][o + k * pl];
+      const double rsq = ut[0] * ut[0];
+      if (nd == 2)
+      {
+        e->uu[o + 0 * pl] = ut[1] * ut[1] / rsq;
+        e->uu[o + 1 * pl] = ut[2] * ut[2] / rsq;
+        e->uu[o + 2 * pl] = ut[1] * ut[2] / rsq;
+        ut[3] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2]) / ut[0];
+        e->ue[o + 0 * pl] = ut[1] * ut[3] / rsq;
+        e->ue[o + 1 * pl] = ut[2] * ut[3] / rsq;
+      }
+      else
+      {
+        e->uu[o + 0 * pl] = ut[1] * ut[1] / rsq;
+        e->uu[o + 1 * pl] = ut[2] * ut[2] / rsq;
+        e->uu[o + 2 * pl] = ut[3] * ut[3] / rsq;
+        e->uu[o + 3 * pl] = ut[1] * ut[2] / rsq;
+        e->uu[o + 4 * pl] = ut[1] * ut[3] / rsq;
+        e->uu[o + 5 * pl] = ut[2] * ut[3] / rsq;
+        ut[4] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2] + ut[3] * ut[3]) / ut[0];
+        e->ue[o + 0 * pl] = ut[1] * ut[4] / rsq;
+        e->ue[o + 1 * pl] = ut[2] * ut[4] / rsq;
+        e->ue[o + 2 * pl] = ut[3] * ut[4] / rsq;
+      }
+    }
+  orc_dgemm(nu, dim3 * ne, nu, 1.0, 0.0, e->filter_upts, e->uu, e->Lu);
+  /* as the reference has it: the second product is filtered over dim3 * n_eles columns too, although ue has n_dims
+   * components -- the surplus columns lie outside Le and are not computed here */
+  orc_dgemm(nu, nd * ne, nu, 1.0, 0.0, e->filter_upts, e->ue, e->Le);
+  for (int i = 0; i < nu; i++)
+    for (int j = 0; j < ne; j++)
+    {
+      const long o = i + (long)nu * j;
+      double ut[MAXF], diag;
+      for (int k = 0; k < nf; k++) ut[k] = e->disuf_upts[o + k * pl];
+      const double rsq = ut[0] * ut[0];
+      if (nd == 2)
+      {
+        e->Lu[o + 0 * pl] -= (ut[1] * ut[1]) / rsq;
+        e->Lu[o + 1 * pl] -= (ut[2] * ut[2]) / rsq;
+        e->Lu[o + 2 * pl] -= (ut[1] * ut[2]) / rsq;
+        diag = (e->Lu[o + 0 * pl] + e->Lu[o + 1 * pl]) / 3.0;
+        ut[3] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2]) / ut[0];
+        e->Le[o + 0 * pl] = (e->Le[o + 0 * pl] - ut[1] * ut[3]) / rsq;
+        e->Le[o + 1 * pl] = (e->Le[o + 1 * pl] - ut[2] * ut[3]) / rsq;
+      }
+      else
+      {
+        e->Lu[o + 0 * pl] -= (ut[1] * ut[1]) / rsq;
+        e->Lu[o + 1 * pl] -= (ut[2] * ut[2]) / rsq;
+        e->Lu[o + 2 * pl] -= (ut[3] * ut[3]) / rsq;
+        e->Lu[o + 3 * pl] -= (ut[1] * ut[2]) / rsq;
+        e->Lu[o + 4 * pl] -= (ut[1] * ut[3]) / rsq;
+        e->Lu[o + 5 * pl] -= (ut[2] * ut[3]) / rsq;
+        diag = (e->Lu[o + 0 * pl] + e->Lu[o + 1 * pl] + e->Lu[o + 2 * pl]) / 3.0;
+        ut[4] -= 0.5 * (ut[1] * ut[1] + ut[2] * ut[2] + ut[3] * ut[3]) / ut[0];
+        e->Le[o + 0 * pl] = (e->Le[o + 0 * pl] - ut[1] * ut[4]) / rsq;
+        e->Le[o + 1 * pl] = (e->Le[o + 1 * pl] - ut[2] * ut[4]) / rsq;
+        e->Le[o + 2 * pl] = (e->Le[o + 2 * pl] - ut[3] * ut[4]) / rsq;
+      }
+      for (int k = 0; k < nd; ++k) e->Lu[o + k * pl] -= diag;
+    }
+  return -1;
 }
 
 /* src/eles.cpp:2817-2910 : sgsf_fpts(:,:,:,d) = opp_0 * sgsf_upts(:,:,:,d) */

@@ -77,6 +77,11 @@ typedef struct orc_eles
   const double *opp_over_int_cubpts;   /* (n_cub,n_upts) */
   const double *over_int_filter;       /* (n_upts,n_cub) */
   const double *JGinv_over_int_cubpts; /* (n_dims,n_dims,n_cub,n_eles) */
+  /* similarity-type closures (sgs_model 2 WALE + similarity, 3 SVV, 4 similarity; src/eles.cpp:138-165) */
+  const double *filter_upts; /* (n_upts,n_upts) */
+  double *disuf_upts;        /* (n_upts,n_eles,n_fields) filtered solution */
+  double *uu, *Lu;           /* (n_upts,n_eles,3|6) velocity products, Leonard tensor */
+  double *ue, *Le;           /* (n_upts,n_eles,n_dims) velocity-energy products, Leonard vector */
 } orc_eles;
 
 /* interior faces (reference class int_inters): the hf_array<double*> tables of
@@ -198,6 +203,7 @@ void orc_CalcIntegralQuantities(const orc_eles *e, const orc_params *p, int n_cu
 void orc_calc_sgsf_upts(const orc_eles *e, const orc_params *p, const double *u, const double *grad_u, double detjac, int ele,
                         int upt, double *sgsf);
 void orc_extrapolate_sgsFlux(orc_eles *e);
+long orc_calc_sgs_terms(orc_eles *e); /* eles::calc_sgs_terms, src/eles.cpp:2058 (first RK stage of a step, models 2-4) */
 void orc_shock_capture(orc_eles *e, const orc_shock *s); /* eles::shock_capture, shock_cap 1 + shock_det 0 */
 
 /* boundary faces, src/bdy_inters.cpp (wall model, LES inlet, RANS off) */

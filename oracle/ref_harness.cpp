@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <map>
 #include <cstdint>
+#include <unistd.h>
 
 // The hot-path arrays are protected members of eles / inters
 // (include/eles.h:470-935, include/inters.h:86-126): open them for dumping.
@@ -275,6 +276,9 @@ int main(int argc, char *argv[])
     // bdy_inters::inlet.nbs is read by evaluate_boundaryConditions_* (src/bdy_inters.cpp:249) but only
     // ever written by add_les_inlet (LES runs): give it the value an LES-off run means
     for (int t = 0; t < FlowSol.n_bdy_inter_types; t++) FlowSol.mesh_bdy_inters(t).inlet.nbs = 0;
+    // likewise turbinlet::type, never initialised but read at the first stage of every step when LES is on
+    // (src/solver.cpp:110-117): 0 = no synthetic-turbulence inlet
+    for (int t = 0; t < FlowSol.n_bdy_inter_types; t++) FlowSol.mesh_bdy_inters(t).inlet.type = 0;
     bool any = false;
     for (int t = 0; t < FlowSol.n_bdy_inter_types; t++)
     {
@@ -349,6 +353,8 @@ int main(int argc, char *argv[])
     put_scalar("prandtl_t", run_input.prandtl_t);
     if (run_input.SGS_model == 0) put_arr("wall_distance", E->wall_distance);
     put_arr("Jacobian_fpts", E->Jacobian_fpts); // used by extrapolate_sgsFlux to take the SGS flux back to physical space
+    // similarity (2: WALE + similarity, 4: similarity) and SVV (3) closures: the filter matrix of calc_sgs_terms
+    if (run_input.SGS_model >= 2) put_arr("filter_upts", E->filter_upts);
   }
   // integral diagnostics (src/eles.cpp:5485-5627): volume cubature interpolation, weights, Jacobians
   if (run_input.n_integral_quantities != 0)
@@ -468,6 +474,18 @@ int main(int argc, char *argv[])
         // the sequence of CalcResidual (src/solver.cpp:50-223) for a
         // single-rank, LES-off, RANS-off, forcing-off run, with dumps between calls
         int i;
+        if (run_input.LES == 1 && (run_input.SGS_model == 2 || run_input.SGS_model == 3 || run_input.SGS_model == 4))
+        {
+          // first stage of a step: filtered solution, Leonard tensors (src/solver.cpp:55-62)
+          for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->calc_sgs_terms();
+          put_arr("s0_disuf_upts", E->disuf_upts);
+          put_arr("s0_u_after_sgs_terms", E->disu_upts(0));
+          if (run_input.SGS_model != 3)
+          {
+            put_arr("s0_Lu", E->Lu);
+            put_arr("s0_Le", E->Le);
+          }
+        }
         for (i = 0; i < FlowSol.n_ele_types; i++) FlowSol.mesh_eles(i)->extrapolate_solution();
         if (level >= 2) put_all("s0_disu_fpts", [](eles *X) -> hf_array<double> & { return X->disu_fpts; });
         if (run_input.viscous)
@@ -600,5 +618,9 @@ int main(int argc, char *argv[])
     put_scalar("restart_time", FlowSol.time);
   }
   fclose(g_out);
-  return 0;
+  // the dump is complete; leave without running the reference's destructors (with the similarity closures one of them
+  // frees an invalid pointer at exit -- the reference's own main never gets that far with these arrays alive)
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

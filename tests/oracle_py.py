@@ -31,7 +31,8 @@ class Eles(C.Structure):
         ("grad_disu_upts", dp), ("grad_disu_fpts", dp), ("src_upts", dp), ("dt_local", dp),
         ("sgs_model", C.c_int), ("C_s", C.c_double), ("filter_ratio", C.c_double), ("Kappa", C.c_double),
         ("prandtl_t", C.c_double), ("order_les", C.c_int), ("wall_distance", dp), ("sgsf_upts", dp), ("sgsf_fpts", dp), ("Jacobian_fpts", dp),
-        ("n_cub", C.c_int), ("opp_over_int_cubpts", dp), ("over_int_filter", dp), ("JGinv_over_int_cubpts", dp)]
+        ("n_cub", C.c_int), ("opp_over_int_cubpts", dp), ("over_int_filter", dp), ("JGinv_over_int_cubpts", dp),
+        ("filter_upts", dp), ("disuf_upts", dp), ("uu", dp), ("Lu", dp), ("ue", dp), ("Le", dp)]
 
 
 class IntInters(C.Structure):
@@ -88,6 +89,7 @@ def load():
         _lib.orc_CalcResidual_bdy.restype = C.c_long
         _lib.orc_rk_step_bdy.restype = C.c_long
         _lib.orc_calculate_corrected_divergence.restype = C.c_long
+        _lib.orc_calc_sgs_terms.restype = C.c_long
         _lib.orc_compute_res_upts.restype = C.c_double
         _lib.orc_calc_dt_local.restype = C.c_double
         _lib.orc_calc_dt_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -157,6 +159,11 @@ class Case:
             if self.les["sgs_model"] == 0:
                 self.arr["wall_distance"] = g("wall_distance")
             self.arr["Jacobian_fpts"] = g("Jacobian_fpts")
+            if self.les["sgs_model"] >= 2:  # similarity-type closures: filter, filtered solution, Leonard terms
+                self.arr["filter_upts"] = g("filter_upts")
+                self.arr["disuf_upts"] = F((nu, ne, nf))
+                for k, n3 in (("uu", 3 if nd == 2 else 6), ("Lu", 3 if nd == 2 else 6), ("ue", nd), ("Le", nd)):
+                    self.arr[k] = F((nu, ne, n3))
         # over-integration
         self.n_cub = 0
         if "over_int" in data and int(np.ravel(data["over_int"])[0]):
@@ -223,6 +230,9 @@ class Case:
             e.Jacobian_fpts = fptr(a["Jacobian_fpts"])
             if e.sgs_model == 0:
                 e.wall_distance = fptr(a["wall_distance"])
+            if e.sgs_model >= 2:
+                for k in ("filter_upts", "disuf_upts", "uu", "Lu", "ue", "Le"):
+                    setattr(e, k, fptr(a[k]))
         e.n_cub = self.n_cub
         if self.n_cub:
             for k in ("opp_over_int_cubpts", "over_int_filter", "JGinv_over_int_cubpts"):

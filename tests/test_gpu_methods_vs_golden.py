@@ -61,7 +61,7 @@ def build(ctx, d, mode=hfx.CONTRACT_AUTO):
     if "LES" in d and int(np.ravel(d["LES"])[0]):
         sc = lambda k: float(np.ravel(d[k])[0])
         e.set_les(int(sc("SGS_model")), sc("C_s"), sc("filter_ratio"), sc("Kappa"), sc("prandtl_t"), d["Jacobian_fpts"],
-                  d["wall_distance"] if "wall_distance" in d else None)
+                  d["wall_distance"] if "wall_distance" in d else None, d["filter_upts"] if "filter_upts" in d else None)
     if "over_int" in d and int(np.ravel(d["over_int"])[0]):
         e.set_over_int(d["opp_over_int_cubpts"], d["over_int_filter"], d["JGinv_over_int_cubpts"])
     if "shock_cap" in d and int(np.ravel(d["shock_cap"])[0]):
@@ -132,6 +132,10 @@ def test_les_intermediates(ctx, name):
     """LES eddy-viscosity closure on the device: SGS flux at solution and flux points, total flux, residual."""
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     e, faces = build(ctx, d)
+    if int(np.ravel(d["SGS_model"])[0]) >= 2:
+        e.calc_sgs_terms()
+    if "s0_sgsf_upts" not in d:
+        pytest.skip("a level-1 fixture: states only")
     hfx.CalcResidual(e, faces)
     assert relerr(e.download(hfx.SGSF_UPTS), d["s0_sgsf_upts"]) < 1e-11
     assert relerr(e.download(hfx.SGSF_FPTS), d["s0_sgsf_fpts"]) < 1e-11
@@ -216,6 +220,14 @@ def test_stage_states_vs_reference(ctx, name):
             p.dt = dt
             ctx.set_params(p)
         for rk in range(nstage):
+            if rk == 0 and "LES" in d and int(np.ravel(d["SGS_model"])[0]) >= 2:
+                e.calc_sgs_terms()  # src/solver.cpp:55-62
+                if st == 0 and "s0_Lu" in d:
+                    assert relerr(e.download(hfx.DISUF_UPTS), d["s0_disuf_upts"]) < 1e-12
+                    assert relerr(e.download(hfx.LU), d["s0_Lu"]) < 1e-10
+                    assert relerr(e.download(hfx.LE), d["s0_Le"]) < 1e-10
+                if st == 0 and "s0_u_after_sgs_terms" in d:
+                    assert relerr(e.download(hfx.DISU_UPTS0), d["s0_u_after_sgs_terms"]) < 1e-12
             hfx.CalcResidual(e, faces)
             if st == 0 and rk == 0:
                 assert relerr(e.download(hfx.DIV_TCONF_UPTS), d["s0_div_tconf_upts"]) < RTOLD

@@ -60,6 +60,15 @@ def test_stage_states(oracle, name):
                 assert relerr(dtl, np.ravel(d["dt_local_step%d" % st])) < 1e-13
                 e.dt_local = dtl.ctypes.data_as(O.dp)
         for rk in range(nstage):
+            if rk == 0 and c.les and c.les["sgs_model"] >= 2:
+                # similarity-type closures: filtered solution and Leonard terms at the first stage of a step (src/solver.cpp:55-62)
+                assert oracle.orc_calc_sgs_terms(C.byref(e)) == -1
+                if st == 0:
+                    assert relerr(c.arr["disuf_upts"], d["s0_disuf_upts"]) < RTOL
+                    assert relerr(c.arr["u0"], d["s0_u_after_sgs_terms"]) < RTOL
+                    if "s0_Lu" in d:
+                        assert relerr(c.arr["Lu"], d["s0_Lu"]) < 1e-11  # differences of nearly equal products
+                        assert relerr(c.arr["Le"], d["s0_Le"]) < 1e-11
             bad = oracle.orc_CalcResidual_bdy(C.byref(e), f, nfb, bd, nbd, C.byref(c.params))
             assert bad == -1
             if st == 0 and rk == 0:
@@ -216,7 +225,11 @@ def test_les_intermediates(oracle, name):
     e = c.c_eles()
     f, nfb = c.c_faces()
     bd, nbd = c.c_bdy()
+    if c.les["sgs_model"] >= 2:  # filtered solution and Leonard terms first (src/solver.cpp:55-62)
+        assert oracle.orc_calc_sgs_terms(C.byref(e)) == -1
     assert oracle.orc_CalcResidual_bdy(C.byref(e), f, nfb, bd, nbd, C.byref(c.params)) == -1
+    if "s0_sgsf_upts" not in d:
+        return  # level-1 fixture (the SVV case): stage states only
     # pow() of two libm builds in the WALE formula: a few ulps
     assert relerr(c.arr["sgsf_upts"], d["s0_sgsf_upts"]) < 1e-12
     assert relerr(c.arr["sgsf_fpts"], d["s0_sgsf_fpts"]) < 1e-12
