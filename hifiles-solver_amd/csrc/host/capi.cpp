@@ -47,7 +47,7 @@ extern "C" int hfxh_case_create(const hfxh_case_desc *d, hfxh_case **out)
   in.LES = d->LES;
   if (d->LES)
   {
-    in.SGS_model = d->SGS_model; in.C_s = d->C_s; in.filter_ratio = d->filter_ratio;
+    in.SGS_model = d->SGS_model; in.C_s = d->C_s; in.filter_ratio = d->filter_ratio; in.filter_type = d->filter_type;
     if (d->prandtl_t > 0) in.prandtl_t = d->prandtl_t;
   }
   in.over_int = d->over_int; in.over_int_order = d->over_int_order;
@@ -149,6 +149,8 @@ extern "C" int hfxh_case_get_array(hfxh_case *c, const char *name, const double 
   else if (n == "norm_basis_persson") a = &E->norm_basis_persson;
   else if (n == "opp_over_int_cubpts") a = &E->opp_over_int_cubpts;
   else if (n == "over_int_filter") a = &E->over_int_filter;
+  else if (n == "filter_upts") a = &E->filter_upts;
+  else if (n == "filter_upts_1D") a = &E->filter_upts_1D;
   else if (n == "JGinv_over_int_cubpts") a = &E->JGinv_over_int_cubpts;
   else if (n == "loc_over_int_cubpts") a = &E->loc_over_int_cubpts;
   else if (n == "detjac_upts") a = &E->detjac_upts;

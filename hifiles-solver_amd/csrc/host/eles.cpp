@@ -39,6 +39,7 @@ int eles::setup(int in_n_eles, int in_max_n_spts_per_ele, input *in_run_input)
   // src/eles_hexas.cpp:74-92, src/eles_quads.cpp:77-102
   if (run_input->shock_cap && set_shock_capture_operators()) return 1;
   if (run_input->over_int && set_over_int()) return 1;
+  if (run_input->LES && run_input->SGS_model >= 2 && compute_filter_upts()) return 1; // LES_filter, src/eles.cpp:74-77
   if (run_input->p_res >= 2) /* src/eles_hexas.cpp:97-100 */
   {
     set_loc_ppts();
@@ -414,6 +415,7 @@ int eles::mv_all_cpu_gpu(hfx_ctx *ctx)
     l.C_s = run_input->C_s; l.filter_ratio = run_input->filter_ratio; l.Kappa = run_input->Kappa; l.prandtl_t = run_input->prandtl_t;
     if (run_input->SGS_model == 0) { fail("Smagorinsky closure: the host mirror has no wall distance (use WALE, SGS_model 1)"); return 1; }
     if (hfx_eles_set_les(dev, &l, nullptr, Jacobian_fpts.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
+    if (run_input->SGS_model >= 2 && hfx_eles_set_les_filter(dev, filter_upts.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
   }
   if (n_ppts_per_ele > 0 && hfx_eles_set_opp_p(dev, n_ppts_per_ele, opp_p.get_ptr_cpu()))
   {
@@ -473,6 +475,7 @@ void eles::shock_capture() { HFX_CALL(hfx_eles_shock_capture(dev)); }
 void eles::correct_gradient() { HFX_CALL(hfx_eles_correct_gradient(dev)); }
 void eles::evaluate_viscFlux() { HFX_CALL(hfx_eles_evaluate_viscFlux(dev)); }
 void eles::extrapolate_sgsFlux() { HFX_CALL(hfx_eles_extrapolate_sgsFlux(dev)); }
+void eles::calc_sgs_terms() { HFX_CALL(hfx_eles_calc_sgs_terms(dev)); }
 void eles::extrapolate_totalFlux() { HFX_CALL(hfx_eles_extrapolate_totalFlux(dev)); }
 void eles::calculate_divergence() { HFX_CALL(hfx_eles_calculate_divergence(dev)); }
 void eles::calculate_corrected_divergence() { HFX_CALL(hfx_eles_calculate_corrected_divergence(dev)); }

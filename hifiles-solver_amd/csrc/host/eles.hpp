@@ -46,6 +46,7 @@ public:
   void correct_gradient();
   void evaluate_viscFlux();
   void extrapolate_sgsFlux(); // src/eles.cpp:2817 (run_input.LES)
+  void calc_sgs_terms();      // src/eles.cpp:2058 (SGS_model 2, 3, 4: at the first RK stage of a step)
   void extrapolate_totalFlux();
   void calculate_divergence();
   void calculate_corrected_divergence();
@@ -92,6 +93,8 @@ public:
   int calc_disu_ppts_all();                                         // every element at once, on the device
   void calc_disu_ppts(int in_ele, hf_array<double> &out_disu_ppts); // the reference's per-element accessor
   int set_shock_capture_operators(); // set_vandermonde1D/3D, calc_norm_basis, set_exp_filter
+  int compute_filter_upts();         // src/eles_hexas.cpp:583, src/eles_quads.cpp:428 (LES_filter)
+  hf_array<double> filter_upts_1D, filter_upts;
   int set_over_int();                // set_over_int (cubature points, interpolation, L2-projection filter)
   void tensor_modes(hf_array<int> &deg) const;
   // ---- ASCII restart (src/eles.cpp:655-760,845-870; info blocks src/eles_hexas.cpp:799-890, eles_quads.cpp)

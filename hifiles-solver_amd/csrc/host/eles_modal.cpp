@@ -127,6 +127,105 @@ static void kron_fill(int nd, int nr1, int nc1, const std::vector<double> &f, hf
     }
 }
 
+// The LES filter of the similarity-type closures (SGS_model 2, 3, 4): a 1-D filter over the solution points of one
+// direction, F1(target, source), and its tensor product (src/eles_hexas.cpp:583-790, src/eles_quads.cpp:428-622).
+//   filter_type 0, order >= 2: the high-order-commuting filter of Vasilyev -- for every target point i the weights
+//     w_j = F1(j, i) (NB: stored by column, as the reference does) solve the moment conditions
+//        sum_j w_j                                   = 1
+//        sum_j w_j cos(pi k_c b_ji)                  = exp(-pi^2/24)            (Gaussian transfer function at k_c)
+//        sum_j w_j (-b_ji pi sin(pi k_c b_ji))       = -exp(-pi^2/24) pi^2 / (12 k_c)   (its slope)
+//        sum_j w_j b_ji^(m+1)                        = 0,   m = 3 .. N-1               (vanishing moments)
+//     with b_ji = (x_j - x_i)/dlt, dlt = 2/order, k_c = 1/filter_ratio; at the centre point of an odd N the third
+//     condition is replaced by sum_j w_j b_ji^3 = 0.
+//   filter_type 1: discrete Gaussian, F1(i, j) = w_j exp(-6 (k_c b_ij)^2) normalised over j (Gauss weights w_j).
+//   filter_type 2: modal, V1 diag(exp(-(2 m / N)^2 / 48)) V1^-1.
+//   otherwise (and type 0 below order 2): the element average 1/N.
+int eles::compute_filter_upts()
+{
+  const int N = order + 1;
+  const double pi = 3.141592653589793238462643383279502884;
+  const double k_c = 1.0 / run_input->filter_ratio, dlt = 2.0 / order;
+  std::vector<double> F1((size_t)N * N, 0.0);
+  auto beta = [&](int j, int i) { return (loc_1d_upts(j) - loc_1d_upts(i)) / dlt; };
+  const int type = run_input->filter_type;
+  if (type == 0 && N >= 3)
+  {
+    const int centre = (N % 2 == 1) ? (N + 1) / 2 - 1 : -1;
+    for (int i = 0; i < N; i++)
+    {
+      // M(k, j): condition k, weight j
+      std::vector<double> M((size_t)N * N), Minv, rhs(N, 0.0);
+      rhs[0] = 1.0;
+      rhs[1] = std::exp(-pi * pi / 24.0);
+      rhs[2] = (i == centre) ? 0.0 : -rhs[1] * pi * pi / k_c / 12.0;
+      for (int j = 0; j < N; j++)
+      {
+        const double b = beta(j, i);
+        M[0 + (size_t)N * j] = 1.0;
+        M[1 + (size_t)N * j] = std::cos(pi * k_c * b);
+        M[2 + (size_t)N * j] = (i == centre) ? b * b * b : -b * pi * std::sin(pi * k_c * b);
+        for (int k = 3; k < N; k++) M[k + (size_t)N * j] = std::pow(b, k + 1);
+      }
+      if (!invert_small(N, M, Minv))
+      {
+        fail("LES filter: singular moment system");
+        return 1;
+      }
+      for (int j = 0; j < N; j++)
+      {
+        double w = 0.0;
+        for (int k = 0; k < N; k++) w += Minv[j + (size_t)N * k] * rhs[k];
+        F1[j + (size_t)N * i] = w;
+      }
+    }
+  }
+  else if (type == 1)
+  {
+    hf_array<double> xg, wg;
+    cubature_1d_nodes(0, N, xg, wg);
+    for (int i = 0; i < N; i++)
+    {
+      double norm = 0.0;
+      for (int j = 0; j < N; j++)
+      {
+        const double a = k_c * beta(i, j);
+        F1[i + (size_t)N * j] = wg(j) * std::exp(-6.0 * a * a);
+        norm += F1[i + (size_t)N * j];
+      }
+      for (int j = 0; j < N; j++) F1[i + (size_t)N * j] /= norm;
+    }
+  }
+  else if (type == 2)
+  {
+    std::vector<double> V1((size_t)N * N), W1;
+    for (int i = 0; i < N; i++)
+      for (int m = 0; m < N; m++) V1[i + (size_t)N * m] = eval_legendre(loc_1d_upts(i), m);
+    if (!invert_small(N, V1, W1))
+    {
+      fail("singular 1-D Vandermonde matrix");
+      return 1;
+    }
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++)
+      {
+        double v = 0.0;
+        for (int m = 0; m < N; m++)
+        {
+          const double eta = m / double(N);
+          v += V1[i + (size_t)N * m] * std::exp(-(2.0 * eta) * (2.0 * eta) / 48.0) * W1[m + (size_t)N * j];
+        }
+        F1[i + (size_t)N * j] = v;
+      }
+  }
+  else
+    for (auto &v : F1) v = 1.0 / N;
+  filter_upts_1D.setup(N, N);
+  for (int j = 0; j < N; j++)
+    for (int i = 0; i < N; i++) filter_upts_1D(i, j) = F1[i + (size_t)N * j];
+  kron_fill(n_dims, N, N, F1, filter_upts);
+  return 0;
+}
+
 int eles::set_shock_capture_operators()
 {
   const int N = order + 1, nu = n_upts_per_ele;

@@ -34,9 +34,10 @@ struct input
   int shock_cap = 0, shock_det = 0, shock_det_field = 0;
   double s0 = 0.0, expf_fac = 36.0;
   int expf_order = 4, expf_cutoff = 0;
-  // ---- LES eddy-viscosity closure (src/input.cpp:167-182,666): SGS_model 0 Smagorinsky (needs the wall distance: meshes
-  // without walls only here), 1 WALE
-  int LES = 0, SGS_model = 1;
+  // ---- LES closure (src/input.cpp:167-182,666): SGS_model 0 Smagorinsky (needs the wall distance: meshes without walls
+  // only here), 1 WALE, 2 WALE + similarity, 3 spectral vanishing viscosity, 4 similarity; the last three filter the
+  // solution with filter_upts built from filter_type / filter_ratio
+  int LES = 0, SGS_model = 1, filter_type = 0;
   double C_s = 0.0, filter_ratio = 1.0, Kappa = 0.41, prandtl_t = 0.9;
   // ---- plotting: points per edge (src/input.cpp:110; the reference's default is 2)
   int p_res = 2;

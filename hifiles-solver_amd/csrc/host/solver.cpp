@@ -434,9 +434,13 @@ int MoveToDevice(solution *S, int device)
 }
 
 // ---- the stage scheduler: same call order as the reference --------------------------------
-void CalcResidual(int /*in_file_num*/, int /*in_rk_stage*/, solution *FlowSol)
+void CalcResidual(int /*in_file_num*/, int in_rk_stage, solution *FlowSol)
 {
   int i;
+  // 0: closures that filter the solution do so once per time step, at its first stage (src/solver.cpp:55-62)
+  if (FlowSol->run_input.LES && FlowSol->run_input.SGS_model >= 2 && in_rk_stage == 0)
+    for (i = 0; i < FlowSol->n_ele_types; i++)
+      if (FlowSol->mesh_eles(i)) FlowSol->mesh_eles(i)->calc_sgs_terms();
   // the reference asks `nproc > 1`; a rank that is its own neighbour (self_partition) has partition faces on one rank
   const bool mpi = FlowSol->nproc > 1 || FlowSol->n_mpi_inters > 0;
   auto each_ele = [&](void (eles::*m)()) {

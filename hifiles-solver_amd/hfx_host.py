@@ -29,7 +29,7 @@ class CaseDesc(C.Structure):
                 ("over_int", C.c_int), ("over_int_order", C.c_int), ("shock_cap", C.c_int), ("shock_det_field", C.c_int),
                 ("s0", C.c_double), ("expf_fac", C.c_double), ("expf_order", C.c_int), ("expf_cutoff", C.c_int),
                 ("LES", C.c_int), ("SGS_model", C.c_int), ("C_s", C.c_double), ("filter_ratio", C.c_double),
-                ("prandtl_t", C.c_double), ("p_res", C.c_int), ("self_partition", C.c_int * 3)]
+                ("prandtl_t", C.c_double), ("p_res", C.c_int), ("self_partition", C.c_int * 3), ("filter_type", C.c_int)]
 
 
 class BcDesc(C.Structure):
@@ -271,6 +271,8 @@ class Case:
             d["Kappa"] = np.array([0.41])
             d["prandtl_t"] = np.array([float(self.cfg.get("prandtl_t", 0.0)) or 0.9])
             d["Jacobian_fpts"] = self.array("Jacobian_fpts")
+            if int(self.cfg.get("SGS_model", 0)) >= 2:
+                d["filter_upts"] = self.array("filter_upts")
         return d
 
     def to_device(self, device=0):

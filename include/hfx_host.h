@@ -72,7 +72,8 @@ typedef struct hfxh_case_desc
   int shock_cap, shock_det_field;
   double s0, expf_fac;
   int expf_order, expf_cutoff;
-  /* LES eddy-viscosity closure (src/input.cpp:167-182): LES 1, SGS_model 1 (WALE), C_s, filter_ratio, prandtl_t (0: 0.9) */
+  /* LES closure (src/input.cpp:167-182): LES 1, SGS_model 1 WALE / 2 WALE + similarity / 3 SVV / 4 similarity, C_s,
+   * filter_ratio, prandtl_t (0: 0.9); filter_type at the end of this struct */
   int LES, SGS_model;
   double C_s, filter_ratio, prandtl_t;
   int p_res; /* plot points per edge (`p_res`, src/input.cpp:110); 0: the reference's default 2 */
@@ -81,6 +82,10 @@ typedef struct hfxh_case_desc
    * one-sided kernels -- then runs on ONE rank: how the RCCL transport is exercised on a one-GPU box, and how
    * bench.py prices the partitioned stage on one GPU (--self-partition). */
   int self_partition[3];
+  /* LES closures 2 (WALE + similarity), 3 (spectral vanishing viscosity), 4 (similarity) filter the solution:
+   * filter_type 0 high-order-commuting Vasilyev, 1 discrete Gaussian, 2 modal, other: average (src/input.cpp:173,
+   * src/eles_hexas.cpp:583-790, src/eles_quads.cpp:428-622; the mirror builds filter_upts in csrc/host/eles_modal.cpp) */
+  int filter_type;
 } hfxh_case_desc;
 
 const char *hfxh_last_error(void);

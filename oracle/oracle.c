@@ -1772,7 +1772,11 @@ long orc_rk_step_bdy(orc_eles *e, const orc_int_inters *faces, int n_face_blocks
     RKSteps = 14;
   for (int s = 0; s < RKSteps; s++)
   {
-    long bad = orc_CalcResidual_bdy(e, faces, n_face_blocks, bdy, n_bdy_blocks, P);
+    long bad = -1;
+    if (s == 0 && e->sgs_model >= 2) /* src/solver.cpp:55-62 */
+      bad = orc_calc_sgs_terms(e);
+    if (bad >= 0) return bad;
+    bad = orc_CalcResidual_bdy(e, faces, n_face_blocks, bdy, n_bdy_blocks, P);
     if (bad >= 0) return bad;
     orc_AdvanceSolution(e, P, s);
   }

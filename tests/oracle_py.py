@@ -356,6 +356,8 @@ class PartitionedCase(Case):
     def rk_step(self):
         o = load()
         for s in range(self.params.n_rk if self.params.adv_type else 1):
+            if s == 0 and self.les and self.les["sgs_model"] >= 2:  # src/solver.cpp:55-62
+                assert o.orc_calc_sgs_terms(C.byref(self.c_eles())) < 0
             bad = self.CalcResidual()
             assert bad < 0, "NaN at %d" % bad
             o.orc_AdvanceSolution(C.byref(self._e), C.byref(self.params), C.c_int(s))

@@ -111,6 +111,29 @@ def test_les_wale_through_the_mirror(name, dims, mode):
     c.close()
 
 
+@pytest.mark.parametrize("mode", ["methods", 2])
+@pytest.mark.parametrize("name", ["hex_p2_les_wsm", "hex_p2_les_sim", "hex_p2_les_svv"])
+def test_les_filtered_closures_through_the_mirror(name, mode):
+    """SGS_model 2 / 4 / 3 from the mesh and the input keys: the mirror builds filter_upts (compute_filter_upts),
+    CalcResidual calls calc_sgs_terms at the first stage of every step; two steps against the reference's states."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    k = meta["keys"]
+    n = meta["n"] if isinstance(meta["n"], list) else [meta["n"]] * 3
+    c = H.Case(n, xv=d["xv"], dims=3, order=k["order"], LES=1, SGS_model=k["SGS_model"], C_s=k["C_s"],
+               filter_ratio=k["filter_ratio"], filter_type=k["filter_type"], T_c_ic=k["T_c_ic"])
+    assert rel(c.array("filter_upts"), d["filter_upts"]) < 1e-12
+    c.to_device(0)
+    if mode == "methods":
+        c.run(2)
+    else:
+        c.run_steps_lib(2, fused=mode)
+    c.sync_host()
+    last = int(d["sizes"][7]) - 1
+    assert rel(c.array("disu_upts0"), d["u_step1_stage%d" % last]) < 1e-11
+    c.close()
+
+
 def test_uniform_mesh_vs_oracle(oracle):
     """Computed nodes on the axis-aligned fixture mesh: GPU and oracle see the same registration data."""
     c, d = fixture_case("hex_p2_n3_uniform")

@@ -165,6 +165,20 @@ def test_gpu_rccl_les_self_partition(tmp_path, mode):
     assert rel(u, u1) < 1e-11
 
 
+@pytest.mark.parametrize("mode", ["methods", "fused"])
+@pytest.mark.parametrize("model,ftype", [(2, 0), (4, 1)])
+def test_gpu_rccl_les_similarity_self_partition(tmp_path, mode, model, ftype):
+    """the closures that filter the solution (WALE + similarity, similarity) on partitioned blocks: calc_sgs_terms at the
+    first stage of every step -- CalcResidual's own call on the per-method path, phase 1 of hfx_stage_partitioned on the
+    fused one -- and the three messages per stage over RCCL"""
+    n_local = [3, 4, 3]
+    cfg = dict(CFG, self_partition=[1, 0, 1], riemann_solve_type=3, LES=1, SGS_model=model, C_s=0.325, filter_ratio=2.0, filter_type=ftype)
+    PU.spawn(PU.gpu_worker, 1, (n_local, [1, 1, 1], cfg, 2, str(tmp_path), mode, "gloo", "rccl"))
+    u1, div1 = PU.single_rank_oracle(n_local, cfg, 2)
+    u = PU.assemble(str(tmp_path), "u", n_local, [1, 1, 1], u1.shape)
+    assert rel(u, u1) < 1e-11
+
+
 @pytest.mark.parametrize("transport", ["rccl", "torch"])
 def test_gpu_partitioned_cfl_time_step(tmp_path, transport):
     """dt_type 1 on the partitioned fused path: calc_time_step at the top of every step (src/HiFiLES.cpp:198), the MIN

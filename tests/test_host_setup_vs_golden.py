@@ -225,3 +225,35 @@ def test_simplex_classes_refuse_what_they_do_not_build():
     d = dict(np.load(os.path.join(GOLDEN, "tet_p2_n2_deformed.npz")))
     with pytest.raises(Exception):
         H.Simplex(2, 9, d["shape"][:, :4, :])  # no point table for this order
+
+
+@pytest.mark.parametrize("ftype,order,dims", [(0, 2, 3), (0, 3, 2), (0, 4, 3), (1, 2, 3), (1, 3, 2), (2, 3, 3), (3, 2, 2), (0, 1, 2)])
+def test_les_filter_properties(ftype, order, dims):
+    """compute_filter_upts (src/eles_hexas.cpp:583, src/eles_quads.cpp:428): every filter preserves constants (rows sum to
+    one: the first moment condition / the normalisation / the mean mode) and is the tensor product of its 1-D factor."""
+    c = H.Case([3] * dims + [1] * (3 - dims), dims=dims, order=order, LES=1, SGS_model=4, C_s=0.1, filter_ratio=2.0, filter_type=ftype)
+    F = c.array("filter_upts")
+    N = order + 1
+    assert F.shape == (N ** dims, N ** dims)
+    if ftype == 0 and order >= 2:
+        # the Vasilyev weights are stored by column (the reference's filter_upts_1D(j,i) = B(j)): columns sum to one
+        assert np.abs(F.sum(axis=0) - 1).max() < 1e-10
+    else:
+        assert np.abs(F.sum(axis=1) - 1).max() < 1e-12
+    # tensor structure with the first direction fastest: F = F1 (x) F1 [(x) F1]
+    f = c.array("filter_upts_1D")
+    K = np.kron(f, f) if dims == 2 else np.kron(f, np.kron(f, f))
+    assert np.abs(K - F).max() < 1e-13
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["hex_p2_les_wsm", "hex_p2_les_sim", "hex_p2_les_svv"])
+def test_les_filter_vs_reference(name):
+    """filter_upts of the genuine reference (Vasilyev and Gaussian filters at P2) from the host mirror's producer"""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    k = meta["keys"]
+    c = H.Case([meta["n"]] * 3 if not isinstance(meta["n"], list) else meta["n"], xv=d["xv"], dims=3, order=k["order"], LES=1,
+               SGS_model=k["SGS_model"], C_s=k["C_s"], filter_ratio=k["filter_ratio"], filter_type=k["filter_type"])
+    assert np.abs(c.array("filter_upts") - d["filter_upts"]).max() < 1e-12 * np.abs(d["filter_upts"]).max()
+    c.close()

@@ -25,6 +25,8 @@ def rel(a, b):
     # LES (WALE): the third exchange, the physical SGS flux at the partition faces (src/mpi_inters.cpp:339-397)
     ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=3, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0)),
     ([3, 4, 3], [1, 1, 1], dict(riemann_solve_type=0, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0, self_partition=[1, 0, 1])),
+    # similarity closure: calc_sgs_terms (filter from the host mirror's producer) at the first stage of the step
+    ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=3, LES=1, SGS_model=4, C_s=0.325, filter_ratio=2.0, filter_type=1)),
     ([2, 4, 4], [2, 1, 1], dict(riemann_solve_type=0, viscous=0, ic_form=1, u_c_ic=30.0, v_c_ic=10.0, w_c_ic=5.0,
                                 p_c_ic=101325.0, rho_c_ic=1.2)),          # inviscid: solution exchange only
 ])
