@@ -410,11 +410,50 @@ static int tensor_build(hfx_eles *e, FusedData *F, int N, const std::vector<doub
     if (sgn == 0.0) return 0;
     L1[(size_t)dq * N] = sgn;
   }
+  // opp_3 (the divergence of the correction functions): row p has one entry per flux point at the ends of the ND pencils
+  // through p, and the entry depends on (direction, end, position on the pencil) only.  The flux kernel then applies
+  // -opp_3 . norm_tdisf pencil-wise, from the pencil values it holds in registers anyway (folded correction)
+  std::vector<double> c3((size_t)nd * 2 * N, 0.0);
+  {
+    const int w3 = std::max(e->opp_3.nnz_max, 1);
+    std::vector<char> have((size_t)nd * 2 * N, 0);
+    for (int p = 0; p < nu; p++)
+    {
+      int seen = 0;
+      for (int d = 0; d < nd; d++)
+      {
+        int i_d;
+        const int line = line_of(nd, N, d, p, i_d);
+        for (int q = 0; q < 2; q++)
+        {
+          const int f = pf[((size_t)d * L + line) * 2 + q];
+          double v = 0.0;
+          for (int c = 0; c < w3; c++)
+            if (I(e->opp_3, p, c) == f && V(e->opp_3, p, c) != 0.0)
+            {
+              v = V(e->opp_3, p, c);
+              seen++;
+            }
+          const size_t slot = ((size_t)d * 2 + q) * N + i_d;
+          if (!have[slot])
+          {
+            c3[slot] = v;
+            have[slot] = 1;
+          }
+          if (!bits_equal(c3[slot], v)) return 0;
+        }
+      }
+      int nonzero = 0;
+      for (int c = 0; c < w3; c++) nonzero += V(e->opp_3, p, c) != 0.0;
+      if (nonzero != seen) return 0; // an entry outside the pencil ends
+    }
+  }
   std::vector<double> coef;
   coef.insert(coef.end(), Dm.begin(), Dm.end());
   coef.insert(coef.end(), c5.begin(), c5.end());
   coef.insert(coef.end(), Lf.begin(), Lf.end());
   coef.insert(coef.end(), L1.begin(), L1.end());
+  coef.insert(coef.end(), c3.begin(), c3.end());
   std::vector<int> idx;
   idx.insert(idx.end(), pf.begin(), pf.end());
   idx.insert(idx.end(), fdq.begin(), fdq.end());
@@ -968,6 +1007,7 @@ struct Split2Args
   const double *delta, *tconf;
   double *fn_fpts;  // (n_fpts,n_eles,n_fields) projected viscous flux of this side
   double *ntd_fpts; // norm_tdisf_fpts
+  int folded;       // 1: div holds div_tdisf - opp_3 norm_tdisf (sum-factorised flux kernel), norm_tdisf_fpts is not written
   double *div;      // div_tdisf (flux kernel) -> read by the update kernel, which may overwrite it with div_tconf
   double *disu_next;
   double *grad_upts, *grad_fpts; // optional outputs (NULL: not written)
@@ -1204,7 +1244,7 @@ struct TGeo
   static constexpr int SP = ((ITEMS_D + 63) / 64) * 64; // padded so that a wave works on one direction
   static constexpr int TB = SGeo<ND, N>::TB;
   static constexpr int ROUNDS = (ND * SP + TB - 1) / TB;
-  static constexpr int C_D = 0, C_5 = N * N, C_LF = C_5 + ND * 2 * N, C_L1 = C_LF + ND * 2 * N;
+  static constexpr int C_D = 0, C_5 = N * N, C_LF = C_5 + ND * 2 * N, C_L1 = C_LF + ND * 2 * N, C_3 = C_L1 + ND * 2 * N;
   static constexpr int I_PF = 0, I_FDQ = ND * L * 2, I_FB = I_FDQ + G::NFP;
 };
 
@@ -1395,7 +1435,6 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   double Lrow[N];
 #pragma unroll
   for (int m = 0; m < N; m++) Lrow[m] = coef_g[T::C_LF + dq * N + m];
-  const double sgn1 = coef_g[T::C_L1 + dq * N]; // merged opp_1 row = sgn1 * Lrow (tnorm = +-1)
   // pencil role: ROUNDS work items (field, direction, pencil); a wave's items share the direction
   int it_d[ROUNDS], it_o[ROUNDS], it_fa[ROUNDS], it_fb[ROUNDS], it_k[ROUNDS];
   int it_dq[ROUNDS]; // the round's direction, wave-uniform (inactive lanes included)
@@ -1431,7 +1470,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   const long tot_u = plane_u * NF, tot_f = plane_f * NF;
   const GArr<BUF> g_u0(a.u0, tot_u), g_delta(a.delta, tot_f), g_JGu(a.JGinv_upts, plane_u * (ND * ND)), g_dju(a.detjac_upts, plane_u);
   const GArr<BUF> g_JGf(a.JGinv_fpts, plane_f * (ND * ND)), g_djf(a.detjac_fpts, plane_f), g_nrm(a.norm_fpts, plane_f * ND);
-  const GArr<BUF> g_gu(a.grad_upts, plane_u * NG), g_gf(a.grad_fpts, plane_f * NG), g_fn(a.fn_fpts, tot_f), g_ntd(a.ntd_fpts, tot_f),
+  const GArr<BUF> g_gu(a.grad_upts, plane_u * NG), g_gf(a.grad_fpts, plane_f * NG), g_fn(a.fn_fpts, tot_f),
       g_div(a.div, tot_u), g_td(a.tdisf_in, plane_u * NG);
   const unsigned lu = tu, lf = tf;
   unsigned lo_u[UNP], lo_d[DNP]; // lane offsets of the state / delta prefetch: (field plane + point)
@@ -1822,32 +1861,29 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++)
       {
+        // folded correction: the normal transformed flux at the two ends of this pencil (norm_tdisf_fpts of those flux
+        // points, which therefore never goes to HBM) and its share -opp_3 . norm_tdisf of the corrected divergence
+        const int d = it_dq[r];
+        double na = 0.0, nb = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; m++)
+        {
+          na += coef[T::C_LF + (d * 2 + 0) * N + m] * xa[r][m];
+          nb += coef[T::C_LF + (d * 2 + 1) * N + m] * xa[r][m];
+        }
+        na *= -coef[T::C_L1 + (d * 2 + 0) * N];
+        nb *= -coef[T::C_L1 + (d * 2 + 1) * N];
 #pragma unroll
         for (int mp = 0; mp < N; mp++)
         {
           double acc = 0.0;
 #pragma unroll
           for (int m = 0; m < N; m++) acc += coef[T::C_D + mp * N + m] * xa[r][m];
+          acc += coef[T::C_3 + (d * 2 + 0) * N + mp] * na;
+          acc += coef[T::C_3 + (d * 2 + 1) * N + mp] * nb;
           if (it_d[r] >= 0) sp[it_o[r] + mp * sr[r]] = acc;
         }
       }
-    }
-    if (is_f)
-    {
-      double nt[NF];
-#pragma unroll
-      for (int k = 0; k < NF; k++) nt[k] = 0.0;
-#pragma unroll
-      for (int m = 0; m < N; m++)
-      {
-        double x[NF];
-#pragma unroll
-        for (int k = 0; k < NF; k++) x[k] = ldsv(&st[(k + NF * d_f) * NU + am[m]]);
-#pragma unroll
-        for (int k = 0; k < NF; k++) nt[k] += Lrow[m] * x[k];
-      }
-#pragma unroll
-      for (int k = 0; k < NF; k++) g_ntd.st(ef + k * plane_f, lf, sgn1 * nt[k]);
     }
     stamp(7);
     lds_barrier();
@@ -1924,6 +1960,7 @@ __global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
 }
 
 // div_tdisf + opp_3 (norm_tconf - norm_tdisf) -> RK update -> disu_fpts of the new state: a streaming kernel
+// (after the sum-factorised flux kernel: (div_tdisf - opp_3 norm_tdisf) + opp_3 norm_tconf, norm_tdisf is not read)
 #ifndef HFX_UPD_WAVES
 #define HFX_UPD_WAVES 3
 #endif
@@ -1968,7 +2005,13 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
     if (is_f)
     {
 #pragma unroll
-      for (int k = 0; k < NF; k++) sc[k][tf] = g_tc.ld(ef + k * plane_f, lf) + -1.0 * g_nt.ld(ef + k * plane_f, lf);
+      for (int k = 0; k < NF; k++)
+      {
+        // folded: the flux kernel has subtracted opp_3 . norm_tdisf already (a.folded, the sum-factorised form)
+        double v = g_tc.ld(ef + k * plane_f, lf);
+        if (!a.folded) v += -1.0 * g_nt.ld(ef + k * plane_f, lf);
+        sc[k][tf] = v;
+      }
     }
     const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
     const double dj = g_dj.ld(eu, lu);
@@ -2115,6 +2158,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.JGinv_fpts = ea.JGinv_fpts; e2.norm_fpts = e->norm_fpts;
     e2.u0 = ea.u0; e2.u1 = ea.u1; e2.delta = ea.delta; e2.tconf = ea.tconf;
     e2.fn_fpts = F->fn_fpts; e2.ntd_fpts = e->arr[HFX_NORM_TDISF_FPTS]; e2.div = ea.div_out;
+    e2.folded = (F->tensor_ok && !opt.dictionary_rows) ? 1 : 0;
     e2.disu_next = ea.disu_next;
     bool any_bdy = false;
     for (int b = 0; b < nfb; b++) any_bdy = any_bdy || faces[b]->is_bdy;
@@ -2412,9 +2456,11 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant)
   if (variant == 3)
   {
     // u, delta, volume + flux-point metrics, own normals r ; div, norm_tdisf, Fn w
-    bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nd + nu * nf + 2 * nfp * nf);
+    // (norm_tdisf: the dictionary-row form only; the sum-factorised kernel folds opp_3 . norm_tdisf into div)
+    const double ntd = (e->fused && e->fused->tensor_ok && !e->ctx->opt.dictionary_rows) ? 0.0 : nfp * nf;
+    bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nd + nu * nf + nfp * nf + ntd);
     bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp); // disu, Fn, normal(left), tdA r; tconf w
-    bytes[3] = ne * 8.0 * (3 * nu * nf + nu + 2 * nfp * nf + 2 * nu * nf + nfp * nf);            // u0,u1,div,detjac,tconf,ntd r; u0,u1,disu w
+    bytes[3] = ne * 8.0 * (3 * nu * nf + nu + nfp * nf + ntd + 2 * nu * nf + nfp * nf);          // u0,u1,div,detjac,tconf(,ntd) r; u0,u1,disu w
   }
 }
 
