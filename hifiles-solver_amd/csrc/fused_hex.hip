@@ -1014,6 +1014,7 @@ struct Split2Args
   int xcd_order;                 // EleOrder: contiguous element ranges per XCD
   const double *tdisf_in;        // over-integration: the transformed inviscid flux, already evaluated (NULL: computed here)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
+  int stamp_it;      // which iteration of workgroup 0 is stamped
   long long *stamps; // diagnostics (tools/flux_phase_stamps.py): cycle counter of wave w of workgroup 0 at the phase boundaries
   // update kernel: opp_3 and opp_0 in ELL form (values, columns, width), rows held in registers
   const double *o3v, *o0v;
@@ -1578,12 +1579,18 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         issue(order.at(0), 0);
         issue_met(order.at(0));
       }
+      auto lstamp = [&](long kk, int slot) {
+        if (a.stamps != nullptr && blockIdx.x == 0 && kk == a.stamp_it && lane == 0) a.stamps[3 * 16 + slot] = clock64();
+      };
       for (long kk = 0, e = order.at(0), e_next; e >= 0; kk++, e = e_next)
       {
         e_next = order.at(kk + 1);
+        lstamp(kk, 0);
         // outstanding, oldest first: state/delta of this element, metrics of this element
         if (viscous) HFX_VMCNT(N_MV); else HFX_VMCNT(N_MI);
+        lstamp(kk, 1);
         lds_barrier(); // 1: the compute waves may read the input slot
+        lstamp(kk, 2);
         if (e_next >= 0)
         {
           issue(e_next, (int)((kk + 1) & 1));
@@ -1591,10 +1598,15 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         }
         else
           HFX_VMCNT(0);
+        lstamp(kk, 3);
         lds_barrier(); // 2: the compute waves may read the metric slot
+        lstamp(kk, 4);
         lds_barrier(); // 3: ... and have finished with it
+        lstamp(kk, 5);
         if (e_next >= 0) issue_met(e_next);
+        lstamp(kk, 6);
         lds_barrier(); // 4
+        lstamp(kk, 7);
       }
 #undef HFX_VMCNT
       return;
@@ -1611,7 +1623,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 
   int it_no = 0;
   auto stamp = [&](int slot) {
-    if (a.stamps != nullptr && blockIdx.x == 0 && it_no == 2 && (t & 63) == 0) a.stamps[(t >> 6) * 16 + slot] = clock64();
+    if (a.stamps != nullptr && blockIdx.x == 0 && it_no == a.stamp_it && (t & 63) == 0) a.stamps[(t >> 6) * 16 + slot] = clock64();
   };
   for (long kk = 0, e = order.at(0), e_next; e >= 0; kk++, e = e_next, it_no++)
   {
@@ -2166,6 +2178,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.grad_fpts = (any_bdy && P.viscous) ? e->arr[HFX_GRAD_DISU_FPTS] : nullptr; // boundary points only
     e2.meta = F->meta;
     e2.stamps = F->stamps;
+    e2.stamp_it = std::max(2, opt.flux_stamps);
     e2.o3v = e->opp_3.ell_val; e2.o3i = e->opp_3.ell_idx; e2.o3w = std::max(e->opp_3.nnz_max, 1);
     e2.o0v = e->opp_0.ell_val; e2.o0i = e->opp_0.ell_idx; e2.o0w = std::max(e->opp_0.nnz_max, 1);
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;
@@ -2435,6 +2448,9 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
       for (int q = 1; q <= 9; q++) fprintf(stderr, "%s%lld", q > 1 ? " " : "", h[w * 16 + q] - h[w * 16 + q - 1]);
       fprintf(stderr, "   (fill | bar1 | A | bar2 | B | bar3 | C | bar4 | D)  total %lld\n", h[w * 16 + 9] - h[w * 16]);
     }
+    fprintf(stderr, "loader wave cycles: ");
+    for (int q = 1; q <= 7; q++) fprintf(stderr, "%s%lld", q > 1 ? " " : "", h[3 * 16 + q] - h[3 * 16 + q - 1]);
+    fprintf(stderr, "   (wait state | bar1 | issue state, wait metrics | bar2 | bar3 | issue metrics | bar4)  total %lld\n", h[3 * 16 + 7] - h[3 * 16]);
   }
   const bool tensor = e->fused->tensor_ok && !e->ctx->opt.dictionary_rows;
   snprintf(names, names_len, "%s",

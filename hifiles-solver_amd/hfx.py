@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libhfx.so")
+LIB_PATH = os.path.join(os.environ.get("HFX_LIB_DIR", HERE), "libhfx.so")  # HFX_LIB_DIR: an A/B build (make variant)
 HEADER = os.path.join(ROOT, "include", "hfx.h")
 
 dp = C.POINTER(C.c_double)

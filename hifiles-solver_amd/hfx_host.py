@@ -8,7 +8,7 @@ import numpy as np
 import hfx
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhfx_host.so")
+LIB_PATH = os.path.join(os.environ.get("HFX_LIB_DIR", HERE), "libhfx_host.so")  # HFX_LIB_DIR: an A/B build (make variant)
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
