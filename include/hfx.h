@@ -308,7 +308,8 @@ int hfx_CalcResidual_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters 
  * kernels, 3 the split kernels with the fluxes evaluated in the gradient kernel (same results to
  * rounding).  All leave disu_upts(0), disu_upts(1), disu_fpts of the new state and, for the step's last
  * stage, div_tconf_upts in the public arrays; mode 2 also leaves grad_disu_upts / grad_disu_fpts of the
- * last stage, mode 3 keeps them in registers (run one per-method stage when a monitor needs them).
+ * last stage, mode 3 keeps them in registers and folds opp_3 . norm_tdisf_fpts into the divergence it stores, so
+ * norm_tdisf_fpts is not refreshed either (run one per-method stage when a monitor needs them).
  * With dt_type 1 / 2 every step starts with calc_time_step (hfx_ctx_set_CFL, hfx_eles_set_h_ref); boundary
  * blocks whose groups ramp get run_input.ramp_counter advanced after every step (src/HiFiLES.cpp:224-225). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
