@@ -1014,6 +1014,7 @@ struct Split2Args
   int xcd_order;                 // EleOrder: contiguous element ranges per XCD
   const double *tdisf_in;        // over-integration: the transformed inviscid flux, already evaluated (NULL: computed here)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
+  int simd_roles;    // 1: the waves' parts are dealt by SIMD (split_flux_tensor_kernel)
   int stamp_it;      // which iteration of workgroup 0 is stamped
   long long *stamps; // diagnostics (tools/flux_phase_stamps.py): cycle counter of wave w of workgroup 0 at the phase boundaries
   // update kernel: opp_3 and opp_0 in ELL form (values, columns, width), rows held in registers
@@ -1229,6 +1230,9 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flu
 #ifndef HFX_SPLIT2T_WAVES
 #define HFX_SPLIT2T_WAVES 2
 #endif
+#ifndef HFX_NO_PAIR
+#define HFX_NO_PAIR 0 // 1: the unpaired point physics also in the loader-wave kernel (A/B builds)
+#endif
 #ifndef HFX_FLUX_FMETRICS
 #define HFX_FLUX_FMETRICS 0
 #endif
@@ -1424,7 +1428,31 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   double *su = sA, *sd = sA + NF * NU;
   double *const st = sA, *const sg = sB, *const sp = sB;
   const cdptr coef = (cdptr)(uintptr_t)coef_g;
-  const int t = threadIdx.x;
+  // ---- which wave plays which part.  With 4 waves (P4 hexes: two HEAVY waves that own solution points and flux points,
+  // a LIGHT one with the remaining flux points, the loader) the hardware puts the 4 waves of a workgroup on the 4 SIMDs
+  // of the CU, rotated from one workgroup to the next -- but not so that the heavy waves of the two co-resident
+  // workgroups avoid each other (tools/probes/hwid_probe.hip: one SIMD gets two heavy waves, another the two idle
+  // ones).  The parts are therefore dealt by SIMD: the workgroup in the even wave slot plays loader / heavy / heavy /
+  // light on SIMDs 0..3, the one in the odd slot heavy / light / loader / heavy, so that every SIMD carries exactly one
+  // heavy wave.  `t` below is the VIRTUAL thread number 64 * part + lane.
+  int t = threadIdx.x;
+  if constexpr (LW && (TB + 64) / 64 == 4)
+  {
+    __shared__ unsigned s_hw[4];
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); // wave slot [3:0], SIMD [5:4]
+    if ((threadIdx.x & 63) == 0) s_hw[threadIdx.x >> 6] = hw;
+    __syncthreads();
+    unsigned seen = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) seen |= 1u << ((s_hw[w] >> 4) & 3);
+    if (a.simd_roles && seen == 0xfu) // (4 waves on 4 SIMDs: otherwise the parts stay with the hardware wave numbers)
+    {
+      const unsigned odd = s_hw[0] & 1u, simd = (hw >> 4) & 3;
+      const unsigned part = odd ? ((0x1320u >> (4 * simd)) & 3u) : ((0x2103u >> (4 * simd)) & 3u);
+      t = (int)(part * 64 + (threadIdx.x & 63));
+    }
+  }
   const int tu = t < NU ? t : NU - 1, tf = t < NFP ? t : NFP - 1;
   const bool is_u = t < NU, is_f = t < NFP;
   const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
@@ -1601,10 +1629,23 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         lstamp(kk, 3);
         lds_barrier(); // 2: the compute waves may read the metric slot
         lstamp(kk, 4);
-        lds_barrier(); // 3: ... and have finished with it
-        lstamp(kk, 5);
-        if (e_next >= 0) issue_met(e_next);
-        lstamp(kk, 6);
+        if (viscous && !HFX_NO_PAIR)
+        {
+          // paired physics: the compute waves take their metrics into registers at the top of phase B and say so (2b):
+          // the slot is refilled most of an iteration ahead of its next use
+          lds_barrier(); // 2b
+          lstamp(kk, 5);
+          if (e_next >= 0) issue_met(e_next);
+          lstamp(kk, 6);
+          lds_barrier(); // 3
+        }
+        else
+        {
+          lds_barrier(); // 3: ... and have finished with it
+          lstamp(kk, 5);
+          if (e_next >= 0) issue_met(e_next);
+          lstamp(kk, 6);
+        }
         lds_barrier(); // 4
         lstamp(kk, 7);
       }
@@ -1709,12 +1750,12 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       }
     }
     double u[NF], uf[NF];
-    if (is_u)
+    if (is_u || LW) // (LW: every lane, on clamped point numbers -- the paired physics of phase B)
     {
 #pragma unroll
       for (int k = 0; k < NF; k++) u[k] = ldsv(&su[k * NUS + tu]);
     }
-    if (viscous && is_f)
+    if (viscous && (is_f || LW))
     {
       // pencil position outermost: NF independent accumulators per batch of LDS reads (one wait per batch
       // instead of one per field); each output still sums over ascending m
@@ -1742,6 +1783,119 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     __builtin_amdgcn_sched_barrier(0);
 #endif
     // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
+    if (LW && viscous && !HFX_NO_PAIR)
+    {
+      // PAIRED form (loader-wave kernel: registers to spare).  A thread's solution point and its flux point go through
+      // metric transform and viscous flux together, statement by statement -- two independent dependency chains, so the
+      // wave issues back to back where one chain alone waits for its previous result (one heavy wave per SIMD: nobody
+      // else would fill the gaps).  Lanes beyond the last point of a kind repeat that point's arithmetic on clamped
+      // numbers and do not store.  The inviscid and the viscous flux are summed BEFORE the one transform to reference space
+      // (the reference transforms them separately, src/eles.cpp:1439-1470 and :2360-2387: a re-association).
+      double jg2[2][NQ], inv2[2], u2[2][NF], g2[2][NG], f2[2][NG];
+#pragma unroll
+      for (int q = 0; q < NQ; q++)
+      {
+        jg2[0][q] = ldsv(&s_met[O_JGU + tu * NQ + q]);
+        jg2[1][q] = ldsv(&s_met[O_JGF + tf * NQ + q]);
+      }
+      double nr2[ND];
+#pragma unroll
+      for (int l = 0; l < ND; l++) nr2[l] = ldsv(&s_met[O_NRM + l * NFPP + tf]);
+      inv2[0] = ldsv(&s_met[O_DJU + tu]);
+      inv2[1] = ldsv(&s_met[O_DJF + tf]);
+      lds_barrier(); // 2b: the metric slot is free, the loader requests the next element's metrics
+      inv2[0] = 1.0 / inv2[0];
+      inv2[1] = 1.0 / inv2[1];
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        u2[0][k] = u[k];
+        u2[1][k] = uf[k];
+      }
+      // transformed gradients: the solution point's own, the flux point's extrapolated along its pencil
+#pragma unroll
+      for (int q = 0; q < NG; q++) g2[0][q] = ldsv(&sg[q * NU + tu]);
+#pragma unroll
+      for (int q = 0; q < NG; q++) g2[1][q] = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; m++)
+      {
+        double x[NG];
+#pragma unroll
+        for (int q = 0; q < NG; q++) x[q] = ldsv(&sg[q * NU + am[m]]);
+#pragma unroll
+        for (int q = 0; q < NG; q++) g2[1][q] += Lrow[m] * x[q];
+      }
+      // to physical space (to_physical, both points per statement)
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double cg[2][ND], tmp[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+          for (int d = 0; d < ND; d++) cg[p][d] = 0.0;
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+        {
+#pragma unroll
+          for (int p = 0; p < 2; p++) tmp[p] = inv2[p] * g2[p][k + NF * l];
+#pragma unroll
+          for (int d = 0; d < ND; d++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) cg[p][d] += tmp[p] * jg2[p][l + ND * d];
+        }
+#pragma unroll
+        for (int d = 0; d < ND; d++)
+#pragma unroll
+          for (int p = 0; p < 2; p++) g2[p][k + NF * d] = cg[p][d];
+      }
+      if (a.grad_fpts && is_f && (a.meta == nullptr || (a.meta[ef + tf] & 4)))
+#pragma unroll
+        for (int q = 0; q < NG; q++) g_gf.st(ef + q * plane_f, lf, g2[1][q]);
+      calc_visf_pair<ND>(a.P, u2, g2, f2);
+      // flux point: this side's viscous flux on its own normal
+      if (is_f)
+      {
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < ND; l++) s += f2[1][k + NF * l] * nr2[l];
+          g_fn.st(ef + k * plane_f, lf, s);
+        }
+      }
+      // solution point: total flux to reference space
+      if (is_u)
+      {
+        double ft[NG];
+        if (OI)
+        {
+          // over-integration: the de-aliased inviscid flux arrives transformed; only the viscous part is transformed here
+#pragma unroll
+          for (int q = 0; q < NG; q++) ft[q] = f2[0][q];
+        }
+        else
+        {
+          calc_invf<ND, true>(a.P.gamma, u, ft);
+#pragma unroll
+          for (int q = 0; q < NG; q++) ft[q] += f2[0][q];
+        }
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+#pragma unroll
+          for (int l = 0; l < ND; l++)
+          {
+            double s = OI ? td[k + NF * l] : 0.0;
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += jg2[0][l + ND * m] * ft[k + NF * m];
+            st[(k + NF * l) * NU + tu] = s;
+          }
+      }
+    }
+    else
+    {
     if (is_u)
     {
       if constexpr (LW)
@@ -1845,6 +1999,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         g_fn.st(ef + k * plane_f, lf, s);
       }
     }
+    } // (unpaired form)
     stamp(5);
     lds_barrier(); // st complete; sg is dead: its region takes the divergence parts
     stamp(6);
@@ -1902,12 +2057,18 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     stamp(8);
     if (is_u)
     {
+      // all NF * ND parts first (one wait), then the sums in the old order
+      double part[ND][NF];
+#pragma unroll
+      for (int d = 0; d < ND; d++)
+#pragma unroll
+        for (int k = 0; k < NF; k++) part[d][k] = ldsv(&sp[(k + NF * d) * NU + tu]);
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
-        double s = ldsv(&sp[k * NU + tu]);
-        s += ldsv(&sp[(k + NF) * NU + tu]);
-        if (ND == 3) s += ldsv(&sp[(k + NF * (ND - 1)) * NU + tu]);
+        double s = part[0][k];
+        s += part[1][k];
+        if (ND == 3) s += part[ND - 1][k];
         g_div.st(eu + k * plane_u, lu, s);
       }
     }
@@ -2179,6 +2340,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.meta = F->meta;
     e2.stamps = F->stamps;
     e2.stamp_it = std::max(2, opt.flux_stamps);
+    e2.simd_roles = opt.simd_roles ? 1 : 0;
     e2.o3v = e->opp_3.ell_val; e2.o3i = e->opp_3.ell_idx; e2.o3w = std::max(e->opp_3.nnz_max, 1);
     e2.o0v = e->opp_0.ell_val; e2.o0i = e->opp_0.ell_idx; e2.o0w = std::max(e->opp_0.nnz_max, 1);
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;

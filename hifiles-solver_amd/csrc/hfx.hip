@@ -376,6 +376,7 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   else if (n == "buffer_addressing") o.buffer_addressing = value != 0;
   else if (n == "loader_wave") o.loader_wave = value != 0;
   else if (n == "flux_stamps") o.flux_stamps = value;
+  else if (n == "simd_roles") o.simd_roles = value != 0;
   else if (n == "tensor_ops") o.tensor_ops = value != 0;
   else if (n == "general_waves") { HFX_CHECK(value == 0 || value == 3 || value == 4 || value == 8, "general_waves must be 0, 3, 4 or 8"); o.general_waves = value; }
   else HFX_CHECK(false, "hfx_ctx_set_option: unknown option %s", name);

@@ -77,6 +77,7 @@ struct hfx_ctx
     int flux_waves = 2;         // waves per SIMD the sum-factorised flux kernel is launched for (2 or 3)
     int buffer_addressing = 1;  // buffer-descriptor addressing where every array is below 4 GiB
     int loader_wave = 1;        // the LDS-DMA loader wave of the flux kernel where the element size fits
+    int simd_roles = 1;         // 1: the flux kernel deals its waves' parts by SIMD (one heavy wave per SIMD)
     int flux_stamps = 0;        // 1: phase time stamps of one workgroup of the flux kernel (printed by hfx_time_fused_kernels)
     int tensor_ops = 1;         // sum-factorised over-integration / shock capturing on tensor-product classes
     int general_waves = 0;      // waves per workgroup of the general flux kernel: 0 by the LDS image (4 or 8), else 3, 4 or 8

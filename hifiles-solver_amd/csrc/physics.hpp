@@ -137,6 +137,72 @@ __device__ __forceinline__ void calc_visf(const Phys &P, const double (&u)[ND + 
   }
 }
 
+// calc_visf<ND, true> for TWO independent states at once, every statement issued for both before the next one: a wave
+// that has nothing else to run beside it (the fused flux kernel: one heavy wave per SIMD) then finds an independent
+// instruction behind every dependent one.  Same operations and order per state as calc_visf<ND, true>.
+template <int ND>
+__device__ __forceinline__ void calc_visf_pair(const Phys &P, const double (&u)[2][ND + 2], const double (&g)[2][(ND + 2) * ND],
+                                               double (&f)[2][(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+#define HFX_P2 _Pragma("unroll") for (int p = 0; p < 2; p++)
+  double ir[2], v[2][ND], ke2[2], inte[2], mu[2];
+  HFX_P2 ir[p] = 1.0 / u[p][0];
+#pragma unroll
+  for (int d = 0; d < ND; d++) HFX_P2 v[p][d] = u[p][d + 1] * ir[p];
+  HFX_P2 ke2[p] = v[p][0] * v[p][0] + v[p][1] * v[p][1];
+  if (ND == 3) HFX_P2 ke2[p] = ke2[p] + v[p][ND - 1] * v[p][ND - 1];
+  HFX_P2 inte[p] = u[p][ND + 1] * ir[p] - 0.5 * ke2[p];
+  if (P.fix_vis == 1.0)
+  {
+    HFX_P2 mu[p] = P.mu_inf;
+  }
+  else
+  {
+    HFX_P2 mu[p] = viscosity<true>(P, inte[p]);
+  }
+  double dv[2][ND][ND];
+#pragma unroll
+  for (int d = 0; d < ND; d++)
+#pragma unroll
+    for (int m = 0; m < ND; m++) HFX_P2 dv[p][d][m] = (g[p][(d + 1) + NF * m] - g[p][0 + NF * m] * v[p][d]) * ir[p];
+  double de[2][ND];
+#pragma unroll
+  for (int m = 0; m < ND; m++)
+  {
+    double conv[2], dke[2];
+    HFX_P2 conv[p] = v[p][0] * dv[p][0][m] + v[p][1] * dv[p][1][m];
+    if (ND == 3) HFX_P2 conv[p] = conv[p] + v[p][ND - 1] * dv[p][ND - 1][m];
+    HFX_P2 dke[p] = 0.5 * ke2[p] * g[p][0 + NF * m] + u[p][0] * conv[p];
+    HFX_P2 de[p][m] = (g[p][(ND + 1) + NF * m] - dke[p] - g[p][0 + NF * m] * inte[p]) * ir[p];
+  }
+  double diag[2];
+  HFX_P2 diag[p] = dv[p][0][0] + dv[p][1][1];
+  if (ND == 3) HFX_P2 diag[p] = diag[p] + dv[p][ND - 1][ND - 1];
+  HFX_P2 diag[p] = diag[p] * (1.0 / 3.0);
+  double tau[2][ND][ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++)
+#pragma unroll
+    for (int b = 0; b < ND; b++)
+      HFX_P2 tau[p][a][b] = (a == b) ? 2.0 * mu[p] * (dv[p][a][a] - diag[p])
+                                     : mu[p] * ((a < b) ? (dv[p][a][b] + dv[p][b][a]) : (dv[p][b][a] + dv[p][a][b]));
+  double kap[2];
+  HFX_P2 kap[p] = (mu[p] / P.prandtl) * P.gamma;
+#pragma unroll
+  for (int m = 0; m < ND; m++)
+  {
+    HFX_P2 f[p][0 + NF * m] = 0.0;
+#pragma unroll
+    for (int d = 0; d < ND; d++) HFX_P2 f[p][(d + 1) + NF * m] = -tau[p][d][m];
+    double work[2];
+    HFX_P2 work[p] = v[p][0] * tau[p][0][m] + v[p][1] * tau[p][1][m];
+    if (ND == 3) HFX_P2 work[p] = work[p] + v[p][ND - 1] * tau[p][ND - 1][m];
+    HFX_P2 f[p][(ND + 1) + NF * m] = -(work[p] + kap[p] * de[p][m]);
+  }
+#undef HFX_P2
+}
+
 template <int ND>
 __device__ __forceinline__ void normal_flux(const double (&f)[(ND + 2) * ND], const double (&n)[ND], double (&fn)[ND + 2])
 {
