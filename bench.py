@@ -201,6 +201,8 @@ def general_workload(args):
         faces = [(classes[0], classes[0], d["int%d_L" % t], d["int%d_R" % t]) for t in range(3) if "int%d_L" % t in d]
         bdy = []
     ctx.set_params(hfx.params_from(per[classes[0]]))
+    for kv in args.opt:
+        ctx.set_option(*kv.split("="))
     E, plane = {}, {}
     for c in classes:
         sz = [int(v) for v in per[c]["sizes"]]

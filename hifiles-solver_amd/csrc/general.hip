@@ -27,6 +27,8 @@
 // point-wise passes are all bank-conflict free.
 #include "general.hpp"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cstring>
 
@@ -49,6 +51,7 @@ struct GeneralData
   double *fn_fpts = nullptr;     // (n_fpts, n_eles, n_fields) viscous flux projected on the point's own normal
   bool any_bdy = false;
   bool built = false;
+  long long *stamps = nullptr;
 };
 
 void general_invalidate(hfx_eles *e)
@@ -61,7 +64,7 @@ void general_destroy(hfx_eles *e)
   if (!e || !e->general) return;
   GeneralData *g = (GeneralData *)e->general;
   void *p[] = {g->o0, g->o1[0], g->o1[1], g->o1[2], g->o2[0], g->o2[1], g->o2[2], g->o3, g->o4[0], g->o4[1], g->o4[2],
-               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts};
+               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts, g->stamps};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete g;
@@ -102,6 +105,7 @@ struct GenArgs
   unsigned long long *nan_flag;
   int adv_type, in_step, dt_local_on, write_div, need_u1;
   double dt, rk_a, rk_b;
+  long long *stamps; // diagnostics (option flux_stamps): cycle counter of every wave of ONE workgroup at the phase boundaries
 };
 
 // NA output tiles at once, sharing the operator fragments: acc[j] += op[rt*16 + (0..15)][0 .. 4 ksteps) . plane_j[k][16 elements],
@@ -140,6 +144,39 @@ __device__ __forceinline__ void tile_mac(g_f64x4 (&acc)[NA], const double *__res
   }
 }
 
+// n items of NF = 5 field tiles each over W waves: whole rounds item by item; the r = n % W items of the last round are
+// cut into field groups so that W / r waves share one item (item(it, integral_constant<int, fields>, first field))
+template <int W, class F>
+__device__ __forceinline__ void split_rounds(int n, int wave, F &&item)
+{
+  const int whole = (n / W) * W, r = n - whole;
+  for (int it = wave; it < whole; it += W) item(it, std::integral_constant<int, 5>{}, 0);
+  if (r == 0) return;
+  const int share = W / r; // waves per remaining item (>= 1)
+  const int it = whole + wave / share, part = wave % share;
+  if (it >= n) return; // (W not a multiple of r: the last few waves have nothing)
+  if (share == 1)
+    item(it, std::integral_constant<int, 5>{}, 0);
+  else if (share == 2)
+  {
+    if (part == 0) item(it, std::integral_constant<int, 3>{}, 0);
+    else item(it, std::integral_constant<int, 2>{}, 3);
+  }
+  else if (share == 3)
+  {
+    if (part == 0) item(it, std::integral_constant<int, 2>{}, 0);
+    else if (part == 1) item(it, std::integral_constant<int, 2>{}, 2);
+    else item(it, std::integral_constant<int, 1>{}, 4);
+  }
+  else if (share == 4)
+  {
+    if (part == 0) item(it, std::integral_constant<int, 2>{}, 0);
+    else item(it, std::integral_constant<int, 1>{}, part + 1);
+  }
+  else if (part < 5)
+    item(it, std::integral_constant<int, 1>{}, part);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // flux kernel: u, delta -> div_tdisf, norm_tdisf, Fn   (steps 3-4, 8 (both halves), 10-12 of CalcResidual's sequence)
 // ---------------------------------------------------------------------------------------------------------------
@@ -162,34 +199,102 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
   const int nval = (int)min((long)GB, a.n_eles - e0);
   const long plane_u = (long)nu * a.n_eles, plane_f = (long)nfp * a.n_eles;
   const bool visc = a.P.viscous != 0;
+  auto stamp = [&](int slot) {
+    if (a.stamps != nullptr && blockIdx.x == gridDim.x / 2 && lane == 0) a.stamps[wave * 16 + slot] = clock64();
+  };
+  stamp(0);
 
-  // ---- P0: stage the state (and delta) of the batch: contiguous nu x 16 doubles per field in HBM -> [k][element]
-  for (int f = 0; f < NF; f++)
+  // ---- P0: stage the state (and delta) of the batch: contiguous nu x 16 doubles per field in HBM -> [k][element].
+  // ALL loads of a thread are requested before the first one is used (one memory latency for the batch instead of one per
+  // trip of the staging loop: the stamps showed 21 000 - 48 000 of a batch's 100 000 cycles here)
   {
-    const double *src = a.u0 + e0 * nu + f * plane_u;
-    for (int q = tid; q < KU * GB; q += T)
+    constexpr int MAXQ_U = NUc ? (((NUc + 3) & ~3) * GB + T - 1) / T : 0, MAXQ_D = NFPc ? (((NFPc + 3) & ~3) * GB + T - 1) / T : 0;
+    if constexpr (NUc != 0 && NFPc != 0 && (MAXQ_U + MAXQ_D) * NF <= 30) // (more would not fit the registers)
     {
-      const int el = (int)__umulhi((unsigned)q, inv_nu), k = q - el * nu; // q < nu*16: a real entry; the rest of the plane: K padding
-      if (q < nu * GB)
-        U[f * KU * GB + sw(k, el)] = (el < nval) ? src[q] : 0.0;
-      else
+      double ru[NF][MAXQ_U], rd[NF][MAXQ_D];
+#pragma unroll
+      for (int f = 0; f < NF; f++)
       {
-        const int p = q - nu * GB; // (KU - nu) * 16 padding entries
-        U[f * KU * GB + sw(nu + p / GB, p % GB)] = 0.0;
+        const double *src = a.u0 + e0 * nu + f * plane_u;
+#pragma unroll
+        for (int i = 0; i < MAXQ_U; i++)
+        {
+          const int q = tid + T * i;
+          const int el = (int)__umulhi((unsigned)q, inv_nu);
+          ru[f][i] = (q < nu * GB && el < nval) ? src[q] : 0.0;
+        }
+        if (visc)
+        {
+          const double *sd = a.delta + e0 * nfp + f * plane_f;
+#pragma unroll
+          for (int i = 0; i < MAXQ_D; i++)
+          {
+            const int q = tid + T * i;
+            const int el = (int)__umulhi((unsigned)q, inv_nfp);
+            rd[f][i] = (q < nfp * GB && el < nval) ? sd[q] : 0.0;
+          }
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NF; f++)
+      {
+#pragma unroll
+        for (int i = 0; i < MAXQ_U; i++)
+        {
+          const int q = tid + T * i;
+          if (q < KU * GB)
+          {
+            const int el = (int)__umulhi((unsigned)q, inv_nu), k = q - el * nu;
+            const int p = q - nu * GB; // >= 0: one of the (KU - nu) * 16 padding entries
+            U[f * KU * GB + ((q < nu * GB) ? sw(k, el) : sw(nu + p / GB, p % GB))] = ru[f][i];
+          }
+        }
+        if (visc)
+        {
+#pragma unroll
+          for (int i = 0; i < MAXQ_D; i++)
+          {
+            const int q = tid + T * i;
+            if (q < KF * GB)
+            {
+              const int el = (int)__umulhi((unsigned)q, inv_nfp), k = q - el * nfp;
+              const int p = q - nfp * GB;
+              D[f * KF * GB + ((q < nfp * GB) ? sw(k, el) : sw(nfp + p / GB, p % GB))] = rd[f][i];
+            }
+          }
+        }
       }
     }
-    if (visc)
+    else
     {
-      const double *sd = a.delta + e0 * nfp + f * plane_f;
-      for (int q = tid; q < KF * GB; q += T)
+      for (int f = 0; f < NF; f++)
       {
-        const int el = (int)__umulhi((unsigned)q, inv_nfp), k = q - el * nfp;
-        if (q < nfp * GB)
-          D[f * KF * GB + sw(k, el)] = (el < nval) ? sd[q] : 0.0;
-        else
+        const double *src = a.u0 + e0 * nu + f * plane_u;
+        for (int q = tid; q < KU * GB; q += T)
         {
-          const int p = q - nfp * GB;
-          D[f * KF * GB + sw(nfp + p / GB, p % GB)] = 0.0;
+          const int el = (int)__umulhi((unsigned)q, inv_nu), k = q - el * nu; // q < nu*16: a real entry; the rest of the plane: K padding
+          if (q < nu * GB)
+            U[f * KU * GB + sw(k, el)] = (el < nval) ? src[q] : 0.0;
+          else
+          {
+            const int p = q - nu * GB; // (KU - nu) * 16 padding entries
+            U[f * KU * GB + sw(nu + p / GB, p % GB)] = 0.0;
+          }
+        }
+        if (visc)
+        {
+          const double *sd = a.delta + e0 * nfp + f * plane_f;
+          for (int q = tid; q < KF * GB; q += T)
+          {
+            const int el = (int)__umulhi((unsigned)q, inv_nfp), k = q - el * nfp;
+            if (q < nfp * GB)
+              D[f * KF * GB + sw(k, el)] = (el < nval) ? sd[q] : 0.0;
+            else
+            {
+              const int p = q - nfp * GB;
+              D[f * KF * GB + sw(nfp + p / GB, p % GB)] = 0.0;
+            }
+          }
         }
       }
     }
@@ -200,29 +305,104 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
     const int c = q / ((KU - nu) * GB), p = q - c * (KU - nu) * GB;
     G[c * KU * GB + sw(nu + p / GB, p % GB)] = 0.0;
   }
+  stamp(1);
   __syncthreads();
+  stamp(2);
+
+  // ---- P3: point physics at the solution points (evaluate_invFlux, the transform of correct_gradient, evaluate_viscFlux;
+  //          src/eles.cpp:1415,1973,2285): G(f,d) <- transformed total flux.  Points first, first + stride, ...
+  auto p3_points = [&](int first, int stride) {
+  // the point's metrics are requested one trip ahead (a trip is one memory latency otherwise: 7 000 cycles measured)
+  double JGn[9], djn = 1.0;
+  auto request_metrics = [&](int q) {
+    const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
+    const bool ok = q < nu * GB && el < nval;
+    const long o = ok ? pt + (long)nu * (e0 + el) : 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) JGn[c] = ok ? a.JGinv_upts[o * 9 + c] : 0.0;
+    djn = (ok && visc) ? a.detjac_upts[o] : 1.0;
+  };
+  request_metrics(first);
+  for (int q = first; q < nu * GB; q += stride)
+  {
+    const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
+    double JG[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) JG[c] = JGn[c];
+    const double dj = djn;
+    request_metrics(q + stride);
+    if (el < nval)
+    {
+      const int so = sw(pt, el);
+      double u[NF], F[NF * ND];
+#pragma unroll
+      for (int k = 0; k < NF; k++) u[k] = U[k * KU * GB + so];
+      calc_invf<ND, true>(a.P.gamma, u, F);
+      if (visc)
+      {
+        const double idj = 1.0 / dj;
+        double g[NF * ND], fv[NF * ND];
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double tg[ND], cg[ND];
+#pragma unroll
+          for (int d = 0; d < ND; d++) tg[d] = G[(k + NF * d) * KU * GB + so];
+          g_to_physical(idj, JG, tg, cg);
+#pragma unroll
+          for (int d = 0; d < ND; d++) g[k + NF * d] = cg[d];
+        }
+        calc_visf<ND, true>(a.P, u, g, fv);
+#pragma unroll
+        for (int c = 0; c < NF * ND; c++) F[c] += fv[c];
+      }
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+        {
+          double t = 0.0;
+#pragma unroll
+          for (int m = 0; m < ND; m++) t += JG[l + ND * m] * F[k + NF * m];
+          G[(k + NF * l) * KU * GB + so] = t;
+        }
+    }
+    else
+    {
+      const int pt2 = q - el * nu, so = sw(pt2, el);
+#pragma unroll
+      for (int c = 0; c < NF * ND; c++) G[c * KU * GB + so] = 0.0;
+    }
+  }
+  };
 
   if (visc)
   {
     // ---- P1: reference-space corrected gradient at the solution points (calculate_gradient + first half of
     //          correct_gradient, src/eles.cpp:1823,1900): G(f,d) = opp_4[d] U(f) + opp_5[d] D(f)
     const int n_rt = MU / 16;
-    for (int it = wave; it < n_rt * ND; it += W)
-    {
+    // one item = (row tile, dimension): NF output tiles that share the operator fragments.  Whole rounds of W items; the
+    // items of the last, partial round are split by FIELD among the waves (W / r waves per item), so that no wave sits
+    // idle while another does a whole second item
+    auto p1_item = [&](int it, auto nf_c, int f0) {
+      constexpr int NFS = decltype(nf_c)::value;
       const int d = it % ND, rt = it / ND;
-      g_f64x4 acc[NF];
+      g_f64x4 acc[NFS];
 #pragma unroll
-      for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
-      tile_mac<NF>(acc, a.o4[d], MU, rt, U, KU * GB, KU / 4, li, lk);
-      tile_mac<NF>(acc, a.o5[d], MU, rt, D, KF * GB, KF / 4, li, lk);
+      for (int f = 0; f < NFS; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
+      tile_mac<NFS>(acc, a.o4[d], MU, rt, U + f0 * KU * GB, KU * GB, KU / 4, li, lk);
+      tile_mac<NFS>(acc, a.o5[d], MU, rt, D + f0 * KF * GB, KF * GB, KF / 4, li, lk);
       const int row = rt * 16 + li;
       if (row < nu)
 #pragma unroll
-        for (int f = 0; f < NF; f++)
+        for (int f = 0; f < NFS; f++)
 #pragma unroll
-          for (int rg = 0; rg < 4; rg++) G[(f + NF * d) * KU * GB + sw(row, lk + 4 * rg)] = acc[f][rg];
-    }
+          for (int rg = 0; rg < 4; rg++) G[(f0 + f + NF * d) * KU * GB + sw(row, lk + 4 * rg)] = acc[f][rg];
+    };
+    split_rounds<W>(n_rt * ND, wave, p1_item);
+    stamp(3);
     __syncthreads();
+    stamp(4);
 
     // ---- P2: gradient at the flux points (second half of correct_gradient: opp_6, then the transform with the flux
     //          points' own metrics, src/eles.cpp:1930,1998) and the viscous flux there, projected on the point's normal
@@ -284,90 +464,46 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
         }
       }
     }
+    stamp(5);
     __syncthreads();
+    stamp(6);
   }
 
-  // ---- P3: point physics at the solution points (evaluate_invFlux, the transform of correct_gradient, evaluate_viscFlux;
-  //          src/eles.cpp:1415,1973,2285): G(f,d) <- transformed total flux
-  for (int q = tid; q < nu * GB; q += T)
-  {
-    const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
-    if (el < nval)
-    {
-      const long o = pt + (long)nu * (e0 + el);
-      const int so = sw(pt, el);
-      double u[NF], JG[9], F[NF * ND];
-#pragma unroll
-      for (int k = 0; k < NF; k++) u[k] = U[k * KU * GB + so];
-#pragma unroll
-      for (int c = 0; c < 9; c++) JG[c] = a.JGinv_upts[o * 9 + c];
-      calc_invf<ND, true>(a.P.gamma, u, F);
-      if (visc)
-      {
-        const double idj = 1.0 / a.detjac_upts[o];
-        double g[NF * ND], fv[NF * ND];
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-        {
-          double tg[ND], cg[ND];
-#pragma unroll
-          for (int d = 0; d < ND; d++) tg[d] = G[(k + NF * d) * KU * GB + so];
-          g_to_physical(idj, JG, tg, cg);
-#pragma unroll
-          for (int d = 0; d < ND; d++) g[k + NF * d] = cg[d];
-        }
-        calc_visf<ND, true>(a.P, u, g, fv);
-#pragma unroll
-        for (int c = 0; c < NF * ND; c++) F[c] += fv[c];
-      }
-#pragma unroll
-      for (int k = 0; k < NF; k++)
-#pragma unroll
-        for (int l = 0; l < ND; l++)
-        {
-          double t = 0.0;
-#pragma unroll
-          for (int m = 0; m < ND; m++) t += JG[l + ND * m] * F[k + NF * m];
-          G[(k + NF * l) * KU * GB + so] = t;
-        }
-    }
-    else
-    {
-      const int pt2 = q - el * nu, so = sw(pt2, el);
-#pragma unroll
-      for (int c = 0; c < NF * ND; c++) G[c * KU * GB + so] = 0.0;
-    }
-  }
+  p3_points(tid, T);
+  stamp(7);
   __syncthreads();
+  stamp(8);
 
   // ---- P4: discontinuous divergence (opp_2) and normal flux at the flux points (opp_1), summed over the dimensions
   //          (calculate_divergence, extrapolate_totalFlux; src/eles.cpp:1651,1549) -> HBM, 128-byte runs
   {
     const int n_ut = MU / 16, n_ft = MF / 16;
-    for (int t = wave; t < n_ut + n_ft; t += W)
-    {
+    auto p4_item = [&](int t, auto nf_c, int f0) {
+      constexpr int NFS = decltype(nf_c)::value;
       const bool is_div = t < n_ut;
       const int rt = is_div ? t : t - n_ut;
-      g_f64x4 acc[NF];
+      g_f64x4 acc[NFS];
 #pragma unroll
-      for (int f = 0; f < NF; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int f = 0; f < NFS; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int d = 0; d < ND; d++)
-        tile_mac<NF>(acc, is_div ? a.o2[d] : a.o1[d], is_div ? MU : MF, rt, G + NF * d * KU * GB, KU * GB, KU / 4, li, lk);
+        tile_mac<NFS>(acc, is_div ? a.o2[d] : a.o1[d], is_div ? MU : MF, rt, G + (f0 + NF * d) * KU * GB, KU * GB, KU / 4, li, lk);
       const int row = rt * 16 + li, n = is_div ? nu : nfp;
       double *out = is_div ? a.div : a.ntd;
       const long plane = is_div ? plane_u : plane_f;
       if (row < n)
 #pragma unroll
-        for (int f = 0; f < NF; f++)
+        for (int f = 0; f < NFS; f++)
 #pragma unroll
           for (int rg = 0; rg < 4; rg++)
           {
             const int el = lk + 4 * rg;
-            if (el < nval) out[row + (long)n * (e0 + el) + f * plane] = acc[f][rg];
+            if (el < nval) out[row + (long)n * (e0 + el) + (f0 + f) * plane] = acc[f][rg];
           }
-    }
+    };
+    split_rounds<W>(n_ut + n_ft, wave, p4_item);
   }
+  stamp(9);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -390,6 +526,46 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
   const int nval = (int)min((long)GB, a.n_eles - e0);
   const long plane_u = (long)nu * a.n_eles, plane_f = (long)nfp * a.n_eles;
 
+  // every load of a thread is requested before the first one is used (one memory latency per staging step, as in the
+  // flux kernel's P0)
+  constexpr int MAXQ_D = NFPc ? (((NFPc + 3) & ~3) * GB + T - 1) / T : 0, MAXQ_U = NUc ? (NUc * GB + T - 1) / T : 0;
+  constexpr bool BATCH = NUc != 0 && NFPc != 0 && MAXQ_D * NF <= 20 && MAXQ_U * NF <= 15;
+  if constexpr (BATCH)
+  {
+    double rt_[NF][MAXQ_D], rn_[NF][MAXQ_D];
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+    {
+      const double *tc = a.tconf + e0 * nfp + f * plane_f, *nt = a.ntd + e0 * nfp + f * plane_f;
+#pragma unroll
+      for (int i = 0; i < MAXQ_D; i++)
+      {
+        const int q = tid + T * i;
+        const int el = (int)__umulhi((unsigned)q, inv_nfp);
+        const bool ok = q < nfp * GB && el < nval;
+        rt_[f][i] = ok ? tc[q] : 0.0;
+        rn_[f][i] = ok ? nt[q] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+    {
+#pragma unroll
+      for (int i = 0; i < MAXQ_D; i++)
+      {
+        const int q = tid + T * i;
+        if (q < KF * GB)
+        {
+          const int el = (int)__umulhi((unsigned)q, inv_nfp), k = q - el * nfp;
+          const int p = q - nfp * GB;
+          X[f * KF * GB + ((q < nfp * GB) ? sw(k, el) : sw(nfp + p / GB, p % GB))] = rt_[f][i] + -1.0 * rn_[f][i]; // the daxpy of src/eles.cpp:1746
+        }
+      }
+      for (int q = tid; q < (KU - nu) * GB; q += T) S[f * KU * GB + sw(nu + q / GB, q % GB)] = 0.0;
+    }
+  }
+  else
+  {
   for (int f = 0; f < NF; f++)
   {
     const double *tc = a.tconf + e0 * nfp + f * plane_f, *nt = a.ntd + e0 * nfp + f * plane_f;
@@ -405,6 +581,7 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
       }
     }
     for (int q = tid; q < (KU - nu) * GB; q += T) S[f * KU * GB + sw(nu + q / GB, q % GB)] = 0.0;
+  }
   }
   __syncthreads();
   {
@@ -423,10 +600,36 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
           for (int rg = 0; rg < 4; rg++) S[f * KU * GB + sw(row, lk + 4 * rg)] = acc[f][rg];
     }
   }
+  // the update's inputs, requested before the barrier that ends the opp_3 tiles (BATCH: all of them at once)
+  double pdv[BATCH ? NF : 1][BATCH ? MAXQ_U : 1], pu0[BATCH ? NF : 1][BATCH ? MAXQ_U : 1], pu1[BATCH ? NF : 1][BATCH ? MAXQ_U : 1],
+      pdj[BATCH ? MAXQ_U : 1];
+  if constexpr (BATCH)
+  {
+#pragma unroll
+    for (int i = 0; i < MAXQ_U; i++)
+    {
+      const int q = tid + T * i;
+      const int el = (int)__umulhi((unsigned)q, inv_nu);
+      const bool okq = q < nu * GB && el < nval;
+      const long p = e0 * nu + q;
+      pdj[i] = okq ? a.detjac_upts[p] : 1.0;
+#pragma unroll
+      for (int f = 0; f < NF; f++)
+      {
+        const long ok = p + f * plane_u;
+        pdv[f][i] = okq ? a.div_in[ok] : 0.0;
+        pu0[f][i] = okq ? a.u0w[ok] : 0.0;
+        pu1[f][i] = (okq && a.need_u1) ? a.u1[ok] : 0.0;
+      }
+    }
+  }
   __syncthreads();
+#pragma unroll
   for (int f = 0; f < NF; f++)
   {
-    for (int q = tid; q < nu * GB; q += T)
+#pragma unroll
+    for (int i = 0; i < (BATCH ? MAXQ_U : 1); i++)
+    for (int q = BATCH ? tid + T * i : tid; q < nu * GB; q += BATCH ? (1 << 30) : T)
     {
       const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
       const int so = f * KU * GB + sw(pt, el);
@@ -436,14 +639,14 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
         continue;
       }
       const long p = e0 * nu + q, ok = p + f * plane_u;
-      const double dv = a.div_in[ok] + S[so];
+      const double dv = (BATCH ? pdv[f][i] : a.div_in[ok]) + S[so];
       if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)ok);
       if (a.write_div) a.div[ok] = dv;
       const double s = a.src ? a.src[ok] : 0.0;
       const double dt = a.dt_local_on ? a.dt_local[e0 + el] : a.dt;
-      const double dd = dv / a.detjac_upts[p];
-      double un = a.u0w[ok];
-      const double u1v = a.need_u1 ? a.u1[ok] : 0.0;
+      const double dd = dv / (BATCH ? pdj[i] : a.detjac_upts[p]);
+      double un = BATCH ? pu0[f][i] : a.u0w[ok];
+      const double u1v = BATCH ? pu1[f][i] : (a.need_u1 ? a.u1[ok] : 0.0);
       if (a.adv_type == 0)
         un -= dt * (dd - s);
       else if (a.adv_type == 1)
@@ -697,6 +900,11 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
   a.rk_a = (p.adv_type >= 3) ? p.RK_a[in_step] : 0.0;
   a.rk_b = (p.adv_type >= 3) ? p.RK_b[in_step] : 0.0;
   a.need_u1 = (p.adv_type >= 3) || (p.adv_type == 1 && in_step == 3) || (p.adv_type == 2 && in_step == 2);
+  if (e->ctx->opt.flux_stamps && !g->stamps)
+  {
+    if (hipMalloc((void **)&g->stamps, sizeof(long long) * 16 * 16) == hipSuccess) (void)hipMemset(g->stamps, 0, sizeof(long long) * 16 * 16);
+  }
+  a.stamps = g->stamps;
   a.write_div = 1; // the flux kernel left the discontinuous part there: always complete it (the monitors read it)
   (void)last_stage;
   return a;
@@ -910,6 +1118,19 @@ int general_time_kernels(hfx_eles *const *eles, int neb, hfx_inters *const *face
   }
   for (auto &x : ev) (void)hipEventDestroy(x);
   for (int i = 0; i < 8; i++) ms[i] = (i < 4) ? acc[i] / reps : 0.0;
+  for (int i = 0; i < neb; i++)
+  {
+    GeneralData *g = (GeneralData *)eles[i]->general;
+    if (!g || !g->stamps) continue;
+    long long h[16 * 16];
+    HFX_HIP(hipMemcpy(h, g->stamps, sizeof h, hipMemcpyDeviceToHost));
+    for (int w = 0; w < 8 && h[w * 16] != 0; w++)
+    {
+      fprintf(stderr, "general flux kernel (block %d) wave %d cycles: ", i, w);
+      for (int q = 1; q <= 9; q++) fprintf(stderr, "%s%lld", q > 1 ? " " : "", h[w * 16 + q] - h[w * 16 + q - 1]);
+      fprintf(stderr, "   (P0 | bar | P1 | bar | P2 | bar | P3 | bar | P4)  total %lld\n", h[w * 16 + 9] - h[w * 16]);
+    }
+  }
   return 0;
 }
 
