@@ -665,5 +665,16 @@ def main():
     return 0
 
 
+def _json_only_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner on
+    stdout when its first communicator comes up), so everything that is not the line goes to stderr: file descriptor 1 is
+    pointed at stderr for the whole run and `print` writes to the saved descriptor."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(saved, "w", buffering=1)
+
+
 if __name__ == "__main__":
+    _json_only_stdout()
     sys.exit(main())
