@@ -313,7 +313,7 @@ def launch_ranks(args, argv):
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
         env = dict(os.environ, HFX_BENCH_TRANSPORT=transport)
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("HFX_BENCH_CHILD_TIMEOUT", "900")))
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("HFX_BENCH_CHILD_TIMEOUT", "420")))
         except subprocess.TimeoutExpired as e:
             last = "transport %s: timed out\n%s" % (transport, (e.stderr or "")[-2000:] if isinstance(e.stderr, str) else "")
             sys.stderr.write(last + "\n")
