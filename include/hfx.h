@@ -119,8 +119,10 @@ int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
 int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
 /* Measurement knobs: kernel variants with the same results (A/B runs; defaults are the product path).  name:
  * "split_grid_per_cu" (16), "xcd_order" (1), "dictionary_rows" (0), "flux_waves" (2 | 3), "buffer_addressing" (1),
- * "loader_wave" (1), "flux_stamps" (0), "tensor_ops" (1), "general_waves" (0 = by LDS image | 3 | 4 | 8) -- see
- * hfx_ctx::Options in csrc/hfx_internal.hpp. */
+ * "loader_wave" (1), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "flux_stamps" (0; n >= 1: cycle
+ * stamps of iteration max(n, 2) of one workgroup of the flux kernels, printed by the hfx_time_* entry points), "tensor_ops" (1),
+ * "general_waves" (0 = by LDS image | 3 | 4 | 8) -- see hfx_ctx::Options in csrc/hfx_internal.hpp;
+ * tests/test_gpu_fused.py::test_split3_variant_knobs_agree holds the variants to each other. */
 int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value);
 /* run_input.dt as the last calc_time_step left it (dt_type 1), or as set (dt_type 0) */
 int hfx_ctx_get_dt(hfx_ctx *ctx, double *dt);

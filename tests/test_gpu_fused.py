@@ -125,6 +125,38 @@ def test_split_paths_every_order_vs_methods(dims, order):
         c.close()
 
 
+@pytest.mark.parametrize("knob,value,exact", [("simd_roles", 0, True), ("loader_wave", 0, False), ("dictionary_rows", 1, False),
+                                              ("buffer_addressing", 0, False), ("xcd_order", 0, True), ("split_grid_per_cu", 2, True)])
+def test_split3_variant_knobs_agree(knob, value, exact):
+    """hfx_ctx_set_option selects between forms of the split3 kernels (wave parts dealt by SIMD or by wave number, loader
+    wave or register pipeline, sum-factorised or dictionary rows, buffer or flat addressing, element order, grid size).
+    Forms that only move work between waves or change addressing give the SAME bits; the others the same state to rounding."""
+    n = [4, 4, 4]
+    ref = H.Case(n, order=4, amp=0.1)
+    ref.to_device(0)
+    ref.run_steps_lib(2, fused=3)
+    ref.sync_host()
+    want = ref.array("disu_upts0").copy()
+    ref.close()
+    c = H.Case(n, order=4, amp=0.1)
+    c.to_device(0)
+    hfx.Context.set_option(_Ctx(c.handles()[0]), knob, value)
+    c.run_steps_lib(2, fused=3)
+    c.sync_host()
+    got = c.array("disu_upts0")
+    if exact:
+        assert np.array_equal(got, want), knob
+    else:
+        assert relerr(got, want) < 1e-12, knob
+    c.close()
+
+
+class _Ctx:
+    """a bare handle with hfx.Context's methods (the host mirror owns the context)"""
+    def __init__(self, h):
+        self.h = h
+
+
 @pytest.mark.parametrize("mode", [2, 3])
 def test_fused_full_size_conservation(mode):
     c = H.Case(32, order=4)
