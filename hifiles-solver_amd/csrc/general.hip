@@ -726,13 +726,20 @@ __global__ __launch_bounds__(256) void gface_delta_kernel(const GFaceArgs a)
   if (q >= a.npairs) return;
   const long il = a.L[q], ir = a.R[q];
   const double beta = (a.meta_l[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+  // every load before the first store (a load behind a store to memory that may overlap it waits for the store)
+  double ul[NF], ur[NF];
 #pragma unroll
   for (int k = 0; k < NF; k++)
   {
-    const double ul = a.disu_l[il + k * a.plane_l], ur = a.disu_r[ir + k * a.plane_r];
-    const double uc = 0.5 * (ul + ur) - beta * (ul - ur); // src/inters.cpp:637
-    a.delta_l[il + k * a.plane_l] = uc - ul;
-    a.delta_r[ir + k * a.plane_r] = uc - ur;
+    ul[k] = a.disu_l[il + k * a.plane_l];
+    ur[k] = a.disu_r[ir + k * a.plane_r];
+  }
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    const double uc = 0.5 * (ul[k] + ur[k]) - beta * (ul[k] - ur[k]); // src/inters.cpp:637
+    a.delta_l[il + k * a.plane_l] = uc - ul[k];
+    a.delta_r[ir + k * a.plane_r] = uc - ur[k];
   }
 }
 
@@ -753,6 +760,16 @@ __global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
 #pragma unroll
   for (int m = 0; m < ND; m++) n[m] = a.norm_l[il + m * a.plane_l];
   const double tl = a.tdA_l[il], tr = a.tdA_r[ir];
+  double fl[NF], fr[NF];
+  if (a.P.viscous)
+  {
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      fl[k] = a.fn_l[il + k * a.plane_l];
+      fr[k] = a.fn_r[ir + k * a.plane_r];
+    }
+  }
   riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
   if (a.P.viscous)
   {
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
     for (int k = 0; k < NF; k++)
     {
       // (1/2+b) F_L.n + (1/2-b) F_R.n - tau (u_R - u_L), n the left normal = -(right normal)
-      double fv = (0.5 + beta) * a.fn_l[il + k * a.plane_l] - (0.5 - beta) * a.fn_r[ir + k * a.plane_r];
+      double fv = (0.5 + beta) * fl[k] - (0.5 - beta) * fr[k];
       fv -= a.P.ldg_tau * (ur[k] - ul[k]);
       a.tconf_l[il + k * a.plane_l] = fn[k] * tl + fv * tl;
       a.tconf_r[ir + k * a.plane_r] = -fn[k] * tr + -fv * tr;

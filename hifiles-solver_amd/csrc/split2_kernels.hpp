@@ -43,13 +43,20 @@ __global__ __launch_bounds__(256) void face_delta_kernel(const SplitFaceArgs a)
   if (q >= a.npairs) return;
   const long il = a.L[q], ir = a.R[q];
   const double beta = (a.meta[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+  // every load before the first store (the compiler must assume that delta and disu overlap: a load behind a store waits)
+  double ul[NF], ur[NF];
 #pragma unroll
   for (int k = 0; k < NF; k++)
   {
-    const double ul = a.disu[il + k * a.plane_f], ur = a.disu[ir + k * a.plane_f];
-    const double uc = 0.5 * (ul + ur) - beta * (ul - ur); // src/inters.cpp:637
-    a.delta[il + k * a.plane_f] = uc - ul;
-    a.delta[ir + k * a.plane_f] = uc - ur;
+    ul[k] = a.disu[il + k * a.plane_f];
+    ur[k] = a.disu[ir + k * a.plane_f];
+  }
+#pragma unroll
+  for (int k = 0; k < NF; k++)
+  {
+    const double uc = 0.5 * (ul[k] + ur[k]) - beta * (ul[k] - ur[k]); // src/inters.cpp:637
+    a.delta[il + k * a.plane_f] = uc - ul[k];
+    a.delta[ir + k * a.plane_f] = uc - ur[k];
   }
 }
 

@@ -1138,6 +1138,17 @@ __global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
 #pragma unroll
   for (int m = 0; m < ND; m++) n[m] = a.fnorm[il + m * a.plane_f];
   const double tl = a.tdA[il], tr = a.tdA[ir];
+  // (every load before the first store: tconf may overlap the inputs as far as the compiler knows)
+  double fl[NF], fr[NF];
+  if (a.P.viscous)
+  {
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+    {
+      fl[k] = a.fn[il + k * a.plane_f];
+      fr[k] = a.fn[ir + k * a.plane_f];
+    }
+  }
   riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
   if (a.P.viscous)
   {
@@ -1146,7 +1157,7 @@ __global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
     for (int k = 0; k < NF; k++)
     {
       // (1/2+b) F_L.n + (1/2-b) F_R.n - tau (u_R - u_L), n the left normal = -(right normal)
-      double fv = (0.5 + beta) * a.fn[il + k * a.plane_f] - (0.5 - beta) * a.fn[ir + k * a.plane_f];
+      double fv = (0.5 + beta) * fl[k] - (0.5 - beta) * fr[k];
       fv -= a.P.ldg_tau * (ur[k] - ul[k]);
       a.tconf[il + k * a.plane_f] = fn[k] * tl + fv * tl;
       a.tconf[ir + k * a.plane_f] = -fn[k] * tr + -fv * tr;
