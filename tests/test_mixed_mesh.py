@@ -234,3 +234,57 @@ def test_mixed_channel_from_the_host_mirrors_own_operators(fused):
     for c in classes:
         E[c].close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_general_fused_stage_at_bench_size_properties():
+    """BASELINE.json configs[3] at the size bench.py --workload mixed runs (the reference's mixed channel tiled; here 512
+    tiles, every tile with its OWN state: the conserved variables scaled by a tile-dependent factor, which keeps the
+    velocity field and scales density and pressure).  Size-independent properties: (i) the general fused stage and the
+    per-method path agree on every element after the fixture's steps; (ii) tile 0, whose state is the fixture's, still equals the
+    genuine reference; (iii) two tiles with different factors differ (an indexing slip between tiles would show)."""
+    import hfx
+    import bench
+    d = dict(np.load(os.path.join(GOLDEN, "mixed_p3_channel.npz")))
+    tiles = 512
+    classes, per, faces, bdy = MU.split(d)
+    factor = 1.0 + 0.02 * (np.arange(tiles) % 7)
+
+    def make(ctx):
+        ctx.set_params(hfx.params_from(per[classes[0]]))
+        E, plane = {}, {}
+        for c in classes:
+            sz = [int(v) for v in per[c]["sizes"]]
+            plane[c] = sz[0] * sz[2]
+            big = bench.tile_arrays(per[c], tiles)
+            u = big["u_init"].copy(order="F")
+            u *= np.repeat(factor, sz[0])[None, :, None]
+            big["u_init"] = u
+            E[c] = hfx.Eles(ctx, [sz[0] * tiles] + sz[1:5], big, ele_type=sz[6], order=sz[5])
+            E[c].upload(hfx.DISU_UPTS0, u)
+        F = [hfx.IntInters(ctx, E[a], E[b], bench.tile_table(L, plane[a], tiles), bench.tile_table(R, plane[b], tiles)) for a, b, L, R in faces]
+        for a, L, ids in bdy:
+            F.append(hfx.BdyInters(ctx, E[a], bench.tile_table(L, plane[a], tiles), np.repeat(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
+                                   float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
+        return E, F
+
+    ctx = hfx.Context(0)
+    Ea, Fa = make(ctx)
+    Eb, Fb = make(ctx)
+    nstage = int(d["c2_sizes"][7])
+    last = max(int(k.split("_")[2][4:]) for k in d if k.startswith("c2_u_step"))
+    hfx.run_steps_blocks([Ea[c] for c in classes], Fa, last + 1, fused=4)
+    hfx.run_steps_blocks([Eb[c] for c in classes], Fb, last + 1, fused=0)
+    for c in classes:
+        ua, ub = Ea[c].download(hfx.DISU_UPTS0), Eb[c].download(hfx.DISU_UPTS0)
+        assert Ea[c].check_nan() == -1
+        assert relerr(ua, ub) < 1e-11, c
+        ne = int(per[c]["sizes"][0])
+        assert relerr(ua[:, :ne, :], d["c%d_u_step%d_stage%d" % (c, last, nstage - 1)]) < 1e-11, c
+        assert relerr(ua[:, ne:2 * ne, :], ua[:, :ne, :]) > 1e-3
+        assert relerr(ua[:, 7 * ne:8 * ne, :], ua[:, :ne, :]) < 1e-13  # tiles 0 and 7 carry the same factor
+    for f in Fa + Fb:
+        f.close()
+    for c in classes:
+        Ea[c].close(); Eb[c].close()
+    ctx.close()
