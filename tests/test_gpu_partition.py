@@ -3,6 +3,8 @@ drive libhfx's partition-face kernels -- through the mirrored CalcResidual with 
 send/receive call order, and through hfx_stage_partitioned (split fused kernels) -- and must reproduce
 the single-rank oracle of the global box.  "fused" = fused mode 3 (projected viscous flux on the wire),
 "fused2" = fused mode 2 (corrected gradient on the wire, as the reference)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -252,3 +254,36 @@ def test_gpu_exchange_rccl_device_buffers(tmp_path):
     stream) with the one rank a 1-GPU box allows: every segment is sent to self."""
     PU.spawn(_nccl_self_worker, 1, (str(tmp_path),))
     assert np.load(str(tmp_path / "ok.npy"))[0]
+
+
+def _fullsize_selfpartition_worker(rank, world, port, outdir):
+    import torch
+    import hfx
+    import hfx_host as H
+    torch.cuda.set_device(0)
+    nodes = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hex_p4_n32_tgv.npz"))["loc_1d_upts"]
+    a = H.Case(32, order=4, loc_1d_upts=nodes)
+    a.to_device(0)
+    a.run_steps_lib(2, fused=3)
+    a.sync_host()
+    ua = a.array("disu_upts0").copy()
+    a.close()
+    b = H.Case(32, order=4, loc_1d_upts=nodes, self_partition=[1, 1, 1])
+    b.to_device(0)
+    b.set_comm(hfx.comm_unique_id())
+    b.run_partitioned(2)
+    b.sync_host()
+    ub = b.array("disu_upts0")
+    err = np.abs(ua - ub).max() / np.abs(ua).max()
+    b.close()
+    np.save(outdir + "/err.npy", np.array([err, float(np.isfinite(ub).all())]))
+
+
+def test_gpu_fullsize_selfpartition_equals_undivided(tmp_path):
+    """BASELINE.json configs[2]'s per-GPU share (32^3 P4 hexes, all six sides partition faces: 6 144 faces to the rank itself
+    over libhfx's RCCL transport, hfx_run_steps_partitioned) against the undivided block (hfx_run_steps, fused 3) after two
+    time steps: the partitioned stage is the same computation at the size bench.py --self-partition / --gpus 8 runs it."""
+    PU.spawn(_fullsize_selfpartition_worker, 1, (str(tmp_path),))
+    err, finite = np.load(str(tmp_path / "err.npy"))
+    assert finite == 1.0
+    assert err < 1e-11
