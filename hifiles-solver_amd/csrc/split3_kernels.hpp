@@ -1216,18 +1216,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
   for (long kk = 0, e = order.at(0); e >= 0; kk++, e = order.at(kk))
   {
     const long eu = (long)NU * e, ef = (long)NFP * e;
-    double u[NF], dvin[NF], u1v[NF];
-    if (is_f)
-    {
+    double u[NF], dvin[NF], u1v[NF], tcv[NF];
+    // EVERY load of the element is requested before the first one is used (clamped lane offsets: no predicate).  With the
+    // LDS writes between them each field's load was waited for on its own -- five memory latencies at the top of an element
 #pragma unroll
-      for (int k = 0; k < NF; k++)
-      {
-        // folded: the flux kernel has subtracted opp_3 . norm_tdisf already (a.folded, the sum-factorised form)
-        double v = g_tc.ld(ef + k * plane_f, lf);
-        if (!a.folded) v += -1.0 * g_nt.ld(ef + k * plane_f, lf);
-        sc[k][tf] = v;
-      }
-    }
+    for (int k = 0; k < NF; k++) tcv[k] = g_tc.ld(ef + k * plane_f, lf);
     const double dt = a.dt_local_on ? a.dt_local[e] : a.dt;
     const double dj = g_dj.ld(eu, lu);
 #pragma unroll
@@ -1236,7 +1229,27 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
       const long ok = eu + k * plane_u;
       u[k] = g_u0.ld(ok, lu);
       dvin[k] = g_div.ld(ok, lu);
-      u1v[k] = a.need_u1 ? g_u1.ld(ok, lu) : 0.0;
+    }
+    if (a.need_u1)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) u1v[k] = g_u1.ld(eu + k * plane_u, lu);
+    }
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) u1v[k] = 0.0;
+    }
+    if (!a.folded)
+    {
+      // the dictionary-row flux kernel leaves norm_tdisf in HBM: norm_tconf - norm_tdisf (the daxpy of src/eles.cpp:1746)
+#pragma unroll
+      for (int k = 0; k < NF; k++) tcv[k] += -1.0 * g_nt.ld(ef + k * plane_f, lf);
+    }
+    if (is_f)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) sc[k][tf] = tcv[k];
     }
     lds_barrier();
     if (is_u)
