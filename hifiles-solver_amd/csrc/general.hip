@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
   for (int m = 0; m < ND; m++) n[m] = a.norm_l[il + m * a.plane_l];
   const double tl = a.tdA_l[il], tr = a.tdA_r[ir];
   double fl[NF], fr[NF];
+  const unsigned char mt = a.meta_l[il]; // with the other loads, not behind the Riemann solver
   if (a.P.viscous)
   {
 #pragma unroll
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
   riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
   if (a.P.viscous)
   {
-    const double beta = (a.meta_l[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+    const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
 #pragma unroll
     for (int k = 0; k < NF; k++)
     {

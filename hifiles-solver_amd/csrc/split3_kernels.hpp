@@ -1140,6 +1140,7 @@ __global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
   const double tl = a.tdA[il], tr = a.tdA[ir];
   // (every load before the first store: tconf may overlap the inputs as far as the compiler knows)
   double fl[NF], fr[NF];
+  const unsigned char mt = a.meta[il]; // with the other loads, not behind the Riemann solver
   if (a.P.viscous)
   {
 #pragma unroll
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(256) void face_flux2_kernel(const Split2FaceArgs a)
   riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
   if (a.P.viscous)
   {
-    const double beta = (a.meta[il] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+    const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
 #pragma unroll
     for (int k = 0; k < NF; k++)
     {
