@@ -415,17 +415,21 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       // the point inputs of (row, element lk + 4 rg) are requested one point ahead: rg = 0 before the MFMA loop
       const int row = rt * 16 + li;
       double pu[2][NF], pJ[2][9], pd[2], pn[2][ND];
+      unsigned char pm[2] = {0, 0}; // the point's flag byte (bit2: boundary point), with the other inputs
       auto request = [&](int slot, int rg) {
         const int el = lk + 4 * rg;
         const bool ok = row < nfp && el < nval;
+        // a lane without a point reads point 0 of the block (its values are not used): UNCONDITIONAL loads -- behind a
+        // predicate every pass waited for the loads it had just issued for the next one (s_waitcnt vmcnt(0) at the join)
         const long o = ok ? row + (long)nfp * (e0 + el) : 0;
 #pragma unroll
-        for (int k = 0; k < NF; k++) pu[slot][k] = ok ? a.disu[o + k * plane_f] : 1.0;
+        for (int k = 0; k < NF; k++) pu[slot][k] = a.disu[o + k * plane_f];
 #pragma unroll
-        for (int q = 0; q < 9; q++) pJ[slot][q] = ok ? a.JGinv_fpts[o * 9 + q] : 0.0;
-        pd[slot] = ok ? a.detjac_fpts[o] : 1.0;
+        for (int q = 0; q < 9; q++) pJ[slot][q] = a.JGinv_fpts[o * 9 + q];
+        pd[slot] = a.detjac_fpts[o];
 #pragma unroll
-        for (int m = 0; m < ND; m++) pn[slot][m] = ok ? a.norm_fpts[o + m * plane_f] : 0.0;
+        for (int m = 0; m < ND; m++) pn[slot][m] = a.norm_fpts[o + m * plane_f];
+        if (a.grad_fpts != nullptr) pm[slot] = a.meta[o];
       };
       request(0, 0);
       tile_mac<NF * ND>(acc, a.o6, MF, rt, G, KU * GB, KU / 4, li, lk);
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
 #pragma unroll
             for (int d = 0; d < ND; d++) g[k + NF * d] = cg[d];
           }
-          if (a.grad_fpts != nullptr && (a.meta[o] & 4)) // boundary point: the boundary kernel reads the gradient
+          if (a.grad_fpts != nullptr && (pm[sl] & 4)) // boundary point: the boundary kernel reads the gradient
 #pragma unroll
             for (int c = 0; c < NF * ND; c++) a.grad_fpts[o + c * plane_f] = g[c];
           calc_visf<ND, true>(a.P, pu[sl], g, fv);
