@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 #pragma unroll
         for (int m = 0; m < N; m++) xa[r][m] = ldsv(st + it_o[r] + m * sr[r]);
       }
+      if (a.stamps != nullptr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(10); }
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++)
       {
