@@ -467,6 +467,52 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   // ones).  The parts are therefore dealt by SIMD: the workgroup in the even wave slot plays loader / heavy / heavy /
   // light on SIMDs 0..3, the one in the odd slot heavy / light / loader / heavy, so that every SIMD carries exactly one
   // heavy wave.  `t` below is the VIRTUAL thread number 64 * part + lane.
+  // LW: the 1-D tables of the pencil phases in LDS, read as 16-byte broadcasts into registers at the top of a phase (through
+  // the scalar cache every two or three FMAs waited for their own s_load: the kernel is out of scalar registers).  For
+  // phase C the correction is folded into the matrix: Dc[d] = D - c3[d][0] (sgn L)[d][0]^T - c3[d][1] (sgn L)[d][1]^T, so
+  // that div_tdisf - opp_3 norm_tdisf along a pencil is ONE 5x5 product (rounded once here, in every workgroup alike).
+  constexpr int NN2 = (N * N + 1) & ~1, NP = (N + 1) & ~1;
+  constexpr int S_D = 0, S_DC = NN2, S_C5 = S_DC + ND * NN2, S_TOT = S_C5 + ND * 2 * NP;
+  __shared__ __attribute__((aligned(16))) double s_coef[LW ? S_TOT : 2];
+  if constexpr (LW)
+  {
+    for (int i = threadIdx.x; i < S_TOT; i += blockDim.x)
+    {
+      double v = 0.0;
+      if (i < S_DC)
+        v = (i < N * N) ? coef_g[T::C_D + i] : 0.0;
+      else if (i < S_C5)
+      {
+        const int d = (i - S_DC) / NN2, q = (i - S_DC) - d * NN2;
+        if (q < N * N)
+        {
+          const int mp = q / N, m = q - mp * N;
+          const double ta = coef_g[T::C_3 + (d * 2 + 0) * N + mp] * (coef_g[T::C_L1 + (d * 2 + 0) * N] * coef_g[T::C_LF + (d * 2 + 0) * N + m]);
+          const double tb = coef_g[T::C_3 + (d * 2 + 1) * N + mp] * (coef_g[T::C_L1 + (d * 2 + 1) * N] * coef_g[T::C_LF + (d * 2 + 1) * N + m]);
+          v = coef_g[T::C_D + q] - ta - tb;
+        }
+      }
+      else
+      {
+        const int row = (i - S_C5) / NP, mp = (i - S_C5) - row * NP;
+        v = (mp < N) ? coef_g[T::C_5 + row * N + mp] : 0.0;
+      }
+      s_coef[i] = v;
+    }
+    if constexpr ((TB + 64) / 64 != 4) __syncthreads();
+  }
+  // CNT doubles (even count, 16-byte aligned) from the table, two per LDS instruction
+  auto table = [&](int off, auto &out) {
+    typedef double hfx_d2 __attribute__((ext_vector_type(2)));
+    constexpr int CNT = sizeof(out) / sizeof(double);
+#pragma unroll
+    for (int i = 0; i < CNT / 2; i++)
+    {
+      const hfx_d2 v = *(const volatile __attribute__((address_space(3))) hfx_d2 *)(&s_coef[off + 2 * i]);
+      out[2 * i] = v.x;
+      out[2 * i + 1] = v.y;
+    }
+  };
   int t = threadIdx.x;
   if constexpr (LW && (TB + 64) / 64 == 4)
   {
@@ -763,6 +809,44 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         da[r] = ldsv(sd + it_fa[r]);
         db[r] = ldsv(sd + it_fb[r]);
       }
+      if constexpr (LW)
+      {
+        double Dm[NN2], c5a[ROUNDS][NP], c5b[ROUNDS][NP];
+        table(S_D, Dm);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+        {
+          table(S_C5 + (it_dq[r] * 2 + 0) * NP, c5a[r]);
+          table(S_C5 + (it_dq[r] * 2 + 1) * NP, c5b[r]);
+        }
+        // the N outputs of a pencil side by side (column outermost: consecutive FMAs are independent; every output still
+        // adds its terms in ascending column order), one predicated block of stores per round
+        double acc[ROUNDS][N];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+        {
+#pragma unroll
+          for (int mp = 0; mp < N; mp++) acc[r][mp] = 0.0;
+#pragma unroll
+          for (int m = 0; m < N; m++)
+#pragma unroll
+            for (int mp = 0; mp < N; mp++) acc[r][mp] += Dm[mp * N + m] * xa[r][m];
+#pragma unroll
+          for (int mp = 0; mp < N; mp++) acc[r][mp] += c5a[r][mp] * da[r];
+#pragma unroll
+          for (int mp = 0; mp < N; mp++) acc[r][mp] += c5b[r][mp] * db[r];
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+          if (it_d[r] >= 0)
+          {
+            double *sg_p = sg + it_o[r];
+#pragma unroll
+            for (int mp = 0; mp < N; mp++) sg_p[mp * sr[r]] = acc[r][mp];
+          }
+      }
+      else
+      {
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++)
       {
@@ -778,6 +862,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
           acc += coef[T::C_5 + (d * 2 + 1) * N + mp] * db[r];
           if (it_d[r] >= 0) sg_p[mp * sr[r]] = acc;
         }
+      }
       }
     }
     double u[NF], uf[NF];
@@ -1057,6 +1142,32 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         for (int m = 0; m < N; m++) xa[r][m] = ldsv(st + it_o[r] + m * sr[r]);
       }
       if (a.stamps != nullptr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(10); }
+      if constexpr (LW)
+      {
+        // the folded matrix of the round's direction: div_tdisf - opp_3 norm_tdisf of the pencil in N^2 FMAs
+        double acc[ROUNDS][N], Dc[ROUNDS][NN2];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) table(S_DC + it_dq[r] * NN2, Dc[r]); // all rounds' tables in one batch of reads
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+        {
+#pragma unroll
+          for (int mp = 0; mp < N; mp++) acc[r][mp] = 0.0;
+#pragma unroll
+          for (int m = 0; m < N; m++)
+#pragma unroll
+            for (int mp = 0; mp < N; mp++) acc[r][mp] += Dc[r][mp * N + m] * xa[r][m];
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+          if (it_d[r] >= 0)
+          {
+#pragma unroll
+            for (int mp = 0; mp < N; mp++) sp[it_o[r] + mp * sr[r]] = acc[r][mp];
+          }
+      }
+      else
+      {
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++)
       {
@@ -1082,6 +1193,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
           acc += coef[T::C_3 + (d * 2 + 1) * N + mp] * nb;
           if (it_d[r] >= 0) sp[it_o[r] + mp * sr[r]] = acc;
         }
+      }
       }
     }
     stamp(7);
