@@ -174,9 +174,10 @@ def tile_arrays(d, tiles, prefix=""):
 def tile_table(T, plane, tiles):
     """a face table (n_fpts_per_inter, n_inters) of offsets into one tile's (fpt, ele) plane, for `tiles` tiles"""
     T = T.astype(np.int64)
-    off = (np.arange(tiles, dtype=np.int64) * plane)[None, None, :]
-    # column j of the result is face j // tiles of tile j % tiles (per-face data of the tiled mesh: np.repeat(x, tiles))
-    return np.asfortranarray((T[:, :, None] + off).transpose(0, 2, 1).reshape(T.shape[0], -1, order="F").astype(np.int32))
+    # TILE-MAJOR: column j of the result is face j % n_inters of tile j // n_inters (per-face data of the tiled mesh:
+    # np.tile(x, tiles)) -- the faces of one tile stay together, as a mesh generator's face list keeps neighbouring faces
+    # together; with the tiles interleaved every face of the list would lie 15 kB from the previous one
+    return np.asfortranarray(np.concatenate([T + t * plane for t in range(tiles)], axis=1).astype(np.int32))
 
 
 def general_workload(args):
@@ -213,7 +214,7 @@ def general_workload(args):
         E[c].upload(hfx.DISU_UPTS0, big["u_init"])
     F = [hfx.IntInters(ctx, E[a], E[b], tile_table(L, plane[a], tiles), tile_table(R, plane[b], tiles)) for a, b, L, R in faces]
     for a, L, ids in bdy:
-        F.append(hfx.BdyInters(ctx, E[a], tile_table(L, plane[a], tiles), np.repeat(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
+        F.append(hfx.BdyInters(ctx, E[a], tile_table(L, plane[a], tiles), np.tile(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
                                float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
     blocks = [E[c] for c in classes]
     fused = 4 if args.mode in ("auto", "general") else 0

@@ -264,7 +264,7 @@ def test_general_fused_stage_at_bench_size_properties():
             E[c].upload(hfx.DISU_UPTS0, u)
         F = [hfx.IntInters(ctx, E[a], E[b], bench.tile_table(L, plane[a], tiles), bench.tile_table(R, plane[b], tiles)) for a, b, L, R in faces]
         for a, L, ids in bdy:
-            F.append(hfx.BdyInters(ctx, E[a], bench.tile_table(L, plane[a], tiles), np.repeat(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
+            F.append(hfx.BdyInters(ctx, E[a], bench.tile_table(L, plane[a], tiles), np.tile(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
                                    float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
         return E, F
 

@@ -37,10 +37,10 @@ def tiled(d, tiles):
     for t in range(3):
         if "int%d_L" % t in d:
             L, R = d["int%d_L" % t].astype(np.int64), d["int%d_R" % t].astype(np.int64)
-            off = (np.arange(tiles, dtype=np.int64) * (nfp * ne))[None, None, :]
-            Lb = (L[:, :, None] + off).transpose(0, 2, 1).reshape(L.shape[0], -1, order="F")
-            Rb = (R[:, :, None] + off).transpose(0, 2, 1).reshape(R.shape[0], -1, order="F")
-            faces.append((Lb.astype(np.int32), Rb.astype(np.int32)))
+            # tile-major: the faces of one tile stay together in the list (bench.tile_table)
+            Lb = np.concatenate([L + k * (nfp * ne) for k in range(tiles)], axis=1)
+            Rb = np.concatenate([R + k * (nfp * ne) for k in range(tiles)], axis=1)
+            faces.append((np.asfortranarray(Lb.astype(np.int32)), np.asfortranarray(Rb.astype(np.int32))))
     return out, faces, ne * tiles
 
 
