@@ -104,11 +104,15 @@ static void exchange_buffers(const hfx_inters *f, int kind, bool projected, doub
 
 // the grouped exchange of `kind` for the given partition-face blocks, ordered after everything the compute stream has
 // been given so far
-static int start_exchange(hfx_comm *c, hfx_inters *const *mpi_faces, int n_mpi, int kind, bool projected)
+// ordered: the communication stream is already behind the kernels that packed the buffers (they ran on it)
+static int start_exchange(hfx_comm *c, hfx_inters *const *mpi_faces, int n_mpi, int kind, bool projected, bool ordered = false)
 {
   hipStream_t cs = c->stream;
-  HFX_HIP(hipEventRecord(c->packed[kind], c->ctx->stream));
-  HFX_HIP(hipStreamWaitEvent(cs, c->packed[kind], 0));
+  if (!ordered)
+  {
+    HFX_HIP(hipEventRecord(c->packed[kind], c->ctx->stream));
+    HFX_HIP(hipStreamWaitEvent(cs, c->packed[kind], 0));
+  }
   bool any = false;
   for (int b = 0; b < n_mpi; b++) any = any || !mpi_faces[b]->seg_peer.empty();
   if (any)
@@ -204,6 +208,8 @@ static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int,
   auto phase = [&](int ph, int stage, int first) {
     return split_stage_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, ph, stage, first);
   };
+  // (the timed form keeps every kernel of a phase on the compute stream, so that its events bracket the phase)
+  const bool beside = ctx->opt.comm_stream_faces && projected && !les && visc && T == nullptr;
   bool first = true;
   int done = 0;
   for (int s = 0; n_stages_total >= 0 ? done < n_stages_total : s < n_steps; s++)
@@ -216,6 +222,40 @@ static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int,
         if (phase(0, rk, 1)) return 1;
         if (start_exchange(comm, mpi_faces, n_mpi, 0, false)) return 1; // later stages: started after phase 4 of the previous one
         first = false;
+      }
+      if (beside)
+      {
+        // ---- partition-face kernels and exchanges on the communication stream, in its order; the compute stream meets it
+        // at two events per stage: before the flux kernel (LDG corrections at the partition faces are in place) and before
+        // the update kernel (common fluxes at the partition faces are in place)
+        if (phase(1, rk, 0)) return 1; // interior LDG pairs                                      | compute stream
+        ctx->mpi_stream = cs;
+        const int r5 = phase(5, rk, 0); // LDG corrections at the partition faces (behind the receive) | communication stream
+        ctx->mpi_stream = nullptr;
+        if (r5) return 1;
+        HFX_HIP(hipEventRecord(comm->received[0], cs));
+        HFX_HIP(hipStreamWaitEvent(st, comm->received[0], 0));
+        if (phase(6, rk, 0)) return 1; // gradient + flux kernel
+        HFX_HIP(hipEventRecord(comm->packed[1], st));
+        HFX_HIP(hipStreamWaitEvent(cs, comm->packed[1], 0));
+        ctx->mpi_stream = cs;
+        int rc = phase(7, rk, 0); // pack the projected flux
+        if (!rc) rc = start_exchange(comm, mpi_faces, n_mpi, 1, true, true);
+        if (!rc) rc = phase(8, rk, 0); // common fluxes at the partition faces
+        ctx->mpi_stream = nullptr;
+        if (rc) return 1;
+        HFX_HIP(hipEventRecord(comm->received[1], cs));
+        if (phase(3, rk, 0)) return 1; // interior common fluxes                                  | compute stream
+        HFX_HIP(hipStreamWaitEvent(st, comm->received[1], 0));
+        if (phase(9, rk, 0)) return 1; // update (+ shock capturing)
+        HFX_HIP(hipEventRecord(comm->packed[0], st));
+        HFX_HIP(hipStreamWaitEvent(cs, comm->packed[0], 0));
+        ctx->mpi_stream = cs;
+        rc = phase(10, rk, 0); // pack the new flux-point solution
+        if (!rc) rc = start_exchange(comm, mpi_faces, n_mpi, 0, false, true);
+        ctx->mpi_stream = nullptr;
+        if (rc) return 1;
+        continue;
       }
       if (T) HFX_HIP(hipEventRecord(T->ph[0], st));
       if (phase(1, rk, 0)) return 1;

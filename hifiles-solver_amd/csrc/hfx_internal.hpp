@@ -63,6 +63,7 @@ struct hfx_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t mpi_stream = nullptr; // when set: the one-sided partition-face kernels of the split path are launched here (hfx_run_steps_partitioned)
   hfx_params params{};
   bool have_params = false;
   int contract_mode = HFX_CONTRACT_AUTO;
@@ -76,6 +77,7 @@ struct hfx_ctx
     int dictionary_rows = 0;    // 1: the dictionary-row flux kernel even when the operators are tensor products
     int flux_waves = 2;         // waves per SIMD the sum-factorised flux kernel is launched for (2 or 3)
     int buffer_addressing = 1;  // buffer-descriptor addressing where every array is below 4 GiB
+    int comm_stream_faces = 1;  // hfx_run_steps_partitioned: partition-face kernels on the communication stream, beside the interior ones
     int loader_wave = 1;        // the LDS-DMA loader wave of the flux kernel where the element size fits
     int simd_roles = 1;         // 1: the flux kernel deals its waves' parts by SIMD (one heavy wave per SIMD)
     int flux_stamps = 0;        // 1: phase time stamps of one workgroup of the flux kernel (printed by hfx_time_fused_kernels)

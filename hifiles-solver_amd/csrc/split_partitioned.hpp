@@ -31,7 +31,7 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
     a.out_sgsf = f->out_sgsf; a.in_sgsf = f->in_sgsf; a.sgs_ref = 1;
   }
   const dim3 g((unsigned)((a.npairs + 255) / 256)), b(256);
-  hipStream_t st = e->ctx->stream;
+  hipStream_t st = e->ctx->mpi_stream ? e->ctx->mpi_stream : e->ctx->stream;
   switch (what)
   {
   case 0: hipLaunchKernelGGL(mpi_pack_disu_kernel<ND>, g, b, 0, st, a); break;
@@ -110,6 +110,18 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
       if (shock_capture_keep_fpts(e)) return 1;
     }
     return mpi_all(0);
+  // ---- the pieces of phases 2 and 4 of variant 3 on their own (hfx_run_steps_partitioned puts the one-sided partition-face
+  // kernels on the communication stream, ctx->mpi_stream, beside the interior face kernels of phases 1 and 3)
+  case 5: return (variant == 3 && p.viscous) ? mpi_all(1) : 1; // LDG common solution at the partition faces
+  case 6: return variant == 3 ? split_stage(e, int_faces, n_int, in_step, false, 2, 3) : 1;
+  case 7: return (variant == 3 && p.viscous) ? mpi_all(5) : 1; // pack the projected viscous flux
+  case 8: return variant == 3 ? mpi_all(6) : 1;                // common fluxes at the partition faces
+  case 9:
+    if (variant != 3) return 1;
+    if (split_stage(e, int_faces, n_int, in_step, last, 4, variant)) return 1;
+    if (e->shock_ready && shock_capture_keep_fpts(e)) return 1;
+    return 0;
+  case 10: return mpi_all(0); // pack the new flux-point solution
   default:
     HFX_CHECK(false, "hfx_stage_partitioned: phase %d out of range", phase);
   }

@@ -119,7 +119,8 @@ int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
 int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
 /* Measurement knobs: kernel variants with the same results (A/B runs; defaults are the product path).  name:
  * "split_grid_per_cu" (16), "xcd_order" (1), "dictionary_rows" (0), "flux_waves" (2 | 3), "buffer_addressing" (1),
- * "loader_wave" (1), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "flux_stamps" (0; n >= 1: cycle
+ * "loader_wave" (1), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "comm_stream_faces" (1:
+ * hfx_run_steps_partitioned launches the one-sided partition-face kernels on the communication stream), "flux_stamps" (0; n >= 1: cycle
  * stamps of iteration max(n, 2) of one workgroup of the flux kernels, printed by the hfx_time_* entry points), "tensor_ops" (1),
  * "general_waves" (0 = by LDS image | 3 | 4 | 8) -- see hfx_ctx::Options in csrc/hfx_internal.hpp;
  * tests/test_gpu_fused.py::test_split3_variant_knobs_agree holds the variants to each other. */
