@@ -287,3 +287,30 @@ def test_gpu_fullsize_selfpartition_equals_undivided(tmp_path):
     err, finite = np.load(str(tmp_path / "err.npy"))
     assert finite == 1.0
     assert err < 1e-11
+
+
+def _comm_stream_worker(rank, world, port, outdir):
+    import ctypes as C
+    import torch
+    import hfx
+    import hfx_host as H
+    torch.cuda.set_device(0)
+    out = []
+    for knob in (1, 0):
+        c = H.Case([4, 5, 3], order=3, amp=0.1, riemann_solve_type=3, self_partition=[1, 1, 0])
+        c.to_device(0)
+        hfx.check(hfx.lib().hfx_ctx_set_option(c.handles()[0], b"comm_stream_faces", C.c_int(knob)))
+        c.set_comm(hfx.comm_unique_id())
+        c.run_partitioned(3)
+        c.sync_host()
+        out.append(c.array("disu_upts0").copy())
+        c.close()
+    np.save(outdir + "/same.npy", np.array([float(np.array_equal(out[0], out[1])), float(np.isfinite(out[0]).all())]))
+
+
+def test_gpu_partition_face_kernels_on_either_stream(tmp_path):
+    """hfx_run_steps_partitioned with the one-sided partition-face kernels on the communication stream (default) and on the
+    compute stream (option comm_stream_faces 0): the same kernels on the same data in the same order -- the same bits."""
+    PU.spawn(_comm_stream_worker, 1, (str(tmp_path),))
+    same, finite = np.load(str(tmp_path / "same.npy"))
+    assert finite == 1.0 and same == 1.0
