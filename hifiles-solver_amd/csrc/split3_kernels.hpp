@@ -1327,10 +1327,36 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
   const GArr<BUF> g_u0(a.u0, tot_u), g_u1(a.u1, tot_u), g_div(a.div, tot_u), g_src(a.src, tot_u), g_dj(a.detjac_upts, plane_u);
   const GArr<BUF> g_tc(a.tconf, tot_f), g_nt(a.ntd_fpts, tot_f), g_dn(a.disu_next, tot_f);
   const EleOrder order(ne, a.xcd_order != 0);
+  // the RK formula of this launch (uniform): 0: u -= dt/div (dd - s), 1: u = ca u + cb u1 + dt/div rhs, 2: low storage
+  int rk_form = 0;
+  double rk_div = 1.0, rk_ca = 0.0, rk_cb = 0.0;
+  bool rk_keep_u = false; // the stage's initial solution goes to disu_upts(1) first
+  if (a.adv_type == 1)
+  {
+    rk_keep_u = a.in_step == 0;
+    if (a.in_step < 3)
+      rk_div = 3.0;
+    else
+    {
+      rk_form = 1; rk_ca = 3.0 / 4.0; rk_cb = 1.0 / 4.0; rk_div = 4.0;
+    }
+  }
+  else if (a.adv_type == 2)
+  {
+    rk_keep_u = a.in_step == 0;
+    if (a.in_step < 2 || a.in_step == 3)
+      rk_div = 2.0;
+    else
+    {
+      rk_form = 1; rk_ca = 1.0 / 3.0; rk_cb = 2.0 / 3.0; rk_div = 6.0;
+    }
+  }
+  else if (a.adv_type != 0)
+    rk_form = 2;
   for (long kk = 0, e = order.at(0); e >= 0; kk++, e = order.at(kk))
   {
     const long eu = (long)NU * e, ef = (long)NFP * e;
-    double u[NF], dvin[NF], u1v[NF], tcv[NF];
+    double u[NF], dvin[NF], u1v[NF], tcv[NF], sv[NF];
     // EVERY load of the element is requested before the first one is used (clamped lane offsets: no predicate).  With the
     // LDS writes between them each field's load was waited for on its own -- five memory latencies at the top of an element
 #pragma unroll
@@ -1353,6 +1379,16 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
     {
 #pragma unroll
       for (int k = 0; k < NF; k++) u1v[k] = 0.0;
+    }
+    if (a.src)
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) sv[k] = g_src.ld(eu + k * plane_u, lu);
+    }
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < NF; k++) sv[k] = 0.0;
     }
     if (!a.folded)
     {
@@ -1381,49 +1417,45 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
 #pragma unroll
         for (int k = 0; k < NF; k++) dva[k] += c3[q] * x[k];
       }
+      // AdvanceSolution (src/eles.cpp:1080-1180).  Which formula applies is the same for every point of the launch: the
+      // choice is made ONCE per element, outside the loop over the fields, and the step's divisor is applied to dt once
+      // (dt / 3.0 etc. as the reference writes it).  With the choice inside the loop the compiler evaluated every
+      // formula's divisions for every field and waited for the previous field's stores before the next one's arithmetic.
+      const double cdt = (rk_div == 1.0) ? dt : dt / rk_div;
+      double unew[NF], r1v[NF];
 #pragma unroll
       for (int k = 0; k < NF; k++)
       {
         const double dv = dva[k];
-        const long ok = eu + k * plane_u;
-        if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)(ok + tu));
-        if (a.write_div) g_div.st(ok, lu, dv);
-        const double s = a.src ? g_src.ld(ok, lu) : 0.0;
+        if (dv != dv) atomicMin(a.nan_flag, (unsigned long long)(eu + k * plane_u + tu));
         const double dd = dv / dj;
         double un = u[k];
-        if (a.adv_type == 0)
-          un -= dt * (dd - s);
-        else if (a.adv_type == 1)
+        if (rk_form == 0)
+          un -= cdt * (dd - sv[k]);
+        else if (rk_form == 1)
         {
-          if (a.in_step == 0) g_u1.st(ok, lu, un);
-          if (a.in_step < 3)
-            un -= dt / 3.0 * (dd - s);
-          else
-          {
-            const double rhs = -dd + s;
-            un = 3.0 / 4.0 * un + 1.0 / 4.0 * u1v[k] + dt / 4.0 * rhs;
-          }
-        }
-        else if (a.adv_type == 2)
-        {
-          if (a.in_step == 0) g_u1.st(ok, lu, un);
-          if (a.in_step < 2 || a.in_step == 3)
-            un -= dt / 2.0 * (dd - s);
-          else if (a.in_step == 2)
-          {
-            const double rhs = -dd + s;
-            un = 1.0 / 3.0 * un + 2.0 / 3.0 * u1v[k] + dt / 6.0 * rhs;
-          }
+          const double rhs = -dd + sv[k];
+          un = rk_ca * un + rk_cb * u1v[k] + cdt * rhs;
         }
         else
         {
-          const double rhs = -dd + s;
+          const double rhs = -dd + sv[k];
           const double r1 = a.rk_a * u1v[k] + dt * rhs;
-          g_u1.st(ok, lu, r1);
+          r1v[k] = r1;
           un += a.rk_b * r1;
         }
-        g_u0.st(ok, lu, un);
-        su[k][tu] = un;
+        unew[k] = un;
+      }
+      // the stores of the element together, nothing between them
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        const long ok = eu + k * plane_u;
+        if (a.write_div) g_div.st(ok, lu, dva[k]);
+        if (rk_keep_u) g_u1.st(ok, lu, u[k]);
+        if (rk_form == 2) g_u1.st(ok, lu, r1v[k]);
+        g_u0.st(ok, lu, unew[k]);
+        su[k][tu] = unew[k];
       }
     }
     lds_barrier();
