@@ -314,3 +314,36 @@ def test_gpu_partition_face_kernels_on_either_stream(tmp_path):
     PU.spawn(_comm_stream_worker, 1, (str(tmp_path),))
     same, finite = np.load(str(tmp_path / "same.npy"))
     assert finite == 1.0 and same == 1.0
+
+
+def test_gpu_rccl_dealiasing_shock_and_walls_self_partition(tmp_path):
+    """the comm-stream form of hfx_run_steps_partitioned (partition-face kernels beside the interior ones) with everything a
+    stage can carry besides: over-integration before the flux kernel, shock capturing after the update, boundary faces --
+    a rank that is its own neighbour in x and z, walls in y, against the undivided run of the same library"""
+    import ctypes as C
+    import hfx
+    import hfx_host as H
+    n = [3, 4, 3]
+    cfg = dict(CFG, order=3, riemann_solve_type=3, over_int=1, over_int_order=5, shock_cap=1, s0=1e30, expf_fac=36.0, expf_order=4,
+               expf_cutoff=1, shock_det_field=0, bcs=[dict(type="isotherm_wall", T_static=310.0, u=3.0), dict(type="adiabat_wall", v=-2.0)],
+               sides={"y-": 0, "y+": 1})
+    c = H.Case(n, **cfg)
+    c.to_device(0)
+    e = c.handles()[1]
+    hfx.check(hfx.lib().hfx_eles_shock_capture(e))
+    sens = np.zeros(c.n_eles)
+    hfx.check(hfx.lib().hfx_eles_download(e, C.c_int(hfx.SENSOR), sens.ctypes.data_as(hfx.dp)))
+    sens = np.sort(sens)
+    c.close()
+    ratio = sens[1:] / sens[:-1]
+    k = int(np.argmax(ratio))
+    cfg["s0"] = float(np.sqrt(sens[k] * sens[k + 1]))
+    one = H.Case(n, **cfg)
+    one.to_device(0)
+    one.run_steps_lib(2, fused=3)
+    one.sync_host()
+    u1 = one.array("disu_upts0").copy()
+    one.close()
+    PU.spawn(PU.gpu_worker, 1, (n, [1, 1, 1], dict(cfg, self_partition=[1, 0, 1]), 2, str(tmp_path), "fused", "gloo", "rccl"))
+    u = PU.assemble(str(tmp_path), "u", n, [1, 1, 1], u1.shape)
+    assert rel(u, u1) < 1e-11
