@@ -496,6 +496,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   const hfx_ctx::Options &opt = e->ctx->opt;
   const int grid_per_cu = std::max(1, opt.split_grid_per_cu);
   const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * grid_per_cu);
+  const int flux_grid = opt.flux_grid_per_cu > 0 ? (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * opt.flux_grid_per_cu) : grid;
   auto face_args = [&](hfx_inters *f) {
     SplitFaceArgs a{};
     a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
@@ -588,9 +589,9 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       if (F->tensor_ok && !dict_only && lw)
       {
         if (oi)
-          LoaderWaveLaunch<ND, N, true, lw_fits>::go(grid, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, true, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
         else
-          LoaderWaveLaunch<ND, N, false, lw_fits>::go(grid, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, false, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
         launched = true;
       }
       if (launched)

@@ -73,6 +73,7 @@ struct hfx_ctx
   struct Options
   {
     int split_grid_per_cu = 16; // persistent workgroups per CU of the split element kernels
+    int flux_grid_per_cu = 0;   // the same for the loader-wave flux kernel alone (0: split_grid_per_cu)
     int xcd_order = 1;          // workgroups of one XCD walk one contiguous eighth of the elements
     int dictionary_rows = 0;    // 1: the dictionary-row flux kernel even when the operators are tensor products
     int flux_waves = 2;         // waves per SIMD the sum-factorised flux kernel is launched for (2 or 3)
