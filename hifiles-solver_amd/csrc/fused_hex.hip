@@ -38,7 +38,7 @@ void fused_destroy(hfx_eles *e)
 {
   if (!e || !e->fused) return;
   FusedData *f = e->fused;
-  void *p[] = {f->meta, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim};
+  void *p[] = {f->meta, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim, f->nbr};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete f;
@@ -466,6 +466,26 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
       HFX_CHECK(paired[o], "fused path: flux point %ld belongs to no registered face (partition faces need "
                            "hfx_stage_partitioned / hfx_run_steps_partitioned)", o);
   if (upload((void **)&F->meta, meta.data(), plane_f)) return 1;
+  {
+    // partner of every interior flux point for the flux kernel that forms the LDG corrections itself:
+    // (partner offset << 2) | beta-sign flipped << 1 | this point is the right side;  -1: boundary or partition-face point
+    std::vector<int> nbr(plane_f, -1);
+    bool fits = plane_f < (1L << 29);
+    for (int b = 0; b < nfb && fits; b++)
+    {
+      hfx_inters *f = faces[b];
+      if (f->is_bdy) continue;
+      const long np = (long)f->n_inters * f->n_fpts_per_inter;
+      for (long q = 0; q < np; q++)
+      {
+        const int il = f->hL[q], ir = f->hR[q];
+        nbr[il] = (ir << 2) | (meta[il] & 2);
+        nbr[ir] = (il << 2) | (meta[il] & 2) | 1;
+      }
+    }
+    if (F->nbr) { (void)hipFree(F->nbr); F->nbr = nullptr; }
+    if (fits && upload((void **)&F->nbr, nbr.data(), sizeof(int) * nbr.size())) return 1;
+  }
   if (!F->disu_alt) HFX_HIP(hipMalloc((void **)&F->disu_alt, sizeof(double) * plane_f * e->n_fields));
   F->built = true;
   return 0;
@@ -540,6 +560,26 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.adv_type = ea.adv_type; e2.in_step = ea.in_step; e2.dt_local_on = ea.dt_local_on; e2.write_div = ea.write_div;
     e2.need_u1 = ea.need_u1; e2.dt = ea.dt; e2.rk_a = ea.rk_a; e2.rk_b = ea.rk_b;
   }
+  // Will the flux kernel form the LDG corrections of the interior points itself?  (the loader-wave form of the sum-factorised
+  // kernel only: same conditions as its selection below)
+  bool gather = false;
+  if (variant == 3 && P.viscous && opt.gather_delta && F->nbr && F->tensor_ok && !opt.dictionary_rows && opt.loader_wave &&
+      opt.buffer_addressing && opt.flux_waves == 2 && loader_wave_fits<ND, N>())
+  {
+    bool any_bdy = false;
+    for (int b = 0; b < nfb; b++) any_bdy = any_bdy || faces[b]->is_bdy;
+    const double plane_most = (double)std::max<long>(plane_f, (long)e->n_upts * e->n_eles);
+    double most = plane_most * std::max(e->n_dims * e->n_dims, e->n_fields);
+    if (any_bdy) most = std::max(most, plane_most * e->n_fields * e->n_dims);
+    if (e->over_int_ready) most = std::max(most, (double)e->n_upts * e->n_eles * e->n_fields * e->n_dims);
+    gather = most * 8.0 < 4294967296.0;
+  }
+  F->gather_on = gather;
+  if (variant == 3)
+  {
+    e2.nbr = gather ? F->nbr : nullptr;
+    e2.disu = e->arr[HFX_DISU_FPTS];
+  }
   if (P.viscous && (which == 0 || which == 1))
   {
     for (int b = 0; b < nfb; b++)
@@ -550,6 +590,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
         if (hfx_bdy_launch_internal(faces[b], 0, 1)) return 1;
         continue;
       }
+      if (gather) continue; // (the flux kernel reads the partner's flux-point solution itself)
       const SplitFaceArgs a = face_args(faces[b]);
       if (a.npairs == 0) continue;
       hipLaunchKernelGGL((face_delta_kernel<ND>), dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
@@ -832,6 +873,13 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant)
     bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nd + nu * nf + nfp * nf + ntd);
     bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp); // disu, Fn, normal(left), tdA r; tconf w
     bytes[3] = ne * 8.0 * (3 * nu * nf + nu + nfp * nf + ntd + 2 * nu * nf + nfp * nf);          // u0,u1,div,detjac,tconf(,ntd) r; u0,u1,disu w
+    if (e->fused && e->fused->gather_on)
+    {
+      // the flux kernel reads the partners' flux-point solution (as many doubles as the corrections it no longer reads) and
+      // a partner word per point; the pairwise LDG kernel is not launched
+      bytes[0] = 0.0;
+      bytes[1] += ne * 4.0 * nfp;
+    }
   }
 }
 

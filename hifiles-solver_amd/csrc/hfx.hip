@@ -376,6 +376,7 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   else if (n == "flux_waves") { HFX_CHECK(value == 2 || value == 3, "flux_waves must be 2 or 3"); o.flux_waves = value; }
   else if (n == "buffer_addressing") o.buffer_addressing = value != 0;
   else if (n == "loader_wave") o.loader_wave = value != 0;
+  else if (n == "gather_delta") o.gather_delta = value != 0;
   else if (n == "comm_stream_faces") o.comm_stream_faces = value != 0;
   else if (n == "flux_stamps") o.flux_stamps = value;
   else if (n == "simd_roles") o.simd_roles = value != 0;

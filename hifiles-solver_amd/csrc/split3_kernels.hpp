@@ -47,6 +47,11 @@ struct Split2Args
   const double *tdisf_in;        // over-integration: the transformed inviscid flux, already evaluated (NULL: computed here)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
   int simd_roles;    // 1: the waves' parts are dealt by SIMD (split_flux_tensor_kernel)
+  // split_flux_tensor_kernel, loader-wave form: the LDG correction of a flux point is formed IN the kernel from the partner's
+  // flux-point solution (nbr: (partner offset << 2) | (beta sign flipped) << 1 | (this point is the right side); -1: a boundary
+  // or partition-face point, whose correction its one-sided kernel has left in `delta`).  NULL: `delta` holds all of them.
+  const int *nbr;
+  const double *disu;
   int stamp_it;      // which iteration of workgroup 0 is stamped
   long long *stamps; // diagnostics (tools/flux_phase_stamps.py): cycle counter of wave w of workgroup 0 at the phase boundaries
   // update kernel: opp_3 and opp_0 in ELL form (values, columns, width), rows held in registers
@@ -535,6 +540,8 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   const bool is_u = t < NU, is_f = t < NFP;
   const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
   const bool viscous = a.P.viscous;
+  const bool gather = LW && viscous && a.nbr != nullptr; // LDG corrections formed here from the partner's flux-point solution
+  const bool dma_delta = viscous && !gather;
 
   // flux-point role: the 1-D extrapolation rows of this point and its pencil
   const int dq = tidx[T::I_FDQ + tf], d_f = dq >> 1;
@@ -653,7 +660,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         const lds_dp base = (lds_dp)s_in + which * SLOT;
 #pragma unroll
         for (int k = 0; k < NF; k++) dma16_region(g_u0, base + k * NUS, L_U, lane, (unsigned)((long)NU * e + k * plane_u) * 8u);
-        if (viscous)
+        if (dma_delta)
         {
 #pragma unroll
           for (int k = 0; k < NF; k++)
@@ -695,11 +702,12 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         if (viscous) HFX_VMCNT(N_MV); else HFX_VMCNT(N_MI);
         lstamp(kk, 1);
         lds_barrier(); // 1: the compute waves may read the input slot
+        if (gather) lds_barrier(); // 1b: (the flux-point threads have written the LDG corrections)
         lstamp(kk, 2);
         if (e_next >= 0)
         {
           issue(e_next, (int)((kk + 1) & 1));
-          if (viscous) HFX_VMCNT(N_UDV); else HFX_VMCNT(N_UDI); // the metrics of this element have landed
+          if (dma_delta) HFX_VMCNT(N_UDV); else HFX_VMCNT(N_UDI); // the metrics of this element have landed
         }
         else
           HFX_VMCNT(0);
@@ -743,6 +751,24 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   auto stamp = [&](int slot) {
     if (a.stamps != nullptr && blockIdx.x == 0 && it_no == a.stamp_it && (t & 63) == 0) a.stamps[(t >> 6) * 16 + slot] = clock64();
   };
+  // gather: what this thread's flux point needs for its LDG correction -- the partner's flux-point solution, or at a
+  // boundary / partition-face point the correction its one-sided kernel left in `delta` -- is requested a whole element
+  // ahead into NF registers, the partner words another element ahead.  (Through the loader wave -- 4-byte LDS-DMA with
+  // per-lane offsets, or its registers -- the 25 scattered requests of an element took 6 000 - 8 000 cycles to ISSUE and
+  // held up the wave's other duties; spread over the 150 flux-point threads they cost 2 700.)
+  double pv[NF];
+  int nb_cur = -1, nb_next = -1;
+  auto request_partner = [&](long e_of, int nb) {
+    const double *src = (nb < 0) ? a.delta + ((long)NFP * e_of + tf) : a.disu + (nb >> 2);
+#pragma unroll
+    for (int k = 0; k < NF; k++) pv[k] = src[k * plane_f];
+  };
+  if (gather && order.at(0) >= 0)
+  {
+    nb_cur = a.nbr[(long)NFP * order.at(0) + tf];
+    request_partner(order.at(0), nb_cur);
+    if (order.at(1) >= 0) nb_next = a.nbr[(long)NFP * order.at(1) + tf];
+  }
   for (long kk = 0, e = order.at(0), e_next; e >= 0; kk++, e = e_next, it_no++)
   {
     e_next = order.at(kk + 1);
@@ -780,6 +806,40 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     lds_barrier();
     stamp(2);
     ef_cur = ef;
+    double u[NF], uf[NF];
+    if (gather)
+    {
+      // ---- A0: this flux point's solution (the extrapolation phase B needs anyway) and its LDG correction
+      // delta = u_common - u_own, u_common = (u_L + u_R)/2 - beta (u_L - u_R) on the pair's left / right orientation
+      // (src/inters.cpp:637) -> the slot's correction region, from where the pencils of phase A take it
+#pragma unroll
+      for (int k = 0; k < NF; k++) uf[k] = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; m++)
+      {
+        double x[NF];
+#pragma unroll
+        for (int k = 0; k < NF; k++) x[k] = ldsv(&su[k * NUS + am[m]]);
+#pragma unroll
+        for (int k = 0; k < NF; k++) uf[k] += Lrow[m] * x[k];
+      }
+      const int nb = nb_cur;
+      const double beta = (nb & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        const double ul = (nb & 1) ? pv[k] : uf[k], ur = (nb & 1) ? uf[k] : pv[k];
+        const double uc = 0.5 * (ul + ur) - beta * (ul - ur);
+        const double dl = (nb < 0) ? pv[k] : uc - uf[k];
+        if (is_f) sd[k * NFP + tf] = dl;
+      }
+      // the next element's partner values, and the words of the one after
+      nb_cur = nb_next;
+      if (e_next >= 0) request_partner(e_next, nb_cur);
+      const long e_nn = order.at(kk + 2);
+      if (e_nn >= 0) nb_next = a.nbr[(long)NFP * e_nn + tf];
+      lds_barrier(); // 1b
+    }
 #if HFX_FLUX_FMETRICS == 2
     fetch_fmetrics();
 #endif
@@ -865,13 +925,12 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       }
       }
     }
-    double u[NF], uf[NF];
     if (is_u || LW) // (LW: every lane, on clamped point numbers -- the paired physics of phase B)
     {
 #pragma unroll
       for (int k = 0; k < NF; k++) u[k] = ldsv(&su[k * NUS + tu]);
     }
-    if (viscous && (is_f || LW))
+    if (viscous && (is_f || LW) && !gather)
     {
       // pencil position outermost: NF independent accumulators per batch of LDS reads (one wait per batch
       // instead of one per field); each output still sums over ascending m

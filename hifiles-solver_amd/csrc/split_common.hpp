@@ -28,6 +28,8 @@ struct FusedData
   unsigned *pk_g = nullptr, *pk_r = nullptr; // packed operator rows of the gradient / residual kernel
   double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)
   int *o1m_dim = nullptr;                    // (n_fpts) dimension slab of the merged opp_1 row
+  int *nbr = nullptr;                        // (n_fpts, n_eles) partner of every interior flux point (split3_kernels.hpp, Split2Args::nbr)
+  bool gather_on = false;                    // the last stage formed the interior LDG corrections in the flux kernel (no face_delta launch)
   bool built = false;
 };
 

@@ -119,7 +119,8 @@ int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
 int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
 /* Measurement knobs: kernel variants with the same results (A/B runs; defaults are the product path).  name:
  * "split_grid_per_cu" (16), "xcd_order" (1), "dictionary_rows" (0), "flux_waves" (2 | 3), "buffer_addressing" (1),
- * "loader_wave" (1), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "comm_stream_faces" (1:
+ * "loader_wave" (1), "gather_delta" (1: the loader-wave flux kernel forms the interior LDG corrections itself, no pairwise
+ * LDG launch), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "comm_stream_faces" (1:
  * hfx_run_steps_partitioned launches the one-sided partition-face kernels on the communication stream), "flux_stamps" (0; n >= 1: cycle
  * stamps of iteration max(n, 2) of one workgroup of the flux kernels, printed by the hfx_time_* entry points), "tensor_ops" (1),
  * "general_waves" (0 = by LDS image | 3 | 4 | 8) -- see hfx_ctx::Options in csrc/hfx_internal.hpp;
@@ -312,7 +313,8 @@ int hfx_CalcResidual_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters 
  * rounding).  All leave disu_upts(0), disu_upts(1), disu_fpts of the new state and, for the step's last
  * stage, div_tconf_upts in the public arrays; mode 2 also leaves grad_disu_upts / grad_disu_fpts of the
  * last stage, mode 3 keeps them in registers and folds opp_3 . norm_tdisf_fpts into the divergence it stores, so
- * norm_tdisf_fpts is not refreshed either (run one per-method stage when a monitor needs them).
+ * norm_tdisf_fpts is not refreshed either; nor is delta_disu_fpts at interior points, whose LDG corrections the flux kernel
+ * forms itself from the partner's flux-point solution (run one per-method stage when a monitor needs them).
  * With dt_type 1 / 2 every step starts with calc_time_step (hfx_ctx_set_CFL, hfx_eles_set_h_ref); boundary
  * blocks whose groups ramp get run_input.ramp_counter advanced after every step (src/HiFiLES.cpp:224-225). */
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
