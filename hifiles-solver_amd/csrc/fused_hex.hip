@@ -843,6 +843,9 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
       fprintf(stderr, "flux kernel wave %d cycles: ", w);
       for (int q = 1; q <= 9; q++) fprintf(stderr, "%s%lld", q > 1 ? " " : "", h[w * 16 + q] - h[w * 16 + q - 1]);
       fprintf(stderr, "   (fill | bar1 | A | bar2 | B | bar3 | C | bar4 | D)  total %lld;  C: reads landed after %lld\n", h[w * 16 + 9] - h[w * 16], h[w * 16 + 10] - h[w * 16 + 6]);
+      if (h[w * 16 + 11])
+        fprintf(stderr, "   A0 cycles: corrections written after %lld, next requests issued %lld, barrier 1b %lld\n", h[w * 16 + 11] - h[w * 16 + 2],
+                h[w * 16 + 12] - h[w * 16 + 11], h[w * 16 + 13] - h[w * 16 + 12]);
     }
     fprintf(stderr, "loader wave cycles: ");
     for (int q = 1; q <= 7; q++) fprintf(stderr, "%s%lld", q > 1 ? " " : "", h[3 * 16 + q] - h[3 * 16 + q - 1]);

@@ -757,7 +757,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   // per-lane offsets, or its registers -- the 25 scattered requests of an element took 6 000 - 8 000 cycles to ISSUE and
   // held up the wave's other duties; spread over the 150 flux-point threads they cost 2 700.)
   double pv[NF];
-  int nb_cur = -1, nb_next = -1;
+  int nb_cur = -1, nb_next = -1, nb_nn = -1;
   auto request_partner = [&](long e_of, int nb) {
     const double *src = (nb < 0) ? a.delta + ((long)NFP * e_of + tf) : a.disu + (nb >> 2);
 #pragma unroll
@@ -833,12 +833,16 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         const double dl = (nb < 0) ? pv[k] : uc - uf[k];
         if (is_f) sd[k * NFP + tf] = dl;
       }
-      // the next element's partner values, and the words of the one after
-      nb_cur = nb_next;
-      if (e_next >= 0) request_partner(e_next, nb_cur);
+      stamp(11);
+      // the next element's partner values, and the word of the one after (unconditional, into a register of its own: the
+      // rotation nb_cur <- nb_next <- nb_nn happens at the END of the iteration -- placed here the compiler waited for the
+      // word, and with it for the five values just requested, right behind the barrier)
+      if (e_next >= 0) request_partner(e_next, nb_next);
       const long e_nn = order.at(kk + 2);
-      if (e_nn >= 0) nb_next = a.nbr[(long)NFP * e_nn + tf];
+      nb_nn = a.nbr[(long)NFP * (e_nn >= 0 ? e_nn : e) + tf];
+      stamp(12);
       lds_barrier(); // 1b
+      stamp(13);
     }
 #if HFX_FLUX_FMETRICS == 2
     fetch_fmetrics();
@@ -1276,6 +1280,12 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       }
     }
     stamp(9);
+    if (gather)
+    {
+      asm volatile("" : "+v"(nb_nn)); // (the word is needed here, not earlier)
+      nb_cur = nb_next;
+      nb_next = nb_nn;
+    }
     // no barrier: the next iteration's writes to sA (dead since the last barrier) do not touch sB, and
     // its writes to sB come after its first barrier
   }
