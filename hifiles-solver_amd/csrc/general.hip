@@ -49,6 +49,7 @@ struct GeneralData
   unsigned char *meta = nullptr; // (n_fpts, n_eles): bit1 beta sign flipped (LEFT point of a pair), bit2 boundary point
   double *disu_alt = nullptr;    // second disu_fpts buffer (the update kernel writes the new state's flux-point solution)
   double *fn_fpts = nullptr;     // (n_fpts, n_eles, n_fields) viscous flux projected on the point's own normal
+  int *nbr = nullptr;            // (n_fpts, n_eles) partner word of every flux point whose pair lies inside this block (GenArgs::nbr)
   bool any_bdy = false;
   bool built = false;
   long long *stamps = nullptr;
@@ -64,7 +65,7 @@ void general_destroy(hfx_eles *e)
   if (!e || !e->general) return;
   GeneralData *g = (GeneralData *)e->general;
   void *p[] = {g->o0, g->o1[0], g->o1[1], g->o1[2], g->o2[0], g->o2[1], g->o2[2], g->o3, g->o4[0], g->o4[1], g->o4[2],
-               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts, g->stamps};
+               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts, g->stamps, g->nbr};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete g;
@@ -94,6 +95,10 @@ struct GenArgs
   unsigned inv_nu, inv_nfp; // floor(2^32 / n) + 1: q / n == __umulhi(q, inv) for the q < 2^16 of the staging loops
   const double *o0, *o1[3], *o2[3], *o3, *o4[3], *o5[3], *o6;
   const double *u0, *delta, *disu;
+  // the LDG correction of a flux point whose partner lies in the SAME element block is formed in the flux kernel from the
+  // partner's flux-point solution: (partner offset << 2) | beta sign flipped << 1 | this point is the right side; -1: a boundary
+  // point or a point whose partner belongs to another block (its correction is in `delta`).  NULL: `delta` holds all of them.
+  const int *nbr;
   const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts, *norm_fpts;
   const unsigned char *meta;
   double *div, *ntd, *fn, *grad_fpts; // grad_fpts: boundary points only (NULL: no boundary faces / inviscid)
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
           const int el = (int)__umulhi((unsigned)q, inv_nu);
           ru[f][i] = (q < nu * GB && el < nval) ? src[q] : 0.0;
         }
-        if (visc)
+        if (visc && a.nbr == nullptr)
         {
           const double *sd = a.delta + e0 * nfp + f * plane_f;
 #pragma unroll
@@ -232,6 +237,47 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
             const int q = tid + T * i;
             const int el = (int)__umulhi((unsigned)q, inv_nfp);
             rd[f][i] = (q < nfp * GB && el < nval) ? sd[q] : 0.0;
+          }
+        }
+      }
+      if (visc && a.nbr != nullptr)
+      {
+        // LDG corrections formed here (the pairwise kernel is not launched for pairs inside this block): the point's partner
+        // word, then its own and its partner's flux-point solution -- or the correction itself where the word is -1 --
+        // delta = u_common - u_own, u_common = (u_L + u_R)/2 - beta (u_L - u_R) on the pair's orientation (src/inters.cpp:637)
+        int w[MAXQ_D];
+        bool okq[MAXQ_D];
+#pragma unroll
+        for (int i = 0; i < MAXQ_D; i++)
+        {
+          const int q = tid + T * i;
+          const int el = (int)__umulhi((unsigned)q, inv_nfp);
+          okq[i] = q < nfp * GB && el < nval;
+          w[i] = okq[i] ? a.nbr[e0 * nfp + q] : -1;
+        }
+        double ro[NF][MAXQ_D];
+#pragma unroll
+        for (int i = 0; i < MAXQ_D; i++)
+        {
+          const long own = e0 * nfp + (okq[i] ? tid + T * i : 0);
+          const double *po = a.disu + own, *pp = (w[i] < 0) ? a.delta + own : a.disu + (w[i] >> 2);
+#pragma unroll
+          for (int f = 0; f < NF; f++)
+          {
+            ro[f][i] = po[f * plane_f];
+            rd[f][i] = pp[f * plane_f];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXQ_D; i++)
+        {
+          const double beta = (w[i] & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+#pragma unroll
+          for (int f = 0; f < NF; f++)
+          {
+            const double ul = (w[i] & 1) ? rd[f][i] : ro[f][i], ur = (w[i] & 1) ? ro[f][i] : rd[f][i];
+            const double uc = 0.5 * (ul + ur) - beta * (ul - ur);
+            rd[f][i] = !okq[i] ? 0.0 : ((w[i] < 0) ? rd[f][i] : uc - ro[f][i]);
           }
         }
       }
@@ -888,6 +934,29 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
       for (long q = 0; q < np; q++) owned[f->hR[q]] = 1;
   }
   for (long o = 0; o < plane_f; o++) HFX_CHECK(owned[o], "general fused stage: flux point %ld belongs to no registered face", o);
+  {
+    std::vector<int> nbr(plane_f, -1);
+    bool fits = plane_f < (1L << 29), any = false;
+    for (int b = 0; b < nfb && fits; b++)
+    {
+      hfx_inters *f = faces[b];
+      if (f->is_bdy || f->left != e || f->right != e) continue;
+      const long np = (long)f->n_inters * f->n_fpts_per_inter;
+      for (long q = 0; q < np; q++)
+      {
+        const int il = f->hL[q], ir = f->hR[q];
+        nbr[il] = (ir << 2) | (meta[il] & 2);
+        nbr[ir] = (il << 2) | (meta[il] & 2) | 1;
+        any = true;
+      }
+    }
+    if (g->nbr) { (void)hipFree(g->nbr); g->nbr = nullptr; }
+    if (fits && any)
+    {
+      HFX_HIP(hipMalloc((void **)&g->nbr, sizeof(int) * (size_t)plane_f));
+      HFX_HIP(hipMemcpy(g->nbr, nbr.data(), sizeof(int) * (size_t)plane_f, hipMemcpyHostToDevice));
+    }
+  }
   if (g->meta) (void)hipFree(g->meta);
   HFX_HIP(hipMalloc((void **)&g->meta, (size_t)plane_f));
   HFX_HIP(hipMemcpy(g->meta, meta.data(), (size_t)plane_f, hipMemcpyHostToDevice));
@@ -895,6 +964,22 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
   if (!g->fn_fpts) HFX_HIP(hipMalloc((void **)&g->fn_fpts, sizeof(double) * plane_f * e->n_fields));
   g->built = true;
   return 0;
+}
+
+// does the flux kernel of this block stage its inputs with all loads requested up front (the form that can also form the
+// LDG corrections itself)?  -- an instantiated element size whose staging registers fit (general_flux_kernel, P0)
+static bool general_batched(const hfx_eles *e)
+{
+  const GeneralData *g = (const GeneralData *)e->general;
+  if (!g) return false;
+  static const int sizes[][2] = {{4, 12}, {10, 24}, {20, 40}, {6, 18}, {18, 39}, {40, 68}};
+  bool known = false;
+  for (const auto &sz : sizes) known = known || (e->n_upts == sz[0] && e->n_fpts == sz[1]);
+  if (!known) return false;
+  int w = e->ctx->opt.general_waves;
+  if (w == 0) w = flux_lds_bytes(g) <= 80 * 1024 ? 4 : 8;
+  const int T = 64 * w, mq_u = (g->KU * GB + T - 1) / T, mq_d = (g->KF * GB + T - 1) / T;
+  return (mq_u + mq_d) * 5 <= 30;
 }
 
 static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
@@ -909,6 +994,7 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
   a.u0 = e->arr[HFX_DISU_UPTS0]; a.delta = e->arr[HFX_DELTA_DISU_FPTS]; a.disu = e->arr[HFX_DISU_FPTS];
   a.detjac_upts = e->detjac_upts; a.JGinv_upts = e->JGinv_upts; a.detjac_fpts = e->detjac_fpts; a.JGinv_fpts = e->JGinv_fpts;
   a.norm_fpts = e->norm_fpts; a.meta = g->meta;
+  a.nbr = (e->ctx->opt.gather_delta && p.viscous && general_batched(e)) ? g->nbr : nullptr;
   a.div = e->arr[HFX_DIV_TCONF_UPTS]; a.ntd = e->arr[HFX_NORM_TDISF_FPTS]; a.fn = g->fn_fpts;
   a.grad_fpts = (g->any_bdy && p.viscous) ? e->arr[HFX_GRAD_DISU_FPTS] : nullptr;
   a.P = e->ctx->phys();
@@ -1007,6 +1093,9 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
         if (hfx_bdy_launch_internal(faces[b], 0, 1)) return 1; // ghost state -> inviscid common flux, LDG common solution
         continue;
       }
+      if (faces[b]->left == faces[b]->right && ctx->opt.gather_delta && faces[b]->left->general &&
+          ((GeneralData *)faces[b]->left->general)->nbr && general_batched(faces[b]->left))
+        continue; // (the flux kernel of that block forms these corrections itself)
       const GFaceArgs a = gface_args(faces[b]);
       if (a.npairs == 0) continue;
       hipLaunchKernelGGL(gface_delta_kernel, dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
