@@ -50,6 +50,7 @@ struct GeneralData
   double *disu_alt = nullptr;    // second disu_fpts buffer (the update kernel writes the new state's flux-point solution)
   double *fn_fpts = nullptr;     // (n_fpts, n_eles, n_fields) viscous flux projected on the point's own normal
   int *nbr = nullptr;            // (n_fpts, n_eles) partner word of every flux point whose pair lies inside this block (GenArgs::nbr)
+  double *o2f[3] = {};           // opp_2[d] - opp_3 opp_1[d], padded like o2: the folded correction (GenArgs::fold)
   bool any_bdy = false;
   bool built = false;
   long long *stamps = nullptr;
@@ -65,7 +66,7 @@ void general_destroy(hfx_eles *e)
   if (!e || !e->general) return;
   GeneralData *g = (GeneralData *)e->general;
   void *p[] = {g->o0, g->o1[0], g->o1[1], g->o1[2], g->o2[0], g->o2[1], g->o2[2], g->o3, g->o4[0], g->o4[1], g->o4[2],
-               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts, g->stamps, g->nbr};
+               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts, g->stamps, g->nbr, g->o2f[0], g->o2f[1], g->o2f[2]};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete g;
@@ -95,6 +96,9 @@ struct GenArgs
   unsigned inv_nu, inv_nfp; // floor(2^32 / n) + 1: q / n == __umulhi(q, inv) for the q < 2^16 of the staging loops
   const double *o0, *o1[3], *o2[3], *o3, *o4[3], *o5[3], *o6;
   const double *u0, *delta, *disu;
+  // fold != 0: o2[d] holds opp_2[d] - opp_3 opp_1[d], so that P4 leaves div_tdisf - opp_3 norm_tdisf in `div` and norm_tdisf is
+  // neither formed nor stored; the update kernel then adds opp_3 norm_tconf alone (as split3's folded correction)
+  int fold;
   // the LDG correction of a flux point whose partner lies in the SAME element block is formed in the flux kernel from the
   // partner's flux-point solution: (partner offset << 2) | beta sign flipped << 1 | this point is the right side; -1: a boundary
   // point or a point whose partner belongs to another block (its correction is in `delta`).  NULL: `delta` holds all of them.
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
             if (el < nval) out[row + (long)n * (e0 + el) + (f0 + f) * plane] = acc[f][rg];
           }
     };
-    split_rounds<W>(n_ut + n_ft, wave, p4_item);
+    split_rounds<W>(a.fold ? n_ut : n_ut + n_ft, wave, p4_item); // (folded: the divergence tiles only)
   }
   stamp(9);
 }
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
         const int el = (int)__umulhi((unsigned)q, inv_nfp);
         const bool ok = q < nfp * GB && el < nval;
         rt_[f][i] = ok ? tc[q] : 0.0;
-        rn_[f][i] = ok ? nt[q] : 0.0;
+        rn_[f][i] = (ok && !a.fold) ? nt[q] : 0.0;
       }
     }
 #pragma unroll
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(64 * W) void general_update_kernel(const GenArgs a)
     {
       const int el = (int)__umulhi((unsigned)q, inv_nfp), k = q - el * nfp;
       if (q < nfp * GB)
-        X[f * KF * GB + sw(k, el)] = (el < nval) ? tc[q] + -1.0 * nt[q] : 0.0; // the daxpy of src/eles.cpp:1746
+        X[f * KF * GB + sw(k, el)] = (el < nval) ? (a.fold ? tc[q] : tc[q] + -1.0 * nt[q]) : 0.0; // the daxpy of src/eles.cpp:1746
       else
       {
         const int p = q - nfp * GB;
@@ -896,6 +900,28 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
   if (padded_operator(&g->o0, e->opp_0, g->MF, g->KU) || padded_operator(&g->o3, e->opp_3, g->MU, g->KF)) return 1;
   for (int d = 0; d < 3; d++)
     if (padded_operator(&g->o1[d], e->opp_1[d], g->MF, g->KU) || padded_operator(&g->o2[d], e->opp_2[d], g->MU, g->KU)) return 1;
+  {
+    // the folded operators: O2f[d] = opp_2[d] - opp_3 . opp_1[d] (sum over the flux points in ascending order)
+    std::vector<double> o3((size_t)nu * nfp), o1((size_t)nfp * nu), o2((size_t)nu * nu), pad((size_t)g->MU * g->KU);
+    HFX_HIP(hipMemcpy(o3.data(), e->opp_3.dense, sizeof(double) * o3.size(), hipMemcpyDeviceToHost));
+    for (int d = 0; d < 3; d++)
+    {
+      HFX_HIP(hipMemcpy(o1.data(), e->opp_1[d].dense, sizeof(double) * o1.size(), hipMemcpyDeviceToHost));
+      HFX_HIP(hipMemcpy(o2.data(), e->opp_2[d].dense, sizeof(double) * o2.size(), hipMemcpyDeviceToHost));
+      std::fill(pad.begin(), pad.end(), 0.0);
+      for (int c = 0; c < nu; c++)
+        for (int r = 0; r < nu; r++)
+        {
+          double t = 0.0;
+          for (int j = 0; j < nfp; j++) t += o3[r + (size_t)nu * j] * o1[j + (size_t)nfp * c];
+          pad[r + (size_t)g->MU * c] = o2[r + (size_t)nu * c] - t;
+        }
+      if (g->o2f[d]) (void)hipFree(g->o2f[d]);
+      g->o2f[d] = nullptr;
+      HFX_HIP(hipMalloc((void **)&g->o2f[d], sizeof(double) * pad.size()));
+      HFX_HIP(hipMemcpy(g->o2f[d], pad.data(), sizeof(double) * pad.size(), hipMemcpyHostToDevice));
+    }
+  }
   if (visc)
   {
     if (padded_operator(&g->o6, e->opp_6, g->MF, g->KU)) return 1;
@@ -990,7 +1016,8 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
   a.inv_nu = (unsigned)(4294967296ull / (unsigned)e->n_upts) + 1u; a.inv_nfp = (unsigned)(4294967296ull / (unsigned)e->n_fpts) + 1u;
   a.n_eles = e->n_eles; a.nu = e->n_upts; a.nfp = e->n_fpts; a.KU = g->KU; a.KF = g->KF; a.MU = g->MU; a.MF = g->MF;
   a.o0 = g->o0; a.o3 = g->o3; a.o6 = g->o6;
-  for (int d = 0; d < 3; d++) { a.o1[d] = g->o1[d]; a.o2[d] = g->o2[d]; a.o4[d] = g->o4[d]; a.o5[d] = g->o5[d]; }
+  a.fold = e->ctx->opt.fold_general ? 1 : 0;
+  for (int d = 0; d < 3; d++) { a.o1[d] = g->o1[d]; a.o2[d] = a.fold ? g->o2f[d] : g->o2[d]; a.o4[d] = g->o4[d]; a.o5[d] = g->o5[d]; }
   a.u0 = e->arr[HFX_DISU_UPTS0]; a.delta = e->arr[HFX_DELTA_DISU_FPTS]; a.disu = e->arr[HFX_DISU_FPTS];
   a.detjac_upts = e->detjac_upts; a.JGinv_upts = e->JGinv_upts; a.detjac_fpts = e->detjac_fpts; a.JGinv_fpts = e->JGinv_fpts;
   a.norm_fpts = e->norm_fpts; a.meta = g->meta;
@@ -1258,6 +1285,20 @@ void general_kernel_bytes(hfx_eles *const *eles, int neb, double *bytes)
                             + nu * nf + 2 * nfp * nf);                                                       // div, norm_tdisf, Fn w
     bytes[2] += ne * (8.0 * (nfp * nf + nfp * nf + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp);            // disu, Fn, normal(left), tdA r; tconf w
     bytes[3] += ne * 8.0 * (3 * nu * nf + nu + 2 * nfp * nf + 3 * nu * nf + nfp * nf);                       // u0,u1,div,detjac,tconf,ntd r; u0,u1,div,disu w
+    if (e->ctx->opt.fold_general)
+    {
+      // folded correction: norm_tdisf is neither written (flux kernel) nor read (update kernel)
+      bytes[1] -= ne * 8.0 * nfp * nf;
+      bytes[3] -= ne * 8.0 * nfp * nf;
+    }
+    const GeneralData *g = (const GeneralData *)e->general;
+    if (g && g->nbr && e->ctx->opt.gather_delta && e->ctx->params.viscous && general_batched(e))
+    {
+      // LDG corrections formed in the flux kernel: the pairwise kernel is not launched for the pairs inside the block (the
+      // partner values it reads are as many doubles as the corrections it no longer reads) + a partner word per point
+      bytes[0] -= ne * (8.0 * (2 * nfp * nf) + 4.0 * nfp + nfp * 0.5);
+      bytes[1] += ne * 4.0 * nfp;
+    }
   }
 }
 
