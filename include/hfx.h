@@ -119,7 +119,7 @@ int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
 int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
 /* Measurement knobs: kernel variants with the same results (A/B runs; defaults are the product path).  name:
  * "split_grid_per_cu" (16), "xcd_order" (1), "dictionary_rows" (0), "flux_waves" (2 | 3), "buffer_addressing" (1),
- * "loader_wave" (1), "gather_delta" (1: the loader-wave flux kernel forms the interior LDG corrections itself, no pairwise
+ * "loader_wave" (1), "fold_general" (1: the general fused stage applies opp_2 - opp_3 opp_1 and never forms norm_tdisf), "gather_delta" (1: the loader-wave flux kernel forms the interior LDG corrections itself, no pairwise
  * LDG launch), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "comm_stream_faces" (1:
  * hfx_run_steps_partitioned launches the one-sided partition-face kernels on the communication stream), "flux_stamps" (0; n >= 1: cycle
  * stamps of iteration max(n, 2) of one workgroup of the flux kernels, printed by the hfx_time_* entry points), "tensor_ops" (1),
@@ -322,7 +322,8 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int 
  * general (non-tensor-product) element classes, three-dimensional Navier-Stokes / Euler blocks with interior and
  * boundary faces (csrc/general.hip): four launches per element block and stage, the dense operator contractions on the
  * FP64 matrix cores over batches of 16 elements; like fused 3 it keeps the corrected gradients on chip (only boundary
- * points get grad_disu_fpts) and leaves disu_upts(0), disu_upts(1), disu_fpts of the new state and div_tconf_upts.
+ * points get grad_disu_fpts) and leaves disu_upts(0), disu_upts(1), disu_fpts of the new state and div_tconf_upts;
+ * norm_tdisf_fpts (folded into the divergence operator) and delta_disu_fpts of pairs inside a block are not refreshed.
  * A block with one element class may of course be passed alone (hfx_run_steps(e, ..., 4) is the same call). */
 int hfx_run_steps_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *faces, int n_face_blocks, int n_steps,
                          int fused);
