@@ -6,7 +6,8 @@
 // (/root/reference/src/solver.cpp:50-223, src/HiFiLES.cpp:201-217).  Executed call by
 // call they stream ~64 000 doubles per P4 hex through HBM.  Here the stage is cut at the two
 // places where data must cross elements (the LDG common solution, the common fluxes) and everything element-local
-// between two cuts is one kernel: four launches per stage.  Two variants:
+// between two cuts is one kernel: four launches per stage, three when the flux kernel forms the LDG corrections itself
+// (DESIGN.md 3.2).  Two variants:
 //   fused = 2: keeps the reference's arrays (grad_disu_upts / grad_disu_fpts in HBM); carries the LES closure
 //   fused = 3: the kernel that has the corrected gradient in registers goes straight on to the fluxes; the default
 // plus the same stage cut into five phases for a partitioned block (hfx_stage_partitioned).

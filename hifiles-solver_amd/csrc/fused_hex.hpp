@@ -7,7 +7,7 @@ namespace hfx
 // drop any fused-path tables derived from the block's face registration
 void fused_invalidate(hfx_eles *e);
 void fused_destroy(hfx_eles *e);
-// the split fused stage (variants 2 and 3): pairwise face kernels + per-element kernels, four launches per stage;
+// the split fused stage (variants 2 and 3): pairwise face kernels + per-element kernels, three or four launches per stage;
 // n_steps time steps, fails loudly when the block does not qualify
 int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int variant = 2);
 // average duration (ms, HIP events on the context stream) of each kernel of the stage over `reps` stages

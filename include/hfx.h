@@ -110,7 +110,7 @@ int hfx_ctx_create(int device, hfx_ctx **out);
 int hfx_ctx_destroy(hfx_ctx *ctx);
 int hfx_ctx_set_params(hfx_ctx *ctx, const hfx_params *p);
 int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode);
-/* which variant of the split fused stage (pairwise face kernels + element kernels, four launches per stage) the
+/* which variant of the split fused stage (pairwise face kernels + element kernels, three or four launches per stage) the
  * measurement entry points describe and hfx_stage_partitioned / hfx_run_steps_partitioned run: 2 keeps the reference's
  * gradient arrays in HBM, 3 (default) evaluates the fluxes in the gradient kernel */
 int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
@@ -320,7 +320,7 @@ int hfx_CalcResidual_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters 
 int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int n_steps, int fused);
 /* The RK loop over several element blocks (mixed meshes).  fused 0: the per-method path; fused 4: the fused stage for
  * general (non-tensor-product) element classes, three-dimensional Navier-Stokes / Euler blocks with interior and
- * boundary faces (csrc/general.hip): four launches per element block and stage, the dense operator contractions on the
+ * boundary faces (csrc/general.hip): three or four launches per element block and stage, the dense operator contractions on the
  * FP64 matrix cores over batches of 16 elements; like fused 3 it keeps the corrected gradients on chip (only boundary
  * points get grad_disu_fpts) and leaves disu_upts(0), disu_upts(1), disu_fpts of the new state and div_tconf_upts;
  * norm_tdisf_fpts (folded into the divergence operator) and delta_disu_fpts of pairs inside a block are not refreshed.
