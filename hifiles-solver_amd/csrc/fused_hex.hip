@@ -493,17 +493,17 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
 }
 
 // launch of the loader-wave form, instantiated only for element sizes it fits (loader_wave_fits)
-template <int ND, int N, bool OI, bool FITS>
+template <int ND, int N, bool OI, bool GA, bool FITS>
 struct LoaderWaveLaunch
 {
   static void go(int, hipStream_t, const Split2Args &, const double *, const int *) {}
 };
-template <int ND, int N, bool OI>
-struct LoaderWaveLaunch<ND, N, OI, true>
+template <int ND, int N, bool OI, bool GA>
+struct LoaderWaveLaunch<ND, N, OI, GA, true>
 {
   static void go(int grid, hipStream_t st, const Split2Args &e2, const double *coef, const int *idx)
   {
-    hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true>), dim3(grid), dim3(SGeo<ND, N>::TB + 64), 0, st, e2, coef, idx);
+    hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA>), dim3(grid), dim3(SGeo<ND, N>::TB + 64), 0, st, e2, coef, idx);
   }
 };
 
@@ -630,10 +630,15 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       bool launched = false;
       if (F->tensor_ok && !dict_only && lw)
       {
-        if (oi)
-          LoaderWaveLaunch<ND, N, true, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+        const bool ga = e2.nbr != nullptr && P.viscous; // (the corrections formed in the kernel)
+        if (oi && ga)
+          LoaderWaveLaunch<ND, N, true, true, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+        else if (oi)
+          LoaderWaveLaunch<ND, N, true, false, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+        else if (ga)
+          LoaderWaveLaunch<ND, N, false, true, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
         else
-          LoaderWaveLaunch<ND, N, false, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, false, false, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
         launched = true;
       }
       if (launched)

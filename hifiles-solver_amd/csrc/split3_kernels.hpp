@@ -438,7 +438,7 @@ constexpr bool loader_wave_fits()
 // an LDS slot by buffer_load ... lds -- no registers, requested a whole element ahead and counted on the loader's own
 // vmcnt, so the compute waves never wait for them (the register prefetch of the LW = false form is issued in phase C
 // and still needs ~2 500 cycles at the top of the next iteration: the kernel is bound by bytes in flight per CU).
-template <int ND, int N, int WV, bool BUF, bool OI, bool LW>
+template <int ND, int N, int WV, bool BUF, bool OI, bool LW, bool GA = false>
 __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_flux_tensor_kernel(const Split2Args a,
                                                                                                const double *coef_g,
                                                                                                const int *tidx)
@@ -540,7 +540,9 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   const bool is_u = t < NU, is_f = t < NFP;
   const long ne = a.n_eles, plane_u = (long)NU * ne, plane_f = (long)NFP * ne;
   const bool viscous = a.P.viscous;
-  const bool gather = LW && viscous && a.nbr != nullptr; // LDG corrections formed here from the partner's flux-point solution
+  // GA: the LDG corrections are formed here from the partner's flux-point solution (a.nbr; viscous runs of the loader-wave form)
+  constexpr bool gather = GA;
+  static_assert(!GA || LW, "the in-kernel LDG corrections belong to the loader-wave form");
   const bool dma_delta = viscous && !gather;
 
   // flux-point role: the 1-D extrapolation rows of this point and its pencil
@@ -807,6 +809,33 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     stamp(2);
     ef_cur = ef;
     double u[NF], uf[NF];
+    double accg[GA ? ROUNDS : 1][N]; // GA: the pencils' D . u, formed in A0 while the partner values are waited for
+    if constexpr (GA)
+    {
+      // first the part of phase A that needs no correction -- the 1-D derivative of the pencils' state: the wait for the
+      // partner values below also drains this wave's last result stores, and this work fills it
+      double xa[ROUNDS][N], Dm[NN2];
+      table(S_D, Dm);
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++)
+      {
+        const int d = it_dq[r];
+        const int srr = (d == 0) ? 1 : (d == 1 ? N : N * N);
+        const double *su_p = su + (it_o[r] - NF * d * NU) + it_k[r] * (NUS - NU);
+#pragma unroll
+        for (int m = 0; m < N; m++) xa[r][m] = ldsv(su_p + m * srr);
+      }
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++)
+      {
+#pragma unroll
+        for (int mp = 0; mp < N; mp++) accg[r][mp] = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; m++)
+#pragma unroll
+          for (int mp = 0; mp < N; mp++) accg[r][mp] += Dm[mp * N + m] * xa[r][m];
+      }
+    }
     if (gather)
     {
       // ---- A0: this flux point's solution (the extrapolation phase B needs anyway) and its LDG correction
@@ -868,15 +897,18 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         const int d = it_dq[r];
         sr[r] = (d == 0) ? 1 : (d == 1 ? N : N * N);
         const double *su_p = su + (it_o[r] - NF * d * NU) + it_k[r] * (NUS - NU);
+        if constexpr (!GA)
+        {
 #pragma unroll
-        for (int m = 0; m < N; m++) xa[r][m] = ldsv(su_p + m * sr[r]);
+          for (int m = 0; m < N; m++) xa[r][m] = ldsv(su_p + m * sr[r]);
+        }
         da[r] = ldsv(sd + it_fa[r]);
         db[r] = ldsv(sd + it_fb[r]);
       }
       if constexpr (LW)
       {
-        double Dm[NN2], c5a[ROUNDS][NP], c5b[ROUNDS][NP];
-        table(S_D, Dm);
+        double Dm[GA ? 2 : NN2], c5a[ROUNDS][NP], c5b[ROUNDS][NP];
+        if constexpr (!GA) table(S_D, Dm);
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++)
         {
@@ -889,12 +921,20 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++)
         {
+          if constexpr (GA)
+          {
 #pragma unroll
-          for (int mp = 0; mp < N; mp++) acc[r][mp] = 0.0;
+            for (int mp = 0; mp < N; mp++) acc[r][mp] = accg[r][mp];
+          }
+          else
+          {
 #pragma unroll
-          for (int m = 0; m < N; m++)
+            for (int mp = 0; mp < N; mp++) acc[r][mp] = 0.0;
 #pragma unroll
-            for (int mp = 0; mp < N; mp++) acc[r][mp] += Dm[mp * N + m] * xa[r][m];
+            for (int m = 0; m < N; m++)
+#pragma unroll
+              for (int mp = 0; mp < N; mp++) acc[r][mp] += Dm[mp * N + m] * xa[r][m];
+          }
 #pragma unroll
           for (int mp = 0; mp < N; mp++) acc[r][mp] += c5a[r][mp] * da[r];
 #pragma unroll
