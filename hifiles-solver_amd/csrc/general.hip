@@ -51,6 +51,8 @@ struct GeneralData
   double *fn_fpts = nullptr;     // (n_fpts, n_eles, n_fields) viscous flux projected on the point's own normal
   int *nbr = nullptr;            // (n_fpts, n_eles) partner word of every flux point whose pair lies inside this block (GenArgs::nbr)
   double *o2f[3] = {};           // opp_2[d] - opp_3 opp_1[d], padded like o2: the folded correction (GenArgs::fold)
+  hfx_eles *blocks[4] = {};      // the element blocks the partner words refer to (bits 3:2 of a word), captured at build
+  int n_blocks = 0;
   bool any_bdy = false;
   bool built = false;
   long long *stamps = nullptr;
@@ -100,9 +102,11 @@ struct GenArgs
   // neither formed nor stored; the update kernel then adds opp_3 norm_tconf alone (as split3's folded correction)
   int fold;
   // the LDG correction of a flux point whose partner lies in the SAME element block is formed in the flux kernel from the
-  // partner's flux-point solution: (partner offset << 2) | beta sign flipped << 1 | this point is the right side; -1: a boundary
-  // point or a point whose partner belongs to another block (its correction is in `delta`).  NULL: `delta` holds all of them.
+  // partner's flux-point solution: (partner offset << 4) | partner's block << 2 | beta sign flipped << 1 | this point is the right
+  // side; -1: a boundary point (its correction is in `delta`).  NULL: `delta` holds all of them.
   const int *nbr;
+  const double *disu_b[4]; // flux-point solution of the blocks a partner word may name (its bits 3:2), and their plane strides
+  long plane_b[4];
   const double *detjac_upts, *JGinv_upts, *detjac_fpts, *JGinv_fpts, *norm_fpts;
   const unsigned char *meta;
   double *div, *ntd, *fn, *grad_fpts; // grad_fpts: boundary points only (NULL: no boundary faces / inviscid)
@@ -264,12 +268,14 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
         for (int i = 0; i < MAXQ_D; i++)
         {
           const long own = e0 * nfp + (okq[i] ? tid + T * i : 0);
-          const double *po = a.disu + own, *pp = (w[i] < 0) ? a.delta + own : a.disu + (w[i] >> 2);
+          const int blk = (w[i] >> 2) & 3;
+          const double *po = a.disu + own, *pp = (w[i] < 0) ? a.delta + own : a.disu_b[blk] + (w[i] >> 4);
+          const long pstr = (w[i] < 0) ? plane_f : a.plane_b[blk];
 #pragma unroll
           for (int f = 0; f < NF; f++)
           {
             ro[f][i] = po[f * plane_f];
-            rd[f][i] = pp[f * plane_f];
+            rd[f][i] = pp[f * pstr];
           }
         }
 #pragma unroll
@@ -886,7 +892,7 @@ static int padded_operator(double **dst, const Operator &op, int M, int K)
 static size_t flux_lds_bytes(const GeneralData *g) { return sizeof(double) * GB * (5 * g->KU + 5 * g->KF + 15 * g->KU); }
 static size_t update_lds_bytes(const GeneralData *g) { return sizeof(double) * GB * (5 * g->KF + 5 * g->KU); }
 
-static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
+static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_eles *const *eles, int neb)
 {
   HFX_CHECK(e->n_dims == 3 && e->n_fields == 5, "general fused stage: three-dimensional Navier-Stokes / Euler blocks only");
   HFX_CHECK(!e->les_ready && !e->over_int_ready && !e->shock_ready, "general fused stage: LES, over-integration and shock capturing run per method");
@@ -961,26 +967,51 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb)
   }
   for (long o = 0; o < plane_f; o++) HFX_CHECK(owned[o], "general fused stage: flux point %ld belongs to no registered face", o);
   {
+    // partner words: pairs inside this block and pairs with another block of this call (mixed meshes: prism | tetrahedron faces);
+    // the beta sign is the LEFT point's (decided above for this block's left points; for a pair whose left side lies in another
+    // block it is decided here the same way, from that block's normals)
     std::vector<int> nbr(plane_f, -1);
-    bool fits = plane_f < (1L << 29), any = false;
+    bool fits = neb <= 4, any = false;
+    for (int i = 0; i < neb; i++) fits = fits && (long)eles[i]->n_fpts * eles[i]->n_eles < (1L << 27);
+    auto block_of = [&](const hfx_eles *x) { for (int i = 0; i < neb; i++) if (eles[i] == x) return i; return -1; };
     for (int b = 0; b < nfb && fits; b++)
     {
       hfx_inters *f = faces[b];
-      if (f->is_bdy || f->left != e || f->right != e) continue;
+      if (f->is_bdy || (f->left != e && f->right != e)) continue;
+      const int bl = block_of(f->left), br = block_of(f->right);
+      if (bl < 0 || br < 0) { fits = false; break; }
       const long np = (long)f->n_inters * f->n_fpts_per_inter;
+      std::vector<double> nl;
+      const long plane_l = (long)f->left->n_fpts * f->left->n_eles;
+      if (f->left != e)
+      {
+        nl.resize((size_t)plane_l * 3);
+        HFX_HIP(hipMemcpy(nl.data(), f->left->norm_fpts, sizeof(double) * nl.size(), hipMemcpyDeviceToHost));
+      }
       for (long q = 0; q < np; q++)
       {
         const int il = f->hL[q], ir = f->hR[q];
-        nbr[il] = (ir << 2) | (meta[il] & 2);
-        nbr[ir] = (il << 2) | (meta[il] & 2) | 1;
+        int flip;
+        if (f->left == e)
+          flip = meta[il] & 2;
+        else
+        {
+          const double n[3] = {nl[il], nl[il + plane_l], nl[il + 2 * plane_l]};
+          flip = ldg_switch_host(1.0, n) < 0 ? 2 : 0;
+        }
+        if (f->left == e) nbr[il] = (ir << 4) | (br << 2) | flip;
+        if (f->right == e) nbr[ir] = (il << 4) | (bl << 2) | flip | 1;
         any = true;
       }
     }
     if (g->nbr) { (void)hipFree(g->nbr); g->nbr = nullptr; }
+    g->n_blocks = 0;
     if (fits && any)
     {
       HFX_HIP(hipMalloc((void **)&g->nbr, sizeof(int) * (size_t)plane_f));
       HFX_HIP(hipMemcpy(g->nbr, nbr.data(), sizeof(int) * (size_t)plane_f, hipMemcpyHostToDevice));
+      g->n_blocks = neb;
+      for (int i = 0; i < neb; i++) g->blocks[i] = eles[i];
     }
   }
   if (g->meta) (void)hipFree(g->meta);
@@ -1022,6 +1053,11 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
   a.detjac_upts = e->detjac_upts; a.JGinv_upts = e->JGinv_upts; a.detjac_fpts = e->detjac_fpts; a.JGinv_fpts = e->JGinv_fpts;
   a.norm_fpts = e->norm_fpts; a.meta = g->meta;
   a.nbr = (e->ctx->opt.gather_delta && p.viscous && general_batched(e)) ? g->nbr : nullptr;
+  for (int i = 0; i < 4; i++)
+  {
+    a.disu_b[i] = (i < g->n_blocks) ? g->blocks[i]->arr[HFX_DISU_FPTS] : nullptr;
+    a.plane_b[i] = (i < g->n_blocks) ? (long)g->blocks[i]->n_fpts * g->blocks[i]->n_eles : 0;
+  }
   a.div = e->arr[HFX_DIV_TCONF_UPTS]; a.ntd = e->arr[HFX_NORM_TDISF_FPTS]; a.fn = g->fn_fpts;
   a.grad_fpts = (g->any_bdy && p.viscous) ? e->arr[HFX_GRAD_DISU_FPTS] : nullptr;
   a.P = e->ctx->phys();
@@ -1120,9 +1156,13 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
         if (hfx_bdy_launch_internal(faces[b], 0, 1)) return 1; // ghost state -> inviscid common flux, LDG common solution
         continue;
       }
-      if (faces[b]->left == faces[b]->right && ctx->opt.gather_delta && faces[b]->left->general &&
-          ((GeneralData *)faces[b]->left->general)->nbr && general_batched(faces[b]->left))
-        continue; // (the flux kernel of that block forms these corrections itself)
+      {
+        // both sides' flux kernels form these corrections themselves?
+        auto own = [&](hfx_eles *x) {
+          return x->general && ((GeneralData *)x->general)->nbr && ((GeneralData *)x->general)->n_blocks && general_batched(x);
+        };
+        if (ctx->opt.gather_delta && own(faces[b]->left) && own(faces[b]->right)) continue;
+      }
       const GFaceArgs a = gface_args(faces[b]);
       if (a.npairs == 0) continue;
       hipLaunchKernelGGL(gface_delta_kernel, dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
@@ -1190,8 +1230,14 @@ static int general_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *fa
   for (int i = 0; i < neb; i++)
   {
     GeneralData *g = (GeneralData *)eles[i]->general;
-    if (!g || !g->built)
-      if (general_build(eles[i], faces, nfb)) return 1;
+    bool same = g && g->built;
+    if (same && g->n_blocks)
+    {
+      same = g->n_blocks == neb;
+      for (int j = 0; j < neb && same; j++) same = g->blocks[j] == eles[j];
+    }
+    if (!same)
+      if (general_build(eles[i], faces, nfb, eles, neb)) return 1;
   }
   return 0;
 }
