@@ -164,24 +164,58 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
   {
     const double *src = a.B + c0 * k;
     const int tile_len = k * ncl;
+    // SB entries per thread are requested before the first one is used: with `LDS = load` per trip every trip waits for its
+    // own load (a tile of k = 125 rows is 31 trips)
+    constexpr int SB = 8;
     if (a.sub != nullptr)
     {
       const double *sb = a.sub + c0 * k;
       double *wb = a.in_writeback + c0 * k;
-      for (int q = tid; q < tile_len; q += 256)
+      for (int q0 = tid; q0 < tile_len; q0 += 256 * SB)
       {
-        const double v = src[q] + -1.0 * sb[q];
-        wb[q] = v;
-        const int j = q / k, kk = q - j * k;
-        btile[kk * LDB + j] = v;
+        double v[SB], w[SB];
+#pragma unroll
+        for (int i = 0; i < SB; i++)
+        {
+          const int q = q0 + 256 * i, qc = q < tile_len ? q : tile_len - 1;
+          v[i] = src[qc];
+          w[i] = sb[qc];
+        }
+#pragma unroll
+        for (int i = 0; i < SB; i++)
+        {
+          const int q = q0 + 256 * i;
+          if (q < tile_len)
+          {
+            const double x = v[i] + -1.0 * w[i];
+            wb[q] = x;
+            const int j = q / k, kk = q - j * k;
+            btile[kk * LDB + j] = x;
+          }
+        }
       }
     }
     else
     {
-      for (int q = tid; q < tile_len; q += 256)
+      for (int q0 = tid; q0 < tile_len; q0 += 256 * SB)
       {
-        const int j = q / k, kk = q - j * k;
-        btile[kk * LDB + j] = src[q];
+        double v[SB];
+#pragma unroll
+        for (int i = 0; i < SB; i++)
+        {
+          const int q = q0 + 256 * i;
+          v[i] = src[q < tile_len ? q : tile_len - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < SB; i++)
+        {
+          const int q = q0 + 256 * i;
+          if (q < tile_len)
+          {
+            const int j = q / k, kk = q - j * k;
+            btile[kk * LDB + j] = v[i];
+          }
+        }
       }
     }
     // zero the k padding rows and the missing columns so that MFMA adds exact zeros
