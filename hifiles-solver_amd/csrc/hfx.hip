@@ -182,13 +182,29 @@ static int launch_dense(hfx_ctx *ctx, const Operator &op, const double *B, doubl
   HFX_CHECK(lds <= 160 * 1024, "dense contraction: k = %d does not fit LDS", op.k);
   const long nblk = (ncols + ct - 1) / ct;
   if (nblk == 0) return 0;
-#define HFX_DENSE(CT_)                                                                                                  \
+  // shape of the workgroup: operators with many 16-row tiles keep eight waves busy on half-tiles; small ones (simplex
+  // classes: 2-5 row tiles) deal quarter-tiles to four waves (measured)
+  const int n_rt = (op.m + 15) / 16;
+  int nw = ctx->opt.dense_waves ? ctx->opt.dense_waves : (n_rt >= 6 ? 8 : 4);
+  int spl = ctx->opt.dense_split ? ctx->opt.dense_split : (n_rt >= 6 ? 2 : 4);
+#define HFX_DENSE_L(CT_, NW_, SP_)                                                                                      \
   {                                                                                                                     \
     if (lds > 48 * 1024)                                                                                                \
-      HFX_HIP(hipFuncSetAttribute((const void *)dense_mfma_kernel<CT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(dense_mfma_kernel<CT_>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, a);                    \
+      HFX_HIP(hipFuncSetAttribute((const void *)dense_mfma_kernel<CT_, NW_, SP_>,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+    hipLaunchKernelGGL((dense_mfma_kernel<CT_, NW_, SP_>), dim3((unsigned)nblk), dim3(64 * NW_), lds, ctx->stream, a);  \
+  }
+#define HFX_DENSE_S(CT_, NW_)                                                                                           \
+  {                                                                                                                     \
+    if (spl == 1) HFX_DENSE_L(CT_, NW_, 1) else if (spl == 2) HFX_DENSE_L(CT_, NW_, 2) else HFX_DENSE_L(CT_, NW_, 4)    \
+  }
+#define HFX_DENSE(CT_)                                                                                                  \
+  {                                                                                                                     \
+    if (nw == 8) HFX_DENSE_S(CT_, 8) else HFX_DENSE_S(CT_, 4)                                                           \
   }
   if (ct == 64) HFX_DENSE(64) else if (ct == 32) HFX_DENSE(32) else HFX_DENSE(16)
+#undef HFX_DENSE_L
+#undef HFX_DENSE_S
 #undef HFX_DENSE
   HFX_HIP(hipGetLastError());
   return 0;
@@ -382,6 +398,8 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   else if (n == "flux_stamps") o.flux_stamps = value;
   else if (n == "simd_roles") o.simd_roles = value != 0;
   else if (n == "tensor_ops") o.tensor_ops = value != 0;
+  else if (n == "dense_waves") { HFX_CHECK(value == 0 || value == 4 || value == 8, "dense_waves must be 0, 4 or 8"); o.dense_waves = value; }
+  else if (n == "dense_split") { HFX_CHECK(value == 0 || value == 1 || value == 2 || value == 4, "dense_split must be 0, 1, 2 or 4"); o.dense_split = value; }
   else if (n == "general_waves") { HFX_CHECK(value == 0 || value == 3 || value == 4 || value == 8, "general_waves must be 0, 3, 4 or 8"); o.general_waves = value; }
   else HFX_CHECK(false, "hfx_ctx_set_option: unknown option %s", name);
   return 0;

@@ -85,6 +85,8 @@ struct hfx_ctx
     int simd_roles = 1;         // 1: the flux kernel deals its waves' parts by SIMD (one heavy wave per SIMD)
     int flux_stamps = 0;        // 1: phase time stamps of one workgroup of the flux kernel (printed by hfx_time_fused_kernels)
     int tensor_ops = 1;         // sum-factorised over-integration / shock capturing on tensor-product classes
+    int dense_waves = 0;        // waves per workgroup of the dense MFMA contraction: 0 by the operator's rows, else 4 or 8
+    int dense_split = 0;        // column groups per 16-row tile dealt to the waves: 0 by the operator's rows, else 1, 2 or 4
     int general_waves = 0;      // waves per workgroup of the general flux kernel: 0 by the LDS image (4 or 8), else 3, 4 or 8
   } opt;
   double CFL = 0.0; // run_input.CFL (hfx_ctx_set_CFL); dt_type 1 / 2 only

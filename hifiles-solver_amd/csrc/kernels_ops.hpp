@@ -121,11 +121,11 @@ __global__ void ell_apply_kernel(const EllArgs<NT, NO> a)
 // v_mfma_f64_16x16x4_f64: lane l holds A[i = l&15][kk = l>>4], B[kk = l>>4][j = l&15],
 // D[row = (l>>4) + 4*reg][col = l&15]  (cdna_hip_programming.md section 3).
 //
-// Workgroup = 256 threads (4 waves) owns a 64-column tile of B/C: the k x 64 B
+// Workgroup = 4 or 8 waves owns a 64-column tile of B/C: the k x 64 B
 // tile is contiguous in HBM and is staged once through LDS (coalesced); A is
 // read from global/L2 (it is the same 100-150 kB for every workgroup and stays
-// cache resident).  Wave w computes row tiles w, w+4, ... (16 rows each) for
-// all four 16-column sub-tiles, so each A fragment loaded from L2 feeds 4 MFMAs.
+// cache resident).  The (16-row tile, group of 16-column sub-tiles) units are dealt
+// to the waves; an A fragment loaded from L2 feeds as many MFMAs as the group has sub-tiles.
 // C is produced transposed inside the MFMA (operands swapped) so that stores
 // are 128-byte contiguous runs along the operator-row index.
 // The k-loop runs l ascending in steps of 4, the reference's summation order
@@ -148,10 +148,12 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int DENSE_CT = 64; // columns per workgroup (32 / 16 for operators with many columns: the B tile holds all of k)
 
-template <int CT>
-__global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
+// NW waves per workgroup; a unit of work is one 16-row tile of the operator times CT/SPL columns, dealt round-robin to
+// the waves (SPLQ asked, at most one unit per 16-column sub-tile)
+template <int CT, int NW, int SPLQ>
+__global__ __launch_bounds__(64 * NW) void dense_mfma_kernel(const DenseArgs a)
 {
-  constexpr int DENSE_CT = CT;
+  constexpr int DENSE_CT = CT, DENSE_THREADS = 64 * NW;
   extern __shared__ double btile[]; // [kpad][DENSE_CT+pad] transposed: bt[kk*LDB + j]
   const int m = a.m, k = a.k;
   const int kpad = (k + 3) & ~3;
@@ -171,20 +173,20 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
     {
       const double *sb = a.sub + c0 * k;
       double *wb = a.in_writeback + c0 * k;
-      for (int q0 = tid; q0 < tile_len; q0 += 256 * SB)
+      for (int q0 = tid; q0 < tile_len; q0 += DENSE_THREADS * SB)
       {
         double v[SB], w[SB];
 #pragma unroll
         for (int i = 0; i < SB; i++)
         {
-          const int q = q0 + 256 * i, qc = q < tile_len ? q : tile_len - 1;
+          const int q = q0 + DENSE_THREADS * i, qc = q < tile_len ? q : tile_len - 1;
           v[i] = src[qc];
           w[i] = sb[qc];
         }
 #pragma unroll
         for (int i = 0; i < SB; i++)
         {
-          const int q = q0 + 256 * i;
+          const int q = q0 + DENSE_THREADS * i;
           if (q < tile_len)
           {
             const double x = v[i] + -1.0 * w[i];
@@ -197,19 +199,19 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
     }
     else
     {
-      for (int q0 = tid; q0 < tile_len; q0 += 256 * SB)
+      for (int q0 = tid; q0 < tile_len; q0 += DENSE_THREADS * SB)
       {
         double v[SB];
 #pragma unroll
         for (int i = 0; i < SB; i++)
         {
-          const int q = q0 + 256 * i;
+          const int q = q0 + DENSE_THREADS * i;
           v[i] = src[q < tile_len ? q : tile_len - 1];
         }
 #pragma unroll
         for (int i = 0; i < SB; i++)
         {
-          const int q = q0 + 256 * i;
+          const int q = q0 + DENSE_THREADS * i;
           if (q < tile_len)
           {
             const int j = q / k, kk = q - j * k;
@@ -219,13 +221,13 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
       }
     }
     // zero the k padding rows and the missing columns so that MFMA adds exact zeros
-    for (int q = tid; q < (kpad - k) * DENSE_CT; q += 256)
+    for (int q = tid; q < (kpad - k) * DENSE_CT; q += DENSE_THREADS)
     {
       const int kk = k + q / DENSE_CT, j = q % DENSE_CT;
       btile[kk * LDB + j] = 0.0;
     }
     if (ncl < DENSE_CT)
-      for (int q = tid; q < kpad * (DENSE_CT - ncl); q += 256)
+      for (int q = tid; q < kpad * (DENSE_CT - ncl); q += DENSE_THREADS)
       {
         const int kk = q / (DENSE_CT - ncl), j = ncl + q % (DENSE_CT - ncl);
         btile[kk * LDB + j] = 0.0;
@@ -237,14 +239,16 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
   const int li = lane & 15, lk = lane >> 4;
   const int n_rt = (m + 15) >> 4;
 
-  for (int rt = wave; rt < n_rt; rt += 4)
+  constexpr int SPL = CT / 16 >= SPLQ ? SPLQ : CT / 16;
+  constexpr int NS = CT / 16 / SPL; // 16-column sub-tiles per unit of work
+  for (int un = wave; un < n_rt * SPL; un += NW)
   {
+    const int rt = un / SPL, s0 = (un % SPL) * NS;
     // MFMA operands are swapped (C^T = B^T A^T) so that the 16 lanes li of an
     // accumulator register hold 16 CONSECUTIVE operator rows of one C column:
     // D[i = lk + 4*reg -> column of the tile][j = li -> operator row]
     const int row = rt * 16 + li;
     const bool row_ok = row < m;
-    constexpr int NS = CT / 16;
     f64x4 acc[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++)
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++)
       {
-        const int ocol = s * 16 + lk + 4 * rg;
+        const int ocol = (s0 + s) * 16 + lk + 4 * rg;
         acc[s][rg] = (a.beta && row_ok && ocol < ncl) ? a.C[(c0 + ocol) * m + row] : 0.0;
       }
     }
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
 #pragma unroll
           for (int s = 0; s < NS; s++)
           {
-            const double bv = btile[kk * LDB + s * 16 + li];
+            const double bv = btile[kk * LDB + (s0 + s) * 16 + li];
             acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av[u], acc[s], 0, 0, 0);
           }
         }
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++)
       {
-        const int ocol = s * 16 + lk + 4 * rg;
+        const int ocol = (s0 + s) * 16 + lk + 4 * rg;
         if (row_ok && ocol < ncl)
         {
           const double v = acc[s][rg];

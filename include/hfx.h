@@ -123,7 +123,8 @@ int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
  * LDG launch), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "comm_stream_faces" (1:
  * hfx_run_steps_partitioned launches the one-sided partition-face kernels on the communication stream), "flux_stamps" (0; n >= 1: cycle
  * stamps of iteration max(n, 2) of one workgroup of the flux kernels, printed by the hfx_time_* entry points), "tensor_ops" (1),
- * "general_waves" (0 = by LDS image | 3 | 4 | 8) -- see hfx_ctx::Options in csrc/hfx_internal.hpp;
+ * "general_waves" (0 = by LDS image | 3 | 4 | 8), "dense_waves" (0 = by the operator's rows | 4 | 8) and "dense_split" (0 | 1 | 2 | 4:
+ * shape of the dense MFMA contraction's workgroup) -- see hfx_ctx::Options in csrc/hfx_internal.hpp;
  * tests/test_gpu_fused.py::test_split3_variant_knobs_agree holds the variants to each other. */
 int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value);
 /* run_input.dt as the last calc_time_step left it (dt_type 1), or as set (dt_type 0) */
