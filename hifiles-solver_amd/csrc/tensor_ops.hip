@@ -312,22 +312,26 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
       }
     }
   };
-  if ((long)blockIdx.x < a.n_eles) fetch_u(blockIdx.x);
-  for (long e = blockIdx.x; e < a.n_eles; e += gridDim.x)
-  {
-    // the metric tensors of this thread's cubature points: requested first, consumed after the interpolation passes
-    double jg[PPT][NQ];
+  // the metric tensors of this thread's cubature points travel the same way: those of the next element are requested as
+  // soon as this element's transformed flux is formed, so that they are in flight during the projection passes
+  double jg[PPT][NQ];
+  auto fetch_jg = [&](long e) {
 #pragma unroll
     for (int r = 0; r < PPT; r++)
     {
       const int q = threadIdx.x + 256 * r;
-      if (q < nc)
-      {
-        const double *src = a.JGc + NQ * ((long)q + (long)nc * e);
+      const double *src = a.JGc + NQ * ((long)(q < nc ? q : nc - 1) + (long)nc * e);
 #pragma unroll
-        for (int m = 0; m < NQ; m++) jg[r][m] = src[m];
-      }
+      for (int m = 0; m < NQ; m++) jg[r][m] = src[m];
     }
+  };
+  if ((long)blockIdx.x < a.n_eles)
+  {
+    fetch_u(blockIdx.x);
+    fetch_jg(blockIdx.x);
+  }
+  for (long e = blockIdx.x; e < a.n_eles; e += gridDim.x)
+  {
 #pragma unroll
     for (int i = 0; i < UPT; i++)
       if (threadIdx.x + 256 * i < NF * nu) R0[threadIdx.x + 256 * i] = pu[i];
@@ -337,24 +341,34 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
     double *ucub = tapply<ND, NC, N>(R0, R1, cI, NF);
     double *fa = (ucub == R0) ? R1 : R0; // two free regions
     double *fb = R2;
-    // the Euler flux at this thread's cubature points, once
-    double fx[PPT][NF * ND];
+    // the transformed Euler flux at this thread's cubature points, once: t(k, l) = sum_m JGinv(l, m) F(k, m)
+    double tf[PPT][NF * ND];
 #pragma unroll
     for (int r = 0; r < PPT; r++)
     {
       const int q = threadIdx.x + 256 * r;
       if (q < nc)
       {
-        double u[NF];
+        double u[NF], fx[NF * ND];
 #pragma unroll
         for (int k = 0; k < NF; k++) u[k] = ucub[q + nc * k];
-        calc_invf<ND>(a.gamma, u, fx[r]);
+        calc_invf<ND>(a.gamma, u, fx);
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+          {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < ND; m++) s += jg[r][l + ND * m] * fx[k + NF * m];
+            tf[r][k + NF * l] = s;
+          }
       }
     }
+    if (e + gridDim.x < a.n_eles) fetch_jg(e + gridDim.x);
 #pragma unroll
     for (int l = 0; l < ND; l++)
     {
-      // row l of the transformed flux at the cubature points: t(k) = sum_m JGinv(l, m) F(k, m)
 #pragma unroll
       for (int r = 0; r < PPT; r++)
       {
@@ -362,13 +376,7 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
         if (q < nc)
         {
 #pragma unroll
-          for (int k = 0; k < NF; k++)
-          {
-            double s = 0.0;
-#pragma unroll
-            for (int m = 0; m < ND; m++) s += jg[r][l + ND * m] * fx[r][k + NF * m];
-            fa[q + nc * k] = s;
-          }
+          for (int k = 0; k < NF; k++) fa[q + nc * k] = tf[r][k + NF * l];
         }
       }
       lds_sync();
