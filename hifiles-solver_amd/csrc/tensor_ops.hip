@@ -233,8 +233,8 @@ typedef const double __attribute__((address_space(4))) *tcptr;
 // store of the wave (vmcnt(0)), i.e. drain the prefetches and expose the latency of each result store
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int MO, int MI>
-__device__ __forceinline__ void tpass(const double *in, double *out, tcptr M, int P, int n_pencils)
+template <int MO, int MI, typename MT>
+__device__ __forceinline__ void tpass(const double *in, double *out, const MT &M, int P, int n_pencils)
 {
   for (int w = threadIdx.x; w < n_pencils; w += blockDim.x)
   {
@@ -256,9 +256,11 @@ __device__ __forceinline__ void tpass(const double *in, double *out, tcptr M, in
 }
 
 // all ND passes of (NIN per direction) -> (NOUT per direction) on nf fields; ping-pongs between a and b and returns
-// the buffer that holds the result.  Every pass ends in a barrier.
-template <int ND, int NOUT, int NIN>
-__device__ __forceinline__ double *tapply(double *a, double *b, tcptr M, int nf)
+// the buffer that holds the result.  Every pass ends in a barrier.  M is either a pointer into the constant address
+// space (re-read by every pass: the barrier's memory clobber forbids keeping it) or a register array the caller loaded
+// once -- wave-uniform values, i.e. scalar registers.
+template <int ND, int NOUT, int NIN, typename MT>
+__device__ __forceinline__ double *tapply(double *a, double *b, const MT &M, int nf)
 {
   double *src = a, *dst = b;
   int P = 1;
@@ -288,23 +290,28 @@ struct OverIntArgs
   double gamma;
 };
 
+// threads of the over-integration workgroup (7^3 = 343 points on 6 waves, one point per thread, took 98 registers instead
+// of 150 and 20.7 k cycles per element instead of 23.5 k, but with three 6-wave workgroups per CU the stage was not faster)
+constexpr int oi_threads(int) { return 256; }
+
 template <int ND, int N, int NC>
-__global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a)
+__global__ __launch_bounds__(oi_threads(cpow(NC, ND))) void overint_tensor_kernel(const OverIntArgs a)
 {
   constexpr int NF = ND + 2, NQ = ND * ND, nu = cpow(N, ND), nc = cpow(NC, ND);
-  constexpr int PPT = (nc + 255) / 256; // cubature points per thread
+  constexpr int THR = oi_threads(nc);
+  constexpr int PPT = (nc + THR - 1) / THR; // cubature points per thread
   extern __shared__ double lds[];
   double *R0 = lds, *R1 = R0 + NF * nc, *R2 = R1 + NF * nc;
   const tcptr cI = (tcptr)(uintptr_t)a.I1, cF = (tcptr)(uintptr_t)a.F1;
   const long plane_u = (long)nu * a.n_eles;
   // software pipeline: the next element's state is requested while this one is worked on
-  constexpr int UPT = (NF * nu + 255) / 256;
+  constexpr int UPT = (NF * nu + THR - 1) / THR;
   double pu[UPT];
   auto fetch_u = [&](long e) {
 #pragma unroll
     for (int i = 0; i < UPT; i++)
     {
-      const int q = threadIdx.x + 256 * i;
+      const int q = threadIdx.x + THR * i;
       if (q < NF * nu)
       {
         const int k = q / nu, pt = q - k * nu;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
 #pragma unroll
     for (int r = 0; r < PPT; r++)
     {
-      const int q = threadIdx.x + 256 * r;
+      const int q = threadIdx.x + THR * r;
       const double *src = a.JGc + NQ * ((long)(q < nc ? q : nc - 1) + (long)nc * e);
 #pragma unroll
       for (int m = 0; m < NQ; m++) jg[r][m] = src[m];
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
   {
 #pragma unroll
     for (int i = 0; i < UPT; i++)
-      if (threadIdx.x + 256 * i < NF * nu) R0[threadIdx.x + 256 * i] = pu[i];
+      if (threadIdx.x + THR * i < NF * nu) R0[threadIdx.x + THR * i] = pu[i];
     lds_sync();
     if (e + gridDim.x < a.n_eles) fetch_u(e + gridDim.x);
     // solution at the cubature points (opp_over_int_cubpts . u)
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
 #pragma unroll
     for (int r = 0; r < PPT; r++)
     {
-      const int q = threadIdx.x + 256 * r;
+      const int q = threadIdx.x + THR * r;
       if (q < nc)
       {
         double u[NF], fx[NF * ND];
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void overint_tensor_kernel(const OverIntArgs a
 #pragma unroll
       for (int r = 0; r < PPT; r++)
       {
-        const int q = threadIdx.x + 256 * r;
+        const int q = threadIdx.x + THR * r;
         if (q < nc)
         {
 #pragma unroll
@@ -398,7 +405,12 @@ template <int ND, int N, int NC>
 static int oi_launch_one(hfx_eles *e, const OverIntArgs &a, size_t lds, int grid)
 {
   HFX_HIP(hipFuncSetAttribute((const void *)overint_tensor_kernel<ND, N, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((overint_tensor_kernel<ND, N, NC>), dim3(grid), dim3(256), lds, e->ctx->stream, a);
+  // persistent grid: exactly the workgroups that are resident at once (registers and LDS decide), so that no workgroup
+  // waits for a slot while the others are half way through their elements
+  int per_cu = 0;
+  HFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, overint_tensor_kernel<ND, N, NC>, oi_threads(cpow(NC, ND)), lds));
+  grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * std::max(per_cu, 1));
+  hipLaunchKernelGGL((overint_tensor_kernel<ND, N, NC>), dim3(grid), dim3(oi_threads(cpow(NC, ND))), lds, e->ctx->stream, a);
   HFX_HIP(hipGetLastError());
   return 0;
 }
@@ -541,6 +553,10 @@ static int shock_pick_n(hfx_eles *e, const ShockArgs &a, int grid, int n)
 {
   if (n == N)
   {
+    // persistent grid: the workgroups resident at once, or all of a small mesh
+    int per_cu = 0;
+    HFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shock_tensor_kernel<ND, N>, 256, 0));
+    grid = (int)std::min<long>(grid, (long)e->ctx->n_cu * std::max(per_cu, 1));
     hipLaunchKernelGGL((shock_tensor_kernel<ND, N>), dim3(grid), dim3(256), 0, e->ctx->stream, a);
     HFX_HIP(hipGetLastError());
     return 0;
