@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 evidence of round 2: kernel stats (--kernel-trace --stats) and, in SEPARATE counter-only passes, HBM traffic and
 # issue counters, for (a) the default bench command (split3), (b) the general fused stage on the mixed channel and on
-# tetrahedra, (c) the partitioned stage with libhfx's RCCL transport on one self-partitioned rank
+# tetrahedra, (c) the partitioned stage with libhfx's RCCL transport on one self-partitioned rank, (d) configs[4]'s
+# ingredients (over-integration + shock capturing), (e) the per-method path with dense FP64 MFMA contractions
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_r02
@@ -25,4 +26,6 @@ stats general_mixed --workload mixed --steps 4 --warmup 1
 traffic general_mixed --workload mixed --steps 1 --warmup 1
 stats general_tets --workload tets --steps 4 --warmup 1
 stats partitioned --self-partition --steps 10 --warmup 2
+stats config5 --steps 6 --warmup 2 --over-int-order 6 --shock-s0 1e-3
+stats dense --mode dense --steps 3 --warmup 1
 ls $OUT
