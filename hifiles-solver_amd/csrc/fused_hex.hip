@@ -493,18 +493,48 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
   return 0;
 }
 
+// workgroups of a persistent (grid-stride over elements) kernel that are resident on one CU at once -- registers and LDS
+// decide.  A grid of exactly that many per CU has no workgroup waiting for a slot: with more, the late ones start when
+// the others are part way through their elements and finish as a tail (LES residual kernel: five resident, 0.70 ms at
+// five per CU, 1.00 ms at six, 0.81 ms at sixteen).
+template <auto KERNEL>
+static int resident_per_cu(int threads)
+{
+  static int n = 0;
+  if (n == 0)
+  {
+    int q = 0;
+    n = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, KERNEL, threads, 0) == hipSuccess && q > 0) ? q : 1;
+  }
+  return n;
+}
+
+// grid of a persistent element kernel: the resident workgroups, or `per_cu` of them per CU when the option asks.  `cap`:
+// the streaming update kernel is fastest at three workgroups per CU (0.27 ms; 0.35 ms at the four that are resident, 0.29 ms
+// at sixteen)
+template <auto KERNEL>
+static int element_grid(const hfx_eles *e, int threads, int per_cu, int cap = 1 << 30)
+{
+  const int pc = per_cu > 0 ? per_cu : std::min(cap, resident_per_cu<KERNEL>(threads));
+  return (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * pc);
+}
+
 // launch of the loader-wave form, instantiated only for element sizes it fits (loader_wave_fits)
 template <int ND, int N, bool OI, bool GA, bool FITS>
 struct LoaderWaveLaunch
 {
-  static void go(int, hipStream_t, const Split2Args &, const double *, const int *) {}
+  static void go(const hfx_eles *, int, hipStream_t, const Split2Args &, const double *, const int *) {}
 };
 template <int ND, int N, bool OI, bool GA>
 struct LoaderWaveLaunch<ND, N, OI, GA, true>
 {
-  static void go(int grid, hipStream_t st, const Split2Args &e2, const double *coef, const int *idx)
+  static void go(const hfx_eles *e, int per_cu, hipStream_t st, const Split2Args &e2, const double *coef, const int *idx)
   {
-    hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA>), dim3(grid), dim3(SGeo<ND, N>::TB + 64), 0, st, e2, coef, idx);
+    constexpr int TB = SGeo<ND, N>::TB + 64;
+    // (the over-integration form measured 3 % faster at sixteen workgroups per CU than at the two that are resident)
+    if (OI && per_cu == 0) per_cu = 16;
+    const int grid = element_grid<split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA>>(e, TB, per_cu);
+    hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA>), dim3(grid), dim3(TB), 0, st, e2, coef, idx);
   }
 };
 
@@ -516,9 +546,10 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   const Phys P = e->ctx->phys();
   const long plane_f = (long)e->n_fpts * e->n_eles;
   const hfx_ctx::Options &opt = e->ctx->opt;
-  const int grid_per_cu = std::max(1, opt.split_grid_per_cu);
-  const int grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * grid_per_cu);
-  const int flux_grid = opt.flux_grid_per_cu > 0 ? (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * opt.flux_grid_per_cu) : grid;
+  // persistent grids: split_grid_per_cu workgroups per CU, 0 = as many as are resident (element_grid)
+  const int per_cu = opt.split_grid_per_cu;
+  const int flux_per_cu = opt.flux_grid_per_cu > 0 ? opt.flux_grid_per_cu : per_cu;
+  constexpr int TB = SGeo<ND, N>::TB;
   auto face_args = [&](hfx_inters *f) {
     SplitFaceArgs a{};
     a.npairs = (long)f->n_inters * f->n_fpts_per_inter;
@@ -623,8 +654,9 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       const bool buf = !nobuf && most * 8.0 < 4294967296.0;
       const bool oi = e2.tdisf_in != nullptr;
 #define HFX_FLUX_LAUNCH(WV_, BUF_, OI_, LW_)                                                                                  \
-  hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_, LW_>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2,   \
-                     F->t_coef, F->t_idx)
+  hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_, LW_>),                                                  \
+                     dim3(element_grid<split_flux_tensor_kernel<ND, N, WV_, BUF_, OI_, LW_>>(e, TB, per_cu)), dim3(TB), 0, st, \
+                     e2, F->t_coef, F->t_idx)
       const bool no_lw = !opt.loader_wave;
       constexpr bool lw_fits = loader_wave_fits<ND, N>();
       const bool lw = lw_fits && buf && !no_lw && waves == 2;
@@ -633,13 +665,13 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       {
         const bool ga = e2.nbr != nullptr && P.viscous; // (the corrections formed in the kernel)
         if (oi && ga)
-          LoaderWaveLaunch<ND, N, true, true, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, true, true, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         else if (oi)
-          LoaderWaveLaunch<ND, N, true, false, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, true, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         else if (ga)
-          LoaderWaveLaunch<ND, N, false, true, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, false, true, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         else
-          LoaderWaveLaunch<ND, N, false, false, lw_fits>::go(flux_grid, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, false, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         launched = true;
       }
       if (launched)
@@ -656,14 +688,14 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
         HFX_FLUX_LAUNCH(2, false, false, false);
 #undef HFX_FLUX_LAUNCH
       else
-        hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+        hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(element_grid<split_flux_kernel<ND, N>>(e, TB, per_cu)), dim3(TB), 0, st, e2);
     }
   }
   else if (P.viscous && (which == 0 || which == 2))
   {
     ea.pk = F->pk_g;
     ea.tab = F->tab_g;
-    hipLaunchKernelGGL((split_gradient_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, ea);
+    hipLaunchKernelGGL((split_gradient_kernel<ND, N>), dim3(element_grid<split_gradient_kernel<ND, N>>(e, TB, per_cu)), dim3(TB), 0, st, ea);
     if (e->les_ready)
     {
       // LES (eddy-viscosity closures): SGS flux at the solution points from the corrected gradient, its extrapolation to
@@ -712,15 +744,15 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       const bool nobuf = !opt.buffer_addressing;
       const bool small = (double)std::max<long>(plane_f, (long)e->n_upts * e->n_eles) * e->n_fields * 8.0 < 4294967296.0;
       if (small && !nobuf)
-        hipLaunchKernelGGL((split_update_kernel<ND, N, true>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+        hipLaunchKernelGGL((split_update_kernel<ND, N, true>), dim3(element_grid<split_update_kernel<ND, N, true>>(e, TB, per_cu, 3)), dim3(TB), 0, st, e2);
       else
-        hipLaunchKernelGGL((split_update_kernel<ND, N, false>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, e2);
+        hipLaunchKernelGGL((split_update_kernel<ND, N, false>), dim3(element_grid<split_update_kernel<ND, N, false>>(e, TB, per_cu, 3)), dim3(TB), 0, st, e2);
     }
     else
     {
       ea.pk = F->pk_r;
       ea.tab = F->tab_r;
-      hipLaunchKernelGGL((split_residual_kernel<ND, N>), dim3(grid), dim3(SGeo<ND, N>::TB), 0, st, ea);
+      hipLaunchKernelGGL((split_residual_kernel<ND, N>), dim3(element_grid<split_residual_kernel<ND, N>>(e, TB, per_cu)), dim3(TB), 0, st, ea);
     }
   }
   HFX_HIP(hipGetLastError());

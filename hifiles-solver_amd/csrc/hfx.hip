@@ -385,7 +385,7 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   HFX_CHECK(ctx && name, "hfx_ctx_set_option: NULL argument");
   hfx_ctx::Options &o = ctx->opt;
   const std::string n(name);
-  if (n == "split_grid_per_cu") { HFX_CHECK(value >= 1, "split_grid_per_cu must be >= 1"); o.split_grid_per_cu = value; }
+  if (n == "split_grid_per_cu") { HFX_CHECK(value >= 0, "split_grid_per_cu must be >= 0"); o.split_grid_per_cu = value; }
   else if (n == "flux_grid_per_cu") { HFX_CHECK(value >= 0, "flux_grid_per_cu must be >= 0"); o.flux_grid_per_cu = value; }
   else if (n == "xcd_order") o.xcd_order = value != 0;
   else if (n == "dictionary_rows") o.dictionary_rows = value != 0;

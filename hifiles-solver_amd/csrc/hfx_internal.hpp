@@ -72,7 +72,7 @@ struct hfx_ctx
   // measurement knobs (hfx_ctx_set_option): kernel variants that give the same results; defaults are the product path
   struct Options
   {
-    int split_grid_per_cu = 16; // persistent workgroups per CU of the split element kernels
+    int split_grid_per_cu = 0;  // persistent workgroups per CU of the split element kernels; 0: as many as are resident
     int flux_grid_per_cu = 0;   // the same for the loader-wave flux kernel alone (0: split_grid_per_cu)
     int xcd_order = 1;          // workgroups of one XCD walk one contiguous eighth of the elements
     int dictionary_rows = 0;    // 1: the dictionary-row flux kernel even when the operators are tensor products

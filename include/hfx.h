@@ -118,7 +118,7 @@ int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode);
  * time step with calc_time_step (src/HiFiLES.cpp:198, src/solver.cpp:484-549) */
 int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
 /* Measurement knobs: kernel variants with the same results (A/B runs; defaults are the product path).  name:
- * "split_grid_per_cu" (16), "xcd_order" (1), "dictionary_rows" (0), "flux_waves" (2 | 3), "buffer_addressing" (1),
+ * "split_grid_per_cu" (0 = the workgroups resident at once | n), "xcd_order" (1), "dictionary_rows" (0), "flux_waves" (2 | 3), "buffer_addressing" (1),
  * "loader_wave" (1), "fold_general" (1: the general fused stage applies opp_2 - opp_3 opp_1 and never forms norm_tdisf), "gather_delta" (1: the loader-wave flux kernel forms the interior LDG corrections itself, no pairwise
  * LDG launch), "simd_roles" (1: the flux kernel deals its waves' parts by SIMD), "comm_stream_faces" (1:
  * hfx_run_steps_partitioned launches the one-sided partition-face kernels on the communication stream), "flux_stamps" (0; n >= 1: cycle
