@@ -266,6 +266,35 @@ def test_dense_mfma_path_vs_reference(ctx, name):
     e.close()
 
 
+@pytest.mark.parametrize("waves,split", [(4, 1), (8, 2), (4, 4), (8, 4)])
+def test_dense_mfma_workgroup_shapes_give_the_same_bits(ctx, waves, split):
+    """options dense_waves / dense_split deal the (16-row tile x column group) units of the dense contraction to 4 or 8
+    waves; every output element is still one MFMA accumulator walked over k in the same order, so all shapes -- and the
+    shape chosen from the operator's rows -- give identical bits."""
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p4_n3_deformed.npz")))
+
+    def run():
+        e, faces = build(ctx, d, hfx.CONTRACT_DENSE)
+        hfx.run_steps(e, faces, 1)
+        u = e.download(hfx.DISU_UPTS0).copy()
+        for f in faces:
+            f.close()
+        e.close()
+        return u
+
+    want = run()
+    try:
+        ctx.set_option("dense_waves", waves)
+        ctx.set_option("dense_split", split)
+        got = run()
+    finally:
+        ctx.set_option("dense_waves", 0)
+        ctx.set_option("dense_split", 0)
+    nstage = int(d["sizes"][7])
+    assert relerr(got, d["u_step0_stage%d" % (nstage - 1)]) < RTOLS
+    assert np.array_equal(got, want)
+
+
 def test_run_steps_matches_oracle_two_steps(ctx, oracle):
     d = dict(np.load(os.path.join(GOLDEN, "hex_p3_n3_deformed.npz")))
     e, faces = build(ctx, d)
