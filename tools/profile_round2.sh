@@ -28,4 +28,5 @@ stats general_tets --workload tets --steps 4 --warmup 1
 stats partitioned --self-partition --steps 10 --warmup 2
 stats config5 --steps 6 --warmup 2 --over-int-order 6 --shock-s0 1e-3
 stats dense --mode dense --steps 3 --warmup 1
+stats les --les-cs 0.325 --steps 6 --warmup 2
 ls $OUT
