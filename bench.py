@@ -553,6 +553,26 @@ def main():
         # collective: every rank runs it, rank 0 reports its own
         phases = case.time_partitioned(10)
 
+    # ---- the reference's UNCHANGED call sequence: the mirrored CalcResidual + AdvanceSolution loop (csrc/host/solver.cpp makes
+    # the seventeen method calls of src/solver.cpp:59-221 + src/HiFiLES.cpp:201-217 one by one through the C ABI), timed with
+    # libhfx deferring them (whole stages run as the fused stage) and with every call launching its own kernels
+    api_path = None
+    if not partitioned and fused:
+        api_path = {}
+        for label, on, nsteps in (("deferred", True, args.steps), ("per_method", False, max(2, args.steps // 4))):
+            case.set_deferred(on)
+            case.run(1)
+            case.synchronize()
+            nf0 = hfx.deferred_stats(ctx)[:2]
+            t0 = time.perf_counter()
+            case.run(nsteps)
+            case.synchronize()
+            el = time.perf_counter() - t0
+            nf1 = hfx.deferred_stats(ctx)[:2]
+            api_path[label] = {"ms_per_rk_stage": 1e3 * el / nsteps / case.n_stages, "steps": nsteps,
+                               "stages_run_fused": nf1[0] - nf0[0], "records_replayed_call_by_call": nf1[1] - nf0[1]}
+        case.set_deferred(True)
+
     roof = None
     cpu = None
     if rank == 0 and not partitioned:
@@ -656,6 +676,12 @@ def main():
                        "multi_gpu": mg, "options": options, "env_knobs": knobs},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if api_path is not None:
+            line["api_path_ms_per_rk_stage"] = {k: v["ms_per_rk_stage"] for k, v in api_path.items()}
+            line["api_path"] = dict(api_path, note="the reference's unchanged call sequence (mirrored CalcResidual + AdvanceSolution, one C-ABI "
+                                    "call per reference method): 'deferred' = libhfx records the calls and runs each whole stage as the fused "
+                                    "stage (the host mirror's default), 'per_method' = every call launches its own kernels; `value` is "
+                                    "hfx_run_steps, the same fused stages without the per-call recording")
         if phases is not None:
             line["partitioned_stage_ms"] = phases
         print(json.dumps(line))

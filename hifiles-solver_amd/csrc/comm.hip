@@ -118,19 +118,30 @@ static int start_exchange(hfx_comm *c, hfx_inters *const *mpi_faces, int n_mpi, 
   if (any)
   {
     ncclComm_t comm = (ncclComm_t)c->nccl;
-    HFX_NCCL(g_rccl.GroupStart());
+    // (checked before the group opens: a failure inside it must not leave the thread's group depth at 1)
     for (int b = 0; b < n_mpi; b++)
+      for (int peer : mpi_faces[b]->seg_peer)
+        HFX_CHECK(peer >= 0 && peer < c->nranks, "partition-face block: neighbour rank %d is not one of the communicator's %d ranks", peer, c->nranks);
+    HFX_NCCL(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int b = 0; b < n_mpi && r == ncclSuccess; b++)
     {
       const hfx_inters *f = mpi_faces[b];
       double *out, *in;
       long rec;
       exchange_buffers(f, kind, projected, out, in, rec);
-      for (size_t s = 0; s < f->seg_peer.size(); s++)
+      for (size_t s = 0; s < f->seg_peer.size() && r == ncclSuccess; s++)
       {
         const size_t n = (size_t)f->seg_count[s] * rec;
-        HFX_NCCL(g_rccl.Send(out + (size_t)f->seg_send[s] * rec, n, ncclDouble, f->seg_peer[s], comm, cs));
-        HFX_NCCL(g_rccl.Recv(in + (size_t)f->seg_recv[s] * rec, n, ncclDouble, f->seg_peer[s], comm, cs));
+        r = g_rccl.Send(out + (size_t)f->seg_send[s] * rec, n, ncclDouble, f->seg_peer[s], comm, cs);
+        if (r == ncclSuccess) r = g_rccl.Recv(in + (size_t)f->seg_recv[s] * rec, n, ncclDouble, f->seg_peer[s], comm, cs);
       }
+    }
+    if (r != ncclSuccess)
+    {
+      (void)g_rccl.GroupEnd(); // close the group whatever it says, so that later RCCL calls on this thread are not queued into it
+      set_error("%s:%d: ncclSend / ncclRecv of exchange %d failed: %s", __FILE__, __LINE__, kind, g_rccl.GetErrorString(r));
+      return 1;
     }
     HFX_NCCL(g_rccl.GroupEnd());
   }
@@ -185,12 +196,9 @@ struct StageTimers
   }
 };
 
-// the loop of hfx_run_steps_partitioned / hfx_time_partitioned.  n_stages_total < 0: n_steps whole time steps
-static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
-                           hfx_comm *comm, int n_steps, int n_stages_total, StageTimers *T)
+static int check_partition_blocks(hfx_eles *e, hfx_inters *const *mpi_faces, int n_mpi, hfx_comm *comm)
 {
-  hfx_ctx *ctx = e->ctx;
-  HFX_CHECK(comm && comm->ctx == ctx, "the communicator belongs to another context");
+  HFX_CHECK(comm && comm->ctx == e->ctx, "the communicator belongs to another context");
   for (int b = 0; b < n_mpi; b++)
   {
     const hfx_inters *f = mpi_faces[b];
@@ -199,8 +207,20 @@ static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int,
     for (int c : f->seg_count) listed += c;
     HFX_CHECK(listed == f->n_inters, "partition-face block: %d of %d faces have a neighbour (hfx_mpi_inters_set_neighbours)", listed,
               f->n_inters);
+    for (int peer : f->seg_peer)
+      HFX_CHECK(peer >= 0 && peer < comm->nranks, "partition-face block: neighbour rank %d is not one of the communicator's %d ranks", peer, comm->nranks);
   }
-  const int nst = n_rk_stages(ctx->params);
+  return 0;
+}
+
+// ONE RK stage of the split fused path on a partitioned block with the library's transport, in CalcResidual's order
+// (src/solver.cpp:68-72,131-139,148-155,197-210).  start: the flux-point solution of the current state has not been packed
+// and sent yet (the first stage after the caller changed the state; later stages find the exchange that the previous
+// stage started after its update).  Leaves the exchange of the NEW state's flux-point solution in flight.
+int partitioned_stage(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi, hfx_comm *comm,
+                      int rk, bool start, StageTimers *T)
+{
+  hfx_ctx *ctx = e->ctx;
   const bool visc = ctx->params.viscous != 0;
   const bool projected = split_variant(e) == 3; // variant 3 sends the projected viscous flux
   const bool les = e->les_ready;                // third message: the SGS flux (src/solver.cpp:168-178,203-206)
@@ -210,6 +230,104 @@ static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int,
   };
   // (the timed form keeps every kernel of a phase on the compute stream, so that its events bracket the phase)
   const bool beside = ctx->opt.comm_stream_faces && projected && !les && visc && T == nullptr;
+  if (start)
+  {
+    if (phase(0, rk, 1)) return 1;
+    if (start_exchange(comm, mpi_faces, n_mpi, 0, false)) return 1; // later stages: started after phase 4 of the previous one
+  }
+  if (beside)
+  {
+    // ---- partition-face kernels and exchanges on the communication stream, in its order; the compute stream meets it
+    // at two events per stage: before the flux kernel (LDG corrections at the partition faces are in place) and before
+    // the update kernel (common fluxes at the partition faces are in place)
+    if (phase(1, rk, 0)) return 1; // interior LDG pairs                                      | compute stream
+    ctx->mpi_stream = cs;
+    const int r5 = phase(5, rk, 0); // LDG corrections at the partition faces (behind the receive) | communication stream
+    ctx->mpi_stream = nullptr;
+    if (r5) return 1;
+    HFX_HIP(hipEventRecord(comm->received[0], cs));
+    HFX_HIP(hipStreamWaitEvent(st, comm->received[0], 0));
+    if (phase(6, rk, 0)) return 1; // gradient + flux kernel
+    HFX_HIP(hipEventRecord(comm->packed[1], st));
+    HFX_HIP(hipStreamWaitEvent(cs, comm->packed[1], 0));
+    ctx->mpi_stream = cs;
+    int rc = phase(7, rk, 0); // pack the projected flux
+    if (!rc) rc = start_exchange(comm, mpi_faces, n_mpi, 1, true, true);
+    if (!rc) rc = phase(8, rk, 0); // common fluxes at the partition faces
+    ctx->mpi_stream = nullptr;
+    if (rc) return 1;
+    HFX_HIP(hipEventRecord(comm->received[1], cs));
+    if (phase(3, rk, 0)) return 1; // interior common fluxes                                  | compute stream
+    HFX_HIP(hipStreamWaitEvent(st, comm->received[1], 0));
+    if (phase(9, rk, 0)) return 1; // update (+ shock capturing)
+    HFX_HIP(hipEventRecord(comm->packed[0], st));
+    HFX_HIP(hipStreamWaitEvent(cs, comm->packed[0], 0));
+    ctx->mpi_stream = cs;
+    rc = phase(10, rk, 0); // pack the new flux-point solution
+    if (!rc) rc = start_exchange(comm, mpi_faces, n_mpi, 0, false, true);
+    ctx->mpi_stream = nullptr;
+    return rc;
+  }
+  if (T) HFX_HIP(hipEventRecord(T->ph[0], st));
+  if (phase(1, rk, 0)) return 1;
+  if (T) HFX_HIP(hipEventRecord(T->ph[1], st));
+  if (wait_exchange(comm, 0)) return 1;
+  if (phase(2, rk, 0)) return 1;
+  if (visc)
+  {
+    if (T) HFX_HIP(hipEventRecord(T->x1[0], st));
+    if (start_exchange(comm, mpi_faces, n_mpi, 1, projected)) return 1;
+    if (les && start_exchange(comm, mpi_faces, n_mpi, 2, false)) return 1;
+    if (T) HFX_HIP(hipEventRecord(T->x1[1], cs));
+  }
+  if (T) HFX_HIP(hipEventRecord(T->ph[2], st));
+  if (phase(3, rk, 0)) return 1;
+  if (T) HFX_HIP(hipEventRecord(T->ph[3], st));
+  if (visc && wait_exchange(comm, 1)) return 1;
+  if (visc && les && wait_exchange(comm, 2)) return 1;
+  if (phase(4, rk, 0)) return 1;
+  if (T) HFX_HIP(hipEventRecord(T->x0[0], st));
+  if (start_exchange(comm, mpi_faces, n_mpi, 0, false)) return 1;
+  if (T)
+  {
+    HFX_HIP(hipEventRecord(T->x0[1], cs));
+    HFX_HIP(hipEventRecord(T->ph[4], st));
+    HFX_HIP(hipStreamSynchronize(st));
+    HFX_HIP(hipStreamSynchronize(cs));
+    float t = 0;
+    for (int w = 0; w < 4; w++)
+    {
+      HFX_HIP(hipEventElapsedTime(&t, T->ph[w], T->ph[w + 1]));
+      T->acc[w] += t;
+    }
+    HFX_HIP(hipEventElapsedTime(&t, T->x0[0], T->x0[1]));
+    T->acc[4] += t;
+    if (visc)
+    {
+      HFX_HIP(hipEventElapsedTime(&t, T->x1[0], T->x1[1]));
+      T->acc[5] += t;
+    }
+    HFX_HIP(hipEventElapsedTime(&t, T->ph[0], T->ph[4]));
+    T->acc[6] += t;
+  }
+  return 0;
+}
+
+// the deferred scheduler's stage (deferred.hip): as above, no timers
+int partitioned_stage_deferred(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                               hfx_comm *comm, int rk, bool start)
+{
+  if (check_partition_blocks(e, mpi_faces, n_mpi, comm)) return 1;
+  return partitioned_stage(e, int_faces, n_int, mpi_faces, n_mpi, comm, rk, start, nullptr);
+}
+
+// the loop of hfx_run_steps_partitioned / hfx_time_partitioned.  n_stages_total < 0: n_steps whole time steps
+static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                           hfx_comm *comm, int n_steps, int n_stages_total, StageTimers *T)
+{
+  hfx_ctx *ctx = e->ctx;
+  if (check_partition_blocks(e, mpi_faces, n_mpi, comm)) return 1;
+  const int nst = n_rk_stages(ctx->params);
   bool first = true;
   int done = 0;
   for (int s = 0; n_stages_total >= 0 ? done < n_stages_total : s < n_steps; s++)
@@ -217,88 +335,8 @@ static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int,
     if (calc_time_step(e, comm)) return 1; /* src/HiFiLES.cpp:198 */
     for (int rk = 0; rk < nst && (n_stages_total < 0 || done < n_stages_total); rk++, done++)
     {
-      if (first)
-      {
-        if (phase(0, rk, 1)) return 1;
-        if (start_exchange(comm, mpi_faces, n_mpi, 0, false)) return 1; // later stages: started after phase 4 of the previous one
-        first = false;
-      }
-      if (beside)
-      {
-        // ---- partition-face kernels and exchanges on the communication stream, in its order; the compute stream meets it
-        // at two events per stage: before the flux kernel (LDG corrections at the partition faces are in place) and before
-        // the update kernel (common fluxes at the partition faces are in place)
-        if (phase(1, rk, 0)) return 1; // interior LDG pairs                                      | compute stream
-        ctx->mpi_stream = cs;
-        const int r5 = phase(5, rk, 0); // LDG corrections at the partition faces (behind the receive) | communication stream
-        ctx->mpi_stream = nullptr;
-        if (r5) return 1;
-        HFX_HIP(hipEventRecord(comm->received[0], cs));
-        HFX_HIP(hipStreamWaitEvent(st, comm->received[0], 0));
-        if (phase(6, rk, 0)) return 1; // gradient + flux kernel
-        HFX_HIP(hipEventRecord(comm->packed[1], st));
-        HFX_HIP(hipStreamWaitEvent(cs, comm->packed[1], 0));
-        ctx->mpi_stream = cs;
-        int rc = phase(7, rk, 0); // pack the projected flux
-        if (!rc) rc = start_exchange(comm, mpi_faces, n_mpi, 1, true, true);
-        if (!rc) rc = phase(8, rk, 0); // common fluxes at the partition faces
-        ctx->mpi_stream = nullptr;
-        if (rc) return 1;
-        HFX_HIP(hipEventRecord(comm->received[1], cs));
-        if (phase(3, rk, 0)) return 1; // interior common fluxes                                  | compute stream
-        HFX_HIP(hipStreamWaitEvent(st, comm->received[1], 0));
-        if (phase(9, rk, 0)) return 1; // update (+ shock capturing)
-        HFX_HIP(hipEventRecord(comm->packed[0], st));
-        HFX_HIP(hipStreamWaitEvent(cs, comm->packed[0], 0));
-        ctx->mpi_stream = cs;
-        rc = phase(10, rk, 0); // pack the new flux-point solution
-        if (!rc) rc = start_exchange(comm, mpi_faces, n_mpi, 0, false, true);
-        ctx->mpi_stream = nullptr;
-        if (rc) return 1;
-        continue;
-      }
-      if (T) HFX_HIP(hipEventRecord(T->ph[0], st));
-      if (phase(1, rk, 0)) return 1;
-      if (T) HFX_HIP(hipEventRecord(T->ph[1], st));
-      if (wait_exchange(comm, 0)) return 1;
-      if (phase(2, rk, 0)) return 1;
-      if (visc)
-      {
-        if (T) HFX_HIP(hipEventRecord(T->x1[0], st));
-        if (start_exchange(comm, mpi_faces, n_mpi, 1, projected)) return 1;
-        if (les && start_exchange(comm, mpi_faces, n_mpi, 2, false)) return 1;
-        if (T) HFX_HIP(hipEventRecord(T->x1[1], cs));
-      }
-      if (T) HFX_HIP(hipEventRecord(T->ph[2], st));
-      if (phase(3, rk, 0)) return 1;
-      if (T) HFX_HIP(hipEventRecord(T->ph[3], st));
-      if (visc && wait_exchange(comm, 1)) return 1;
-      if (visc && les && wait_exchange(comm, 2)) return 1;
-      if (phase(4, rk, 0)) return 1;
-      if (T) HFX_HIP(hipEventRecord(T->x0[0], st));
-      if (start_exchange(comm, mpi_faces, n_mpi, 0, false)) return 1;
-      if (T)
-      {
-        HFX_HIP(hipEventRecord(T->x0[1], cs));
-        HFX_HIP(hipEventRecord(T->ph[4], st));
-        HFX_HIP(hipStreamSynchronize(st));
-        HFX_HIP(hipStreamSynchronize(cs));
-        float t = 0;
-        for (int w = 0; w < 4; w++)
-        {
-          HFX_HIP(hipEventElapsedTime(&t, T->ph[w], T->ph[w + 1]));
-          T->acc[w] += t;
-        }
-        HFX_HIP(hipEventElapsedTime(&t, T->x0[0], T->x0[1]));
-        T->acc[4] += t;
-        if (visc)
-        {
-          HFX_HIP(hipEventElapsedTime(&t, T->x1[0], T->x1[1]));
-          T->acc[5] += t;
-        }
-        HFX_HIP(hipEventElapsedTime(&t, T->ph[0], T->ph[4]));
-        T->acc[6] += t;
-      }
+      if (partitioned_stage(e, int_faces, n_int, mpi_faces, n_mpi, comm, rk, first, T)) return 1;
+      first = false;
     }
     advance_ramp_counters(int_faces, n_int);
   }
@@ -345,13 +383,24 @@ int hfx_comm_create(hfx_ctx *ctx, const char id[HFX_COMM_ID_BYTES], int nranks, 
     return 1;
   }
   c->nccl = comm;
-  HFX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int k = 0; k < 3; k++)
+  // (a failure from here on must not leak the communicator: the peers hold its other members)
+  auto rest = [&]() -> int {
+    HFX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; k++)
+    {
+      HFX_HIP(hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming));
+      HFX_HIP(hipEventCreateWithFlags(&c->received[k], hipEventDisableTiming));
+    }
+    HFX_HIP(hipMalloc((void **)&c->scratch, sizeof(double) * 64));
+    return 0;
+  };
+  if (rest())
   {
-    HFX_HIP(hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming));
-    HFX_HIP(hipEventCreateWithFlags(&c->received[k], hipEventDisableTiming));
+    const std::string msg = hfx_last_error();
+    (void)hfx_comm_destroy(c);
+    set_error("%s", msg.c_str());
+    return 1;
   }
-  HFX_HIP(hipMalloc((void **)&c->scratch, sizeof(double) * 64));
   *out = c;
   return 0;
 }
@@ -359,6 +408,12 @@ int hfx_comm_create(hfx_ctx *ctx, const char id[HFX_COMM_ID_BYTES], int nranks, 
 int hfx_comm_destroy(hfx_comm *c)
 {
   if (!c) return 0;
+  if (c->ctx)
+  {
+    // what has been recorded may name this communicator: run it, then forget the plans that do
+    (void)defer_flush(c->ctx, 0);
+    c->ctx->defer.plans.clear();
+  }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
   for (int k = 0; k < 3; k++)
@@ -389,6 +444,8 @@ int hfx_mpi_inters_set_neighbours(hfx_inters *f, int n_seg, const int *peer, con
 {
   HFX_CHECK(f && f->is_mpi, "not a partition-face block");
   HFX_CHECK(n_seg >= 0 && (n_seg == 0 || (peer && send_first && recv_first && count)), "hfx_mpi_inters_set_neighbours: bad argument");
+  HFX_IMMEDIATE(f->ctx, 0);
+  f->ctx->defer.plans.clear();
   std::vector<char> sent((size_t)f->n_inters, 0), got((size_t)f->n_inters, 0);
   for (int s = 0; s < n_seg; s++)
   {
@@ -411,6 +468,8 @@ int hfx_mpi_inters_set_neighbours(hfx_inters *f, int n_seg, const int *peer, con
 int hfx_mpi_inters_send_solution(hfx_inters *f, hfx_comm *c)
 {
   HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_send_solution: bad argument");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_MPI_SEND_SOLUTION, nullptr, f, c, 0, 0);
   if (hfx_mpi_inters_pack_solution(f)) return 1;
   return start_exchange(c, &f, 1, 0, false);
 }
@@ -418,12 +477,16 @@ int hfx_mpi_inters_send_solution(hfx_inters *f, hfx_comm *c)
 int hfx_mpi_inters_receive_solution(hfx_inters *f, hfx_comm *c)
 {
   HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_receive_solution: bad argument");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_MPI_RECEIVE_SOLUTION, nullptr, f, c, 0, 0);
   return wait_exchange(c, 0);
 }
 
 int hfx_mpi_inters_send_corrected_gradient(hfx_inters *f, hfx_comm *c)
 {
   HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_send_corrected_gradient: bad argument");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_MPI_SEND_GRADIENT, nullptr, f, c, 0, 0);
   if (hfx_mpi_inters_pack_corrected_gradient(f)) return 1;
   return start_exchange(c, &f, 1, 1, false);
 }
@@ -431,12 +494,16 @@ int hfx_mpi_inters_send_corrected_gradient(hfx_inters *f, hfx_comm *c)
 int hfx_mpi_inters_receive_corrected_gradient(hfx_inters *f, hfx_comm *c)
 {
   HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_receive_corrected_gradient: bad argument");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_MPI_RECEIVE_GRADIENT, nullptr, f, c, 0, 0);
   return wait_exchange(c, 1);
 }
 
 int hfx_mpi_inters_send_sgsf_fpts(hfx_inters *f, hfx_comm *c)
 {
   HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_send_sgsf_fpts: bad argument");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_MPI_SEND_SGSF, nullptr, f, c, 0, 0);
   if (hfx_mpi_inters_pack_sgsf(f)) return 1;
   return start_exchange(c, &f, 1, 2, false);
 }
@@ -444,6 +511,8 @@ int hfx_mpi_inters_send_sgsf_fpts(hfx_inters *f, hfx_comm *c)
 int hfx_mpi_inters_receive_sgsf_fpts(hfx_inters *f, hfx_comm *c)
 {
   HFX_CHECK(f && f->is_mpi && c, "hfx_mpi_inters_receive_sgsf_fpts: bad argument");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_MPI_RECEIVE_SGSF, nullptr, f, c, 0, 0);
   return wait_exchange(c, 2);
 }
 
@@ -452,6 +521,7 @@ int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_i
 {
   HFX_CHECK(e && comm, "hfx_run_steps_partitioned: NULL argument");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
+  HFX_IMMEDIATE(e->ctx, 0);
   return run_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, comm, n_steps, -1, nullptr);
 }
 
@@ -460,6 +530,7 @@ int hfx_time_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, h
 {
   HFX_CHECK(e && comm && ms && reps > 0, "hfx_time_partitioned: bad argument");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
+  HFX_IMMEDIATE(e->ctx, 0);
   StageTimers T;
   if (T.create()) return 1;
   const int rc = run_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, comm, 0, reps, &T);

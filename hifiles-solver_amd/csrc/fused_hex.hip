@@ -805,6 +805,23 @@ static int shock_capture_keep_fpts(hfx_eles *e)
   return hfx_eles_extrapolate_solution(e);
 }
 
+int split_deferred_prepare(hfx_eles *e, hfx_inters *const *faces, int nfb, bool partitioned)
+{
+  HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
+  if (e->fused && e->fused->built) return 0;
+  return fused_build(e, faces, nfb, partitioned);
+}
+
+int split_deferred_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_step, bool write_div, bool shock)
+{
+  const int variant = split_variant(e); // an LES closure reads the corrected gradients, which variant 3 keeps in registers
+  HFX_CHECK(!e->over_int_ready || variant == 3, "the split variant that keeps the gradients (fused 2, which LES selects) has no over-integration");
+  if (split_deferred_prepare(e, faces, nfb, false)) return 1;
+  if (split_stage(e, faces, nfb, in_step, write_div, 0, variant)) return 1;
+  // the filter changes disu_upts(0) after the stage: redo the flux-point solution of the new state
+  return shock ? shock_capture_keep_fpts(e) : 0;
+}
+
 int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int variant)
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");

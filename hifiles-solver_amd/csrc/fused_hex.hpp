@@ -21,4 +21,15 @@ int split_variant(const hfx_eles *e);
 // one phase of a split-path stage on a partitioned block (see hfx_stage_partitioned)
 int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                             int phase, int in_step, int first);
+// ---- the deferred scheduler's pieces (deferred.hip) ----
+// builds the block's fused tables for these face blocks unless they exist; non-zero (message in hfx_last_error) when the
+// block does not qualify for the split fused stage.  partitioned: flux points without a registered face are partition-face points
+int split_deferred_prepare(hfx_eles *e, hfx_inters *const *faces, int nfb, bool partitioned);
+// ONE stage of the split fused path (the variant split_variant(e) names) on a block whose disu_fpts belongs to the current
+// state; write_div: store div_tconf_upts; shock: shock_capture follows AdvanceSolution (src/HiFiLES.cpp:214-216)
+int split_deferred_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_step, bool write_div, bool shock);
+// the same on a partitioned block with the library's transport (comm.hip); start: this state's flux-point solution has not
+// been sent yet
+int partitioned_stage_deferred(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
+                               hfx_comm *comm, int rk, bool start);
 } // namespace hfx

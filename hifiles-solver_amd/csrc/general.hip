@@ -1108,23 +1108,17 @@ static int launch_element_kernels_t(hfx_eles *e, const GenArgs &a, bool flux)
   if (flux)
   {
     const size_t lds = flux_lds_bytes(g);
-    static size_t configured = 0;
-    if (lds > configured)
-    {
+    // (function attributes are per device: set whenever the image exceeds the default, as launch_dense does -- a cached
+    // "configured" size would be wrong for a second context on another GPU of the same process)
+    if (lds > 48 * 1024)
       HFX_HIP(hipFuncSetAttribute((const void *)general_flux_kernel<W, NUc, NFPc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = lds;
-    }
     hipLaunchKernelGGL((general_flux_kernel<W, NUc, NFPc>), dim3(grid), dim3(64 * W), lds, st, a);
   }
   else
   {
     const size_t lds = update_lds_bytes(g);
-    static size_t configured = 0;
-    if (lds > configured)
-    {
+    if (lds > 48 * 1024)
       HFX_HIP(hipFuncSetAttribute((const void *)general_update_kernel<W, NUc, NFPc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = lds;
-    }
     hipLaunchKernelGGL((general_update_kernel<W, NUc, NFPc>), dim3(grid), dim3(64 * W), lds, st, a);
   }
   HFX_HIP(hipGetLastError());
@@ -1241,6 +1235,17 @@ static int general_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *fa
       if (general_build(eles[i], faces, nfb, eles, neb)) return 1;
   }
   return 0;
+}
+
+int general_deferred_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb)
+{
+  return general_prepare(eles, neb, faces, nfb);
+}
+
+int general_deferred_stage(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool write_div)
+{
+  if (general_prepare(eles, neb, faces, nfb)) return 1; // (no-op unless the registration changed)
+  return general_stage(eles, neb, faces, nfb, in_step, write_div, 0);
 }
 
 int general_run_steps(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int n_steps)

@@ -15,4 +15,8 @@ int general_run_steps(hfx_eles *const *eles, int neb, hfx_inters *const *faces, 
 int general_time_kernels(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int reps, double *ms);
 // algorithmic HBM bytes per launch group, same order
 void general_kernel_bytes(hfx_eles *const *eles, int neb, double *bytes);
+// ---- the deferred scheduler's pieces (deferred.hip): tables for these blocks (non-zero when a block does not qualify), and
+// ONE stage on blocks whose disu_fpts belong to the current state
+int general_deferred_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb);
+int general_deferred_stage(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool write_div);
 } // namespace hfx

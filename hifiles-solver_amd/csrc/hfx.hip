@@ -350,6 +350,7 @@ int hfx_ctx_set_params(hfx_ctx *ctx, const hfx_params *p)
   HFX_CHECK(p->vis_riemann_solve_type == 0, "Viscous Riemann solver not implemented"); /* src/int_inters.cpp:233 */
   HFX_CHECK(p->adv_type >= 0 && p->adv_type <= 4, "ERROR: Time integration type not recognised ... "); /* src/eles.cpp:1262 */
   HFX_CHECK(p->n_rk >= 0 && p->n_rk <= 16, "hfx_ctx_set_params: n_rk out of range");
+  HFX_IMMEDIATE(ctx, 0); // (what has been recorded runs with the parameters it was recorded under)
   ctx->params = *p;
   ctx->have_params = true;
   return 0;
@@ -359,6 +360,7 @@ int hfx_ctx_set_contract_mode(hfx_ctx *ctx, int mode)
 {
   HFX_CHECK(ctx, "NULL ctx");
   HFX_CHECK(mode >= 0 && mode <= 2, "hfx_ctx_set_contract_mode: bad mode %d", mode);
+  HFX_IMMEDIATE(ctx, 0);
   ctx->contract_mode = mode;
   return 0;
 }
@@ -367,6 +369,8 @@ int hfx_ctx_set_fused_mode(hfx_ctx *ctx, int mode)
 {
   HFX_CHECK(ctx, "NULL ctx");
   HFX_CHECK(mode == 2 || mode == 3, "hfx_ctx_set_fused_mode: mode must be 2 (split, the reference's arrays kept) or 3 (split, fluxes in the gradient kernel)");
+  HFX_IMMEDIATE(ctx, 0);
+  ctx->defer.plans.clear();
   ctx->fused_mode = mode;
   return 0;
 }
@@ -375,6 +379,7 @@ int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL)
 {
   HFX_CHECK(ctx, "NULL ctx");
   HFX_CHECK(CFL > 0.0, "hfx_ctx_set_CFL: CFL must be positive");
+  HFX_IMMEDIATE(ctx, 0);
   ctx->CFL = CFL;
   ctx->have_CFL = true;
   return 0;
@@ -383,9 +388,12 @@ int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL)
 int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
 {
   HFX_CHECK(ctx && name, "hfx_ctx_set_option: NULL argument");
+  HFX_IMMEDIATE(ctx, 0);
+  ctx->defer.plans.clear();
   hfx_ctx::Options &o = ctx->opt;
   const std::string n(name);
-  if (n == "split_grid_per_cu") { HFX_CHECK(value >= 0, "split_grid_per_cu must be >= 0"); o.split_grid_per_cu = value; }
+  if (n == "deferred") ctx->defer.on = value != 0;
+  else if (n == "split_grid_per_cu") { HFX_CHECK(value >= 0, "split_grid_per_cu must be >= 0"); o.split_grid_per_cu = value; }
   else if (n == "flux_grid_per_cu") { HFX_CHECK(value >= 0, "flux_grid_per_cu must be >= 0"); o.flux_grid_per_cu = value; }
   else if (n == "xcd_order") o.xcd_order = value != 0;
   else if (n == "dictionary_rows") o.dictionary_rows = value != 0;
@@ -415,7 +423,23 @@ int hfx_ctx_get_dt(hfx_ctx *ctx, double *dt)
 int hfx_ctx_synchronize(hfx_ctx *ctx)
 {
   HFX_CHECK(ctx, "NULL ctx");
+  HFX_IMMEDIATE(ctx, 0);
   HFX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int hfx_ctx_flush(hfx_ctx *ctx)
+{
+  HFX_CHECK(ctx, "NULL ctx");
+  return defer_flush(ctx, 0);
+}
+
+int hfx_ctx_deferred_stats(hfx_ctx *ctx, long *n_fused, long *n_replayed, const char **why)
+{
+  HFX_CHECK(ctx, "NULL ctx");
+  if (n_fused) *n_fused = ctx->defer.n_fused;
+  if (n_replayed) *n_replayed = ctx->defer.n_replayed;
+  if (why) *why = ctx->defer.last_why.c_str();
   return 0;
 }
 
@@ -430,6 +454,8 @@ int hfx_eles_create(hfx_ctx *ctx, const hfx_eles_desc *d, hfx_eles **out)
   HFX_CHECK(d->n_eles >= 0 && d->n_upts > 0 && d->n_fpts > 0, "hfx_eles_create: bad sizes");
   HFX_CHECK(d->opp_0 && d->opp_3 && d->detjac_upts && d->JGinv_upts && d->tdA_fpts && d->norm_fpts,
             "hfx_eles_create: missing operator or metric");
+  HFX_IMMEDIATE(ctx, 0);
+  ctx->defer.plans.clear();
   HFX_HIP(hipSetDevice(ctx->device));
   hfx_eles *e = new hfx_eles();
   e->ctx = ctx;
@@ -494,6 +520,12 @@ int hfx_eles_create(hfx_ctx *ctx, const hfx_eles_desc *d, hfx_eles **out)
 int hfx_eles_destroy(hfx_eles *e)
 {
   if (!e) return 0;
+  {
+    // (a record that still names this block cannot run any more: drop it with the plans that point here)
+    hfx::Deferred &d = e->ctx->defer;
+    d.log.clear();
+    d.plans.clear();
+  }
   free_operator(e->opp_0); free_operator(e->opp_3); free_operator(e->opp_6);
   free_operator(e->inv_vandermonde); free_operator(e->exp_filter);
   free_operator(e->opp_over_int_cubpts); free_operator(e->over_int_filter);
@@ -534,6 +566,9 @@ int hfx_eles_upload(hfx_eles *e, int id, const double *host)
 {
   HFX_CHECK(e && host, "hfx_eles_upload: NULL argument");
   HFX_CHECK(id >= 0 && id < HFX_N_ARRAYS, "hfx_eles_upload: bad array id %d", id);
+  HFX_IMMEDIATE(e->ctx, 0);
+  if (id == HFX_DISU_UPTS0 || id == HFX_DISU_FPTS) invalidate_fpts(e);
+  e->stale &= ~(1u << id);
   if (!e->arr[id]) HFX_HIP(hipMalloc((void **)&e->arr[id], sizeof(double) * (size_t)std::max<long>(e->arr_len[id], 1)));
   HFX_HIP(hipStreamSynchronize(e->ctx->stream));
   HFX_HIP(hipMemcpy(e->arr[id], host, sizeof(double) * (size_t)e->arr_len[id], hipMemcpyHostToDevice));
@@ -546,6 +581,10 @@ int hfx_eles_download(hfx_eles *e, int id, double *host)
   HFX_CHECK(e && host, "hfx_eles_download: NULL argument");
   HFX_CHECK(id >= 0 && id < HFX_N_ARRAYS, "hfx_eles_download: bad array id %d", id);
   HFX_CHECK(e->arr[id] != nullptr, "hfx_eles_download: array %d was never uploaded", id);
+  HFX_IMMEDIATE(e->ctx, 1u << id);
+  HFX_CHECK(!(e->ctx->defer.on && (e->stale & (1u << id))),
+            "hfx_eles_download: array %d was not materialised by the fused stage that ran last (deferred execution): read it before the "
+            "next stage begins, or switch the option \"deferred\" off", id);
   HFX_HIP(hipStreamSynchronize(e->ctx->stream));
   HFX_HIP(hipMemcpy(host, e->arr[id], sizeof(double) * (size_t)e->arr_len[id], hipMemcpyDeviceToHost));
   return 0;
@@ -555,6 +594,8 @@ int hfx_eles_device_ptr(hfx_eles *e, int id, double **dev)
 {
   HFX_CHECK(e && dev, "hfx_eles_device_ptr: NULL argument");
   HFX_CHECK(id >= 0 && id < HFX_N_ARRAYS, "hfx_eles_device_ptr: bad array id %d", id);
+  HFX_IMMEDIATE(e->ctx, 1u << id);
+  if (id == HFX_DISU_UPTS0 || id == HFX_DISU_FPTS) invalidate_fpts(e); // (the caller may write through the pointer)
   *dev = e->arr[id];
   return 0;
 }
@@ -564,6 +605,9 @@ int hfx_eles_extrapolate_solution(hfx_eles *e)
 {
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0; /* src/eles.cpp:1362 */
+  HFX_DEFER(e->ctx, DM_EXTRAPOLATE_SOLUTION, e, nullptr, nullptr, 0, 0);
+  e->fpts_valid = true;
+  e->stale &= ~(1u << HFX_DISU_FPTS);
   const Operator *ops[1] = {&e->opp_0};
   const double *in[1] = {e->arr[HFX_DISU_UPTS0]};
   return contract_multi_in(e->ctx, ops, 1, in, e->arr[HFX_DISU_FPTS], (long)e->n_eles * e->n_fields, 0);
@@ -574,6 +618,8 @@ int hfx_eles_calculate_gradient(hfx_eles *e)
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
   HFX_CHECK(e->viscous_ops, "calculate_gradient: block was registered without opp_4");
+  HFX_DEFER(e->ctx, DM_CALCULATE_GRADIENT, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~(1u << HFX_GRAD_DISU_UPTS);
   const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
   const Operator *ops[3] = {&e->opp_4[0], &e->opp_4[1], &e->opp_4[2]};
   double *out[3] = {e->arr[HFX_GRAD_DISU_UPTS], e->arr[HFX_GRAD_DISU_UPTS] + slab, e->arr[HFX_GRAD_DISU_UPTS] + 2 * slab};
@@ -585,6 +631,8 @@ int hfx_eles_evaluate_invFlux(hfx_eles *e)
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
   HFX_CHECK(e->ctx->have_params, "parameters not set");
+  HFX_DEFER(e->ctx, DM_EVALUATE_INVFLUX, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~(1u << HFX_TDISF_UPTS);
   const long plane = (long)e->n_upts * e->n_eles;
   if (e->n_dims == 2)
     hipLaunchKernelGGL(invflux_kernel<2>, dim3(nblocks(plane, PT_BLOCK)), dim3(PT_BLOCK), 0, e->ctx->stream, plane,
@@ -602,6 +650,8 @@ int hfx_eles_correct_gradient(hfx_eles *e)
   if (e->n_eles == 0) return 0;
   HFX_CHECK(e->viscous_ops, "correct_gradient: block was registered without opp_5/opp_6");
   hfx_ctx *ctx = e->ctx;
+  HFX_DEFER(ctx, DM_CORRECT_GRADIENT, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~((1u << HFX_GRAD_DISU_UPTS) | (1u << HFX_GRAD_DISU_FPTS));
   const long slab_u = (long)e->n_upts * e->n_eles * e->n_fields;
   const long ncols = (long)e->n_eles * e->n_fields;
   // (i) grad_disu_upts(:,:,:,d) += opp_5[d] * delta_disu_fpts
@@ -641,6 +691,8 @@ int hfx_eles_evaluate_viscFlux(hfx_eles *e)
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
   HFX_CHECK(e->ctx->have_params, "parameters not set");
+  HFX_DEFER(e->ctx, DM_EVALUATE_VISCFLUX, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~((1u << HFX_TDISF_UPTS) | (1u << HFX_SGSF_UPTS));
   const long plane = (long)e->n_upts * e->n_eles;
   const Phys P = e->ctx->phys();
   if (e->les_ready)
@@ -670,6 +722,8 @@ int hfx_eles_extrapolate_totalFlux(hfx_eles *e)
 {
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
+  HFX_DEFER(e->ctx, DM_EXTRAPOLATE_TOTALFLUX, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~(1u << HFX_NORM_TDISF_FPTS);
   const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
   const Operator *ops[3] = {&e->opp_1[0], &e->opp_1[1], &e->opp_1[2]};
   const double *in[3] = {e->arr[HFX_TDISF_UPTS], e->arr[HFX_TDISF_UPTS] + slab, e->arr[HFX_TDISF_UPTS] + 2 * slab};
@@ -680,6 +734,8 @@ int hfx_eles_calculate_divergence(hfx_eles *e)
 {
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
+  HFX_DEFER(e->ctx, DM_CALCULATE_DIVERGENCE, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~(1u << HFX_DIV_TCONF_UPTS);
   const long slab = (long)e->n_upts * e->n_eles * e->n_fields;
   const Operator *ops[3] = {&e->opp_2[0], &e->opp_2[1], &e->opp_2[2]};
   const double *in[3] = {e->arr[HFX_TDISF_UPTS], e->arr[HFX_TDISF_UPTS] + slab, e->arr[HFX_TDISF_UPTS] + 2 * slab};
@@ -690,6 +746,8 @@ int hfx_eles_calculate_corrected_divergence(hfx_eles *e)
 {
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
+  HFX_DEFER(e->ctx, DM_CORRECTED_DIVERGENCE, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~((1u << HFX_DIV_TCONF_UPTS) | (1u << HFX_NORM_TCONF_FPTS));
   // norm_tconf -= norm_tdisf (overwriting norm_tconf, src/eles.cpp:1746) is fused into the tile load;
   // div_tconf += opp_3 * norm_tconf; NaN scan -> device flag
   const Operator *ops[1] = {&e->opp_3};
@@ -707,6 +765,8 @@ int hfx_eles_AdvanceSolution(hfx_eles *e, int in_step, int adv_type)
   HFX_CHECK(adv_type >= 0 && adv_type <= 4, "ERROR: Time integration type not recognised ... ");
   const int nst = (adv_type == 0) ? 1 : (adv_type <= 2) ? 4 : (adv_type == 3) ? 5 : 14;
   HFX_CHECK(in_step >= 0 && in_step < nst, "AdvanceSolution: stage %d out of range for adv_type %d", in_step, adv_type);
+  HFX_DEFER(ctx, DM_ADVANCE_SOLUTION, e, nullptr, nullptr, in_step, adv_type);
+  invalidate_fpts(e);
   AdvArgs a;
   a.n = (long)e->n_upts * e->n_eles * e->n_fields;
   a.plane = (long)e->n_upts * e->n_eles;
@@ -732,6 +792,7 @@ int hfx_eles_AdvanceSolution(hfx_eles *e, int in_step, int adv_type)
 int hfx_eles_check_nan(hfx_eles *e, long *first_nan)
 {
   HFX_CHECK(e && first_nan, "NULL argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   unsigned long long v = 0;
   HFX_HIP(hipStreamSynchronize(e->ctx->stream));
   HFX_HIP(hipMemcpy(&v, e->nan_flag, sizeof v, hipMemcpyDeviceToHost));
@@ -745,6 +806,10 @@ int hfx_eles_compute_res_upts(hfx_eles *e, int norm_type, int field, double *out
   HFX_CHECK(e && out, "NULL argument");
   HFX_CHECK(norm_type >= 0 && norm_type <= 2, "compute_res_upts: bad norm type");
   HFX_CHECK(field >= 0 && field < e->n_fields, "compute_res_upts: bad field");
+  HFX_IMMEDIATE(e->ctx, 1u << HFX_DIV_TCONF_UPTS);
+  HFX_CHECK(!(e->ctx->defer.on && (e->stale & (1u << HFX_DIV_TCONF_UPTS))),
+            "compute_res_upts: div_tconf_upts was not stored by the fused stage that ran last (deferred execution stores it at the last "
+            "stage of a step, or when asked before the next stage begins)");
   const long plane = (long)e->n_upts * e->n_eles;
   const int nb = (int)std::min<long>(e->red_blocks, std::max<long>(1, (plane + PT_BLOCK - 1) / PT_BLOCK));
   hipLaunchKernelGGL(res_partial_kernel, dim3(nb), dim3(PT_BLOCK), 0, e->ctx->stream, plane, norm_type,
@@ -765,6 +830,8 @@ int hfx_int_inters_create(hfx_ctx *ctx, hfx_eles *left, hfx_eles *right, int n_i
                           const int *R, hfx_inters **out)
 {
   HFX_CHECK(ctx && left && right && out, "hfx_int_inters_create: NULL argument");
+  HFX_IMMEDIATE(ctx, 0);
+  ctx->defer.plans.clear();
   HFX_CHECK(n_inters >= 0 && nfpi > 0, "hfx_int_inters_create: bad sizes");
   HFX_CHECK(n_inters == 0 || (L && R), "hfx_int_inters_create: NULL table");
   HFX_CHECK(left->n_dims == right->n_dims && left->n_fields == right->n_fields, "left/right blocks differ in n_dims");
@@ -806,6 +873,9 @@ int hfx_int_inters_create(hfx_ctx *ctx, hfx_eles *left, hfx_eles *right, int n_i
 int hfx_inters_destroy(hfx_inters *f)
 {
   if (!f) return 0;
+  // (a record that still names this block cannot run any more: drop it with the plans that point here)
+  f->ctx->defer.log.clear();
+  f->ctx->defer.plans.clear();
   for (hfx_eles *e : {f->left, f->right})
     if (e)
     {
@@ -828,6 +898,8 @@ int hfx_inters_destroy(hfx_inters *f)
 int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distance, const double *Jacobian_fpts)
 {
   HFX_CHECK(e && les && Jacobian_fpts, "hfx_eles_set_les: NULL argument");
+  HFX_IMMEDIATE(e->ctx, 0);
+  e->ctx->defer.plans.clear();
   HFX_CHECK(les->sgs_model >= 0 && les->sgs_model <= 4, "SGS model not implemented"); /* src/eles.cpp:2461 */
   HFX_CHECK(les->sgs_model != 0 || wall_distance, "hfx_eles_set_les: the Smagorinsky model needs wall_distance");
   HFX_CHECK(e->viscous_ops, "LES not supported with inviscid flow"); /* src/input.cpp:570 */
@@ -852,6 +924,8 @@ int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distanc
 int hfx_eles_set_les_filter(hfx_eles *e, const double *filter_upts)
 {
   HFX_CHECK(e && filter_upts, "hfx_eles_set_les_filter: NULL argument");
+  HFX_IMMEDIATE(e->ctx, 0);
+  e->ctx->defer.plans.clear();
   free_operator(e->filter_upts);
   if (make_operator(e->filter_upts, filter_upts, e->n_upts, e->n_upts)) return 1;
   for (int id : {HFX_DISUF_UPTS, HFX_LU, HFX_LE})
@@ -876,6 +950,9 @@ int hfx_eles_calc_sgs_terms(hfx_eles *e)
   if (model < 2) return 0; /* src/solver.cpp:57 */
   HFX_CHECK(e->filter_upts.present(), "calc_sgs_terms: SGS model %d filters the solution: register filter_upts (hfx_eles_set_les_filter)", model);
   hfx_ctx *ctx = e->ctx;
+  HFX_DEFER(ctx, DM_CALC_SGS_TERMS, e, nullptr, nullptr, 0, 0);
+  if (model == 3) invalidate_fpts(e); // (the filtered solution replaces the state)
+  e->stale &= ~((1u << HFX_DISUF_UPTS) | (1u << HFX_LU) | (1u << HFX_LE));
   hipStream_t st = ctx->stream;
   const long plane = (long)e->n_upts * e->n_eles;
   const Operator *ops[1] = {&e->filter_upts};
@@ -943,6 +1020,8 @@ int hfx_eles_extrapolate_sgsFlux(hfx_eles *e)
   HFX_CHECK(e, "NULL eles");
   if (e->n_eles == 0) return 0;
   HFX_CHECK(e->les_ready, "extrapolate_sgsFlux: hfx_eles_set_les was not called");
+  HFX_DEFER(e->ctx, DM_EXTRAPOLATE_SGSFLUX, e, nullptr, nullptr, 0, 0);
+  e->stale &= ~(1u << HFX_SGSF_FPTS);
   // sgsf_fpts(:,:,:,d) = opp_0 * sgsf_upts(:,:,:,d): the dim slabs are contiguous -> one launch
   {
     const Operator *ops[1] = {&e->opp_0};
@@ -966,6 +1045,7 @@ int hfx_eles_set_volume_cubpts(hfx_eles *e, int n_cubpts, const double *opp_volu
 {
   HFX_CHECK(e && opp_volume_cubpts && weight_volume_cubpts && vol_detjac_vol_cubpts && n_cubpts > 0,
             "hfx_eles_set_volume_cubpts: bad argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   free_operator(e->opp_volume_cubpts);
   for (double **p : {&e->weight_volume_cubpts, &e->vol_detjac_vol_cubpts, &e->iq_u, &e->iq_g})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -979,6 +1059,7 @@ int hfx_eles_set_volume_cubpts(hfx_eles *e, int n_cubpts, const double *opp_volu
 int hfx_eles_CalcIntegralQuantities(hfx_eles *e, int n_q, const int *quantity_ids, double *integral_quantities)
 {
   HFX_CHECK(e && quantity_ids && integral_quantities, "hfx_eles_CalcIntegralQuantities: NULL argument");
+  HFX_IMMEDIATE(e->ctx, (1u << HFX_DISU_UPTS0) | (1u << HFX_GRAD_DISU_UPTS));
   HFX_CHECK(n_q >= 0 && n_q <= IQ_MAX, "hfx_eles_CalcIntegralQuantities: at most %d quantities per call", IQ_MAX);
   if (e->n_eles == 0 || n_q == 0) return 0;
   HFX_CHECK(e->opp_volume_cubpts.dense, "CalcIntegralQuantities: hfx_eles_set_volume_cubpts was not called");
@@ -1027,6 +1108,7 @@ int hfx_eles_CalcIntegralQuantities(hfx_eles *e, int n_q, const int *quantity_id
 int hfx_eles_set_h_ref(hfx_eles *e, const double *h_ref)
 {
   HFX_CHECK(e && h_ref, "hfx_eles_set_h_ref: NULL argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   if (e->h_ref) (void)hipFree(e->h_ref);
   if (e->wall_distance) (void)hipFree(e->wall_distance);
   if (e->Jacobian_fpts) (void)hipFree(e->Jacobian_fpts);
@@ -1037,6 +1119,7 @@ int hfx_eles_set_h_ref(hfx_eles *e, const double *h_ref)
 int hfx_eles_calc_dt_local(hfx_eles *e, double CFL, double *dt_min)
 {
   HFX_CHECK(e && dt_min, "hfx_eles_calc_dt_local: NULL argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   *dt_min = 1e12; /* src/solver.cpp:490 */
   if (e->n_eles == 0) return 0;
@@ -1062,6 +1145,7 @@ int hfx_eles_calc_dt_local(hfx_eles *e, double CFL, double *dt_min)
 int hfx_eles_set_opp_p(hfx_eles *e, int n_ppts, const double *opp_p)
 {
   HFX_CHECK(e && opp_p && n_ppts > 0, "hfx_eles_set_opp_p: bad argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   free_operator(e->opp_p);
   if (e->disu_ppts) { (void)hipFree(e->disu_ppts); e->disu_ppts = nullptr; }
   if (make_operator(e->opp_p, opp_p, n_ppts, e->n_upts)) return 1;
@@ -1073,6 +1157,7 @@ int hfx_eles_set_opp_p(hfx_eles *e, int n_ppts, const double *opp_p)
 int hfx_eles_calc_disu_ppts(hfx_eles *e, double *host)
 {
   HFX_CHECK(e && host, "hfx_eles_calc_disu_ppts: NULL argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   if (e->n_eles == 0) return 0; /* src/eles.cpp:3759 */
   HFX_CHECK(e->n_ppts > 0, "calc_disu_ppts: hfx_eles_set_opp_p was not called");
   hfx_ctx *ctx = e->ctx;
@@ -1091,6 +1176,8 @@ int hfx_eles_set_over_int(hfx_eles *e, int n_cubpts, const double *opp_over_int_
 {
   HFX_CHECK(e && opp_over_int_cubpts && over_int_filter && JGinv_over_int_cubpts && n_cubpts > 0,
             "hfx_eles_set_over_int: bad argument");
+  HFX_IMMEDIATE(e->ctx, 0);
+  e->ctx->defer.plans.clear();
   free_operator(e->opp_over_int_cubpts);
   free_operator(e->over_int_filter);
   for (double **p : {&e->JGinv_over_int_cubpts, &e->u_cub, &e->t_cub})
@@ -1115,6 +1202,8 @@ int hfx_eles_evaluate_invFlux_over_int(hfx_eles *e)
   HFX_CHECK(e->over_int_ready, "evaluate_invFlux_over_int: hfx_eles_set_over_int was not called");
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   hfx_ctx *ctx = e->ctx;
+  HFX_DEFER(ctx, DM_EVALUATE_INVFLUX, e, nullptr, nullptr, 1, 0);
+  e->stale &= ~(1u << HFX_TDISF_UPTS);
   if (tensor_over_int_available(e) && ctx->contract_mode != HFX_CONTRACT_DENSE) return tensor_over_int_launch(e);
   // interpolate the solution to the over-integration cubature points
   {
@@ -1145,6 +1234,8 @@ int hfx_eles_set_shock_capture(hfx_eles *e, const double *inv_vandermonde, const
                                const double *norm_basis_persson, const int *high_modes, double s0, int shock_det_field)
 {
   HFX_CHECK(e && inv_vandermonde && exp_filter && norm_basis_persson && high_modes, "hfx_eles_set_shock_capture: NULL argument");
+  HFX_IMMEDIATE(e->ctx, 0);
+  e->ctx->defer.plans.clear();
   HFX_CHECK(shock_det_field == 0 || shock_det_field == 1, "Unsupported shock capturing field."); /* src/eles_hexas.cpp:1034 */
   free_operator(e->inv_vandermonde);
   free_operator(e->exp_filter);
@@ -1173,6 +1264,9 @@ int hfx_eles_shock_capture(hfx_eles *e)
   if (e->n_eles == 0) return 0; /* src/eles.cpp:2920 */
   HFX_CHECK(e->shock_ready, "shock_capture: hfx_eles_set_shock_capture was not called");
   hfx_ctx *ctx = e->ctx;
+  HFX_DEFER(ctx, DM_SHOCK_CAPTURE, e, nullptr, nullptr, 0, 0);
+  invalidate_fpts(e);
+  e->stale &= ~(1u << HFX_SENSOR);
   if (tensor_shock_available(e) && ctx->contract_mode != HFX_CONTRACT_DENSE) return tensor_shock_launch(e);
   const long plane = (long)e->n_upts * e->n_eles;
   double *scratch = e->arr[HFX_TDISF_UPTS]; // free between AdvanceSolution and the next stage's evaluate_invFlux
@@ -1203,6 +1297,8 @@ int hfx_bdy_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, 
                           const hfx_bc *bcs, int n_bcs, double R_ref, hfx_inters **out)
 {
   HFX_CHECK(ctx && left && out, "hfx_bdy_inters_create: NULL argument");
+  HFX_IMMEDIATE(ctx, 0);
+  ctx->defer.plans.clear();
   HFX_CHECK(n_inters >= 0 && nfpi > 0 && n_bcs >= 0, "hfx_bdy_inters_create: bad sizes");
   HFX_CHECK(n_inters == 0 || (L && boundary_id && bcs && n_bcs > 0), "hfx_bdy_inters_create: NULL table");
   const long np = (long)n_inters * nfpi;
@@ -1243,6 +1339,13 @@ int hfx_bdy_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, 
 int hfx_bdy_inters_set_ramp_counter(hfx_inters *f, int ramp_counter)
 {
   HFX_CHECK(f && f->is_bdy, "not a boundary-face block");
+  {
+    // between two time steps (src/HiFiLES.cpp:224-225): behind a recorded stage the new value waits for that stage to run
+    hfx::Deferred &d = f->ctx->defer;
+    if (d.on && !d.busy && !d.log.empty() && d.log.back().method >= DM_ADVANCE_SOLUTION)
+      return defer_record(f->ctx, DM_SET_RAMP_COUNTER, nullptr, f, nullptr, ramp_counter, 0);
+  }
+  HFX_IMMEDIATE(f->ctx, 0);
   f->ramp_counter = ramp_counter;
   return 0;
 }
@@ -1292,14 +1395,29 @@ int hfx_bdy_launch_internal(hfx_inters *f, int visc, int fast)
   return 0;
 }
 
-int hfx_bdy_inters_evaluate_boundaryConditions_invFlux(hfx_inters *f, double /*time_bound*/) { return hfx_bdy_launch_internal(f, 0, 0); }
-int hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(hfx_inters *f, double /*time_bound*/) { return hfx_bdy_launch_internal(f, 1, 0); }
+int hfx_bdy_inters_evaluate_boundaryConditions_invFlux(hfx_inters *f, double /*time_bound*/)
+{
+  HFX_CHECK(f && f->is_bdy, "not a boundary-face block");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_BDY_INVFLUX, nullptr, f, nullptr, 0, 0);
+  f->left->stale &= ~((1u << HFX_NORM_TCONF_FPTS) | (1u << HFX_DELTA_DISU_FPTS));
+  return hfx_bdy_launch_internal(f, 0, 0);
+}
+int hfx_bdy_inters_evaluate_boundaryConditions_viscFlux(hfx_inters *f, double /*time_bound*/)
+{
+  HFX_CHECK(f && f->is_bdy, "not a boundary-face block");
+  if (f->n_inters == 0) return 0;
+  HFX_DEFER(f->ctx, DM_BDY_VISCFLUX, nullptr, f, nullptr, 0, 0);
+  return hfx_bdy_launch_internal(f, 1, 0);
+}
 
 // ---- mpi_inters ----------------------------------------------------------------------
 int hfx_mpi_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int nfpi, const int *L, const int *Rlut,
                           hfx_inters **out)
 {
   HFX_CHECK(ctx && left && out, "hfx_mpi_inters_create: NULL argument");
+  HFX_IMMEDIATE(ctx, 0);
+  ctx->defer.plans.clear();
   HFX_CHECK(n_inters >= 0 && nfpi > 0, "hfx_mpi_inters_create: bad sizes");
   HFX_CHECK(n_inters == 0 || (L && Rlut), "hfx_mpi_inters_create: NULL table");
   const long np = (long)n_inters * nfpi;
@@ -1362,12 +1480,16 @@ extern "C" int hfx_mpi_sgsf_buffers_internal(hfx_inters *f)
   return 0;
 }
 
-#define HFX_MPI_LAUNCH(KERNEL2, KERNEL3)                                                                    \
+// METHOD: the DeferMethod of a recordable call, or -1 for the packing halves (not part of the reference's call sequence:
+// what has been recorded runs first)
+#define HFX_MPI_LAUNCH(METHOD, KERNEL2, KERNEL3)                                                            \
   do                                                                                                        \
   {                                                                                                         \
     HFX_CHECK(f && f->is_mpi, "not a partition-face block");                                                \
     if (f->n_inters == 0) return 0;                                                                         \
     HFX_CHECK(f->ctx->have_params, "parameters not set");                                                   \
+    if ((METHOD) >= 0) { HFX_DEFER(f->ctx, METHOD, nullptr, f, nullptr, 0, 0); }                            \
+    HFX_IMMEDIATE(f->ctx, 0);                                                                               \
     if (hfx_mpi_sgsf_buffers_internal(f)) return 1;                                                         \
     const MpiArgs a = mpi_args(f);                                                                          \
     if (f->left->n_dims == 2)                                                                               \
@@ -1378,25 +1500,26 @@ extern "C" int hfx_mpi_sgsf_buffers_internal(hfx_inters *f)
     return 0;                                                                                               \
   } while (0)
 
-int hfx_mpi_inters_pack_solution(hfx_inters *f) { HFX_MPI_LAUNCH(mpi_pack_disu_kernel<2>, mpi_pack_disu_kernel<3>); }
-int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f) { HFX_MPI_LAUNCH(mpi_pack_grad_kernel<2>, mpi_pack_grad_kernel<3>); }
+int hfx_mpi_inters_pack_solution(hfx_inters *f) { HFX_MPI_LAUNCH(-1, mpi_pack_disu_kernel<2>, mpi_pack_disu_kernel<3>); }
+int hfx_mpi_inters_pack_corrected_gradient(hfx_inters *f) { HFX_MPI_LAUNCH(-1, mpi_pack_grad_kernel<2>, mpi_pack_grad_kernel<3>); }
 int hfx_mpi_inters_pack_sgsf(hfx_inters *f)
 {
   HFX_CHECK(f && f->is_mpi && f->left->les_ready, "hfx_mpi_inters_pack_sgsf: the left block has no LES closure (hfx_eles_set_les)");
-  HFX_MPI_LAUNCH(mpi_pack_sgsf_kernel<2>, mpi_pack_sgsf_kernel<3>);
+  HFX_MPI_LAUNCH(-1, mpi_pack_sgsf_kernel<2>, mpi_pack_sgsf_kernel<3>);
 }
 int hfx_mpi_inters_calculate_common_invFlux(hfx_inters *f)
 {
-  HFX_MPI_LAUNCH((mpi_common_invflux_kernel<2, false>), (mpi_common_invflux_kernel<3, false>));
+  HFX_MPI_LAUNCH(DM_MPI_COMMON_INVFLUX, (mpi_common_invflux_kernel<2, false>), (mpi_common_invflux_kernel<3, false>));
 }
 int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f)
 {
-  HFX_MPI_LAUNCH((mpi_common_viscflux_kernel<2, false>), (mpi_common_viscflux_kernel<3, false>));
+  HFX_MPI_LAUNCH(DM_MPI_COMMON_VISCFLUX, (mpi_common_viscflux_kernel<2, false>), (mpi_common_viscflux_kernel<3, false>));
 }
 
 int hfx_mpi_inters_buffer(hfx_inters *f, int which, double **dev, long *n)
 {
   HFX_CHECK(f && f->is_mpi && dev && n, "hfx_mpi_inters_buffer: bad argument");
+  HFX_IMMEDIATE(f->ctx, 0);
   HFX_CHECK(which >= 0 && which <= 7, "hfx_mpi_inters_buffer: which must be 0..7");
   if (which >= 6)
   {
@@ -1414,6 +1537,7 @@ int hfx_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, 
                           int phase, int in_step, int first)
 {
   HFX_CHECK(e, "NULL eles");
+  HFX_IMMEDIATE(e->ctx, 0);
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   HFX_CHECK(phase >= 0 && phase <= 4, "hfx_stage_partitioned: phase must be 0..4");
   return split_stage_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, phase, in_step, first);
@@ -1443,6 +1567,8 @@ int hfx_int_inters_calculate_common_invFlux(hfx_inters *f)
   HFX_CHECK(f, "NULL inters");
   if (f->n_inters == 0) return 0;
   HFX_CHECK(f->ctx->have_params, "parameters not set");
+  HFX_DEFER(f->ctx, DM_INT_COMMON_INVFLUX, nullptr, f, nullptr, 0, 0);
+  for (hfx_eles *x : {f->left, f->right}) x->stale &= ~((1u << HFX_NORM_TCONF_FPTS) | (1u << HFX_DELTA_DISU_FPTS));
   const FaceArgs a = face_args(f);
   const Phys P = f->ctx->phys();
   if (f->left->n_dims == 2)
@@ -1458,6 +1584,7 @@ int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f)
   HFX_CHECK(f, "NULL inters");
   if (f->n_inters == 0) return 0;
   HFX_CHECK(f->ctx->have_params, "parameters not set");
+  HFX_DEFER(f->ctx, DM_INT_COMMON_VISCFLUX, nullptr, f, nullptr, 0, 0);
   const FaceArgs a = face_args(f);
   const Phys P = f->ctx->phys();
   if (f->left->n_dims == 2)
@@ -1472,6 +1599,7 @@ int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f)
 int hfx_CalcResidual_blocks(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb)
 {
   HFX_CHECK(eles && neb > 0, "hfx_CalcResidual_blocks: no element blocks");
+  HFX_IMMEDIATE(eles[0]->ctx, 0);
   hfx_ctx *ctx = eles[0]->ctx;
   for (int i = 0; i < neb; i++) HFX_CHECK(eles[i] && eles[i]->ctx == ctx, "element blocks of different contexts");
   HFX_CHECK(ctx->have_params, "parameters not set");
@@ -1544,6 +1672,7 @@ static int calc_time_step_blocks(hfx_eles *const *eles, int neb)
 int hfx_run_steps_blocks(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int n_steps, int fused)
 {
   HFX_CHECK(eles && neb > 0 && eles[0], "hfx_run_steps_blocks: no element blocks");
+  HFX_IMMEDIATE(eles[0]->ctx, 0);
   hfx_ctx *ctx = eles[0]->ctx;
   HFX_CHECK(ctx->have_params, "parameters not set");
   const int adv = ctx->params.adv_type;
@@ -1582,6 +1711,7 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, i
 int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double ms[HFX_N_TIMED_METHODS])
 {
   HFX_CHECK(e && ms && reps > 0, "hfx_time_methods: bad argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   hipStream_t st = e->ctx->stream;
   const int adv = e->ctx->params.adv_type;
@@ -1635,6 +1765,7 @@ int hfx_time_methods(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, d
 int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps, double ms[8], char names[256])
 {
   HFX_CHECK(e && ms && names && reps > 0, "hfx_time_fused_kernels: bad argument");
+  HFX_IMMEDIATE(e->ctx, 0);
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   return split_time_kernels(e, faces, nfb, reps, ms, names, 256, e->ctx->fused_mode);
 }
@@ -1642,6 +1773,7 @@ int hfx_time_fused_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int r
 int hfx_time_general_kernels(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int reps, double ms[8], char names[256])
 {
   HFX_CHECK(eles && neb > 0 && ms && names && reps > 0, "hfx_time_general_kernels: bad argument");
+  HFX_IMMEDIATE(eles[0]->ctx, 0);
   HFX_CHECK(eles[0]->ctx->have_params, "parameters not set");
   snprintf(names, 256, "gface_delta_kernel,general_flux_kernel,gface_flux_kernel,general_update_kernel");
   return general_time_kernels(eles, neb, faces, nfb, reps, ms);

@@ -59,6 +59,55 @@ struct Operator
 } // namespace hfx
 
 struct hfx_inters;
+struct hfx_comm;
+
+namespace hfx
+{
+// ---- deferred execution (deferred.hip) -------------------------------------------------------------------------------
+// With the option "deferred" the per-method entry points -- the calls CalcResidual (src/solver.cpp:59-221) and the RK loop
+// (src/HiFiLES.cpp:201-217) make -- are RECORDED instead of launched.  When the record is complete (the next stage begins,
+// or any other entry point needs the device state) it is compared with CalcResidual's canonical order: a whole stage runs as
+// the split / general / partitioned fused stage, anything else is replayed call by call.
+enum DeferMethod
+{
+  DM_CALC_SGS_TERMS = 0, DM_EXTRAPOLATE_SOLUTION, DM_MPI_SEND_SOLUTION, DM_CALCULATE_GRADIENT, DM_EVALUATE_INVFLUX,
+  DM_INT_COMMON_INVFLUX, DM_BDY_INVFLUX, DM_MPI_RECEIVE_SOLUTION, DM_MPI_COMMON_INVFLUX, DM_CORRECT_GRADIENT,
+  DM_MPI_SEND_GRADIENT, DM_EVALUATE_VISCFLUX, DM_EXTRAPOLATE_SGSFLUX, DM_MPI_SEND_SGSF, DM_EXTRAPOLATE_TOTALFLUX,
+  DM_CALCULATE_DIVERGENCE, DM_INT_COMMON_VISCFLUX, DM_BDY_VISCFLUX, DM_MPI_RECEIVE_GRADIENT, DM_MPI_RECEIVE_SGSF,
+  DM_MPI_COMMON_VISCFLUX, DM_CORRECTED_DIVERGENCE, DM_ADVANCE_SOLUTION, DM_SHOCK_CAPTURE, DM_N_METHODS,
+  // not a method of the stage: `run_input.ramp_counter++` between two time steps (src/HiFiLES.cpp:224-225).  Recorded behind a
+  // whole stage so that it does not force that stage to run before the caller has said what it wants of it; applied after it
+  DM_SET_RAMP_COUNTER = DM_N_METHODS
+};
+struct DeferCall
+{
+  int method = 0;         // DeferMethod; the enumeration is in CalcResidual's order, so it doubles as the call's phase
+  hfx_eles *e = nullptr;  // element-block methods
+  hfx_inters *f = nullptr; // face-block methods
+  hfx_comm *c = nullptr;  // send_* / receive_*
+  int i0 = 0, i1 = 0;     // AdvanceSolution: in_step, adv_type; evaluate_invFlux: 1 = the over-integration form; ramp counter: value
+};
+struct DeferPlan
+{
+  std::vector<DeferCall> signature; // the record this plan was made for (methods and objects; stage number excluded)
+  int kind = 0;                     // 0 replay, 1 split fused stage, 2 partitioned split stage, 3 general fused stage
+  std::string why;                  // kind 0: why the record is not run as a fused stage
+  std::vector<hfx_eles *> eles;
+  std::vector<hfx_inters *> faces, mpi_faces; // interior + boundary blocks | partition-face blocks
+  hfx_comm *comm = nullptr;
+  bool sgs_terms = false, shock = false;
+};
+struct Deferred
+{
+  bool on = false;   // option "deferred"
+  bool busy = false; // a flush / replay / immediate entry point is running: calls execute at once
+  std::vector<DeferCall> log;
+  std::vector<DeferPlan> plans; // one per distinct record seen (a run has one or two)
+  long n_fused = 0, n_replayed = 0; // stages run fused | records replayed call by call (hfx_ctx_deferred_stats)
+  std::string last_why;
+};
+} // namespace hfx
+
 struct hfx_ctx
 {
   int device = 0;
@@ -89,6 +138,7 @@ struct hfx_ctx
     int dense_split = 0;        // column groups per 16-row tile dealt to the waves: 0 by the operator's rows, else 1, 2 or 4
     int general_waves = 0;      // waves per workgroup of the general flux kernel: 0 by the LDS image (4 or 8), else 3, 4 or 8
   } opt;
+  hfx::Deferred defer;
   double CFL = 0.0; // run_input.CFL (hfx_ctx_set_CFL); dt_type 1 / 2 only
   bool have_CFL = false;
   hfx::Phys phys() const
@@ -148,6 +198,11 @@ struct hfx_eles
   double *arr[HFX_N_ARRAYS] = {};
   long arr_len[HFX_N_ARRAYS] = {};
   bool src_nonzero = false;
+  // deferred execution: disu_fpts holds opp_0 . disu_upts(0) of the CURRENT state (the fused stages leave it so; anything
+  // else that changes the state clears it), and on a partitioned block that flux-point solution is already on its way to
+  // the neighbours; stale: bit i = array i was not refreshed by the last fused stage (its contents are older)
+  bool fpts_valid = false, fpts_sent = false;
+  unsigned stale = 0;
   unsigned long long *nan_flag = nullptr; // device: smallest flat index of a NaN in div_tconf, or ~0
   double *red_buf = nullptr;              // device partial sums for reductions
   int red_blocks = 0;
@@ -200,6 +255,30 @@ int calc_time_step(hfx_eles *e, hfx_comm *comm);
 // run_input.ramp_counter++ after a time step for the boundary blocks with a ramping group (src/HiFiLES.cpp:224-225)
 void advance_ramp_counters(hfx_inters *const *faces, int nfb);
 } // namespace hfx
+
+namespace hfx
+{
+// ---- deferred execution (deferred.hip) ----
+int defer_record(hfx_ctx *ctx, int method, hfx_eles *e, hfx_inters *f, hfx_comm *c, int i0, int i1);
+// run what has been recorded.  need: bit i = array i (hfx_array_id) must hold the reference's values afterwards -- a record
+// that a fused stage would leave without them is replayed call by call
+int defer_flush(hfx_ctx *ctx, unsigned need = 0);
+struct DeferBusy
+{
+  hfx_ctx *c;
+  bool prev;
+  explicit DeferBusy(hfx_ctx *ctx) : c(ctx), prev(ctx->defer.busy) { c->defer.busy = true; }
+  ~DeferBusy() { c->defer.busy = prev; }
+};
+inline void invalidate_fpts(hfx_eles *e) { e->fpts_valid = e->fpts_sent = false; }
+} // namespace hfx
+// a per-method entry point: recorded while the context defers (and is not replaying)
+#define HFX_DEFER(ctx_, method_, e_, f_, c_, i0_, i1_)  \
+  if ((ctx_)->defer.on && !(ctx_)->defer.busy) return hfx::defer_record(ctx_, method_, e_, f_, c_, i0_, i1_)
+// any other entry point that reads or changes device state: what has been recorded runs first
+#define HFX_IMMEDIATE(ctx_, need_)                \
+  if (hfx::defer_flush(ctx_, need_)) return 1;    \
+  hfx::DeferBusy _defer_busy(ctx_)
 
 // boundary-face kernels (hfx.hip); visc 0: inviscid sweep (+ LDG common solution), 1: viscous sweep;
 // fast: the fused paths' reciprocal-multiply physics

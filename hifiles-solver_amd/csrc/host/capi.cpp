@@ -268,6 +268,12 @@ extern "C" int hfxh_case_run_partitioned(hfxh_case *c, int n_steps)
   return 0;
 }
 
+extern "C" int hfxh_case_set_deferred(hfxh_case *c, int on)
+{
+  if (SetDeferred(&c->S, on != 0)) { g_err = c->S.err; return 1; }
+  return 0;
+}
+
 extern "C" int hfxh_case_to_device(hfxh_case *c, int device)
 {
   if (MoveToDevice(&c->S, device)) { g_err = c->S.err; return 1; }
@@ -332,12 +338,14 @@ extern "C" int hfxh_case_calc_time_step(hfxh_case *c, double *dt)
 extern "C" int hfxh_case_sync_host(hfxh_case *c)
 {
   eles *E = the_eles(c);
+  // the gradient first: with deferred execution a pending stage then runs call by call and leaves every array of the
+  // reference behind (asked for the state first it would run fused and keep the gradient on chip)
+  if (E->viscous && E->cp_grad_disu_upts_gpu_cpu()) { g_err = E->last_error(); return 1; }
   if (E->cp_disu_upts_gpu_cpu() || E->cp_div_tconf_upts_gpu_cpu() || E->cp_array_gpu_cpu(HFX_DISU_UPTS1, E->disu_upts(1)))
   {
     g_err = E->last_error();
     return 1;
   }
-  if (E->viscous && E->cp_grad_disu_upts_gpu_cpu()) { g_err = E->last_error(); return 1; }
   return 0;
 }
 

@@ -421,6 +421,7 @@ int MoveToDevice(solution *S, int device)
   S->run_input.fill(p);
   if (hfx_ctx_set_params(S->ctx, &p)) { S->err = hfx_last_error(); return 1; }
   if (S->run_input.dt_type != 0 && hfx_ctx_set_CFL(S->ctx, S->run_input.CFL)) { S->err = hfx_last_error(); return 1; }
+  if (hfx_ctx_set_option(S->ctx, "deferred", S->deferred ? 1 : 0)) { S->err = hfx_last_error(); return 1; }
   for (int i = 0; i < S->n_ele_types; i++)
     if (S->mesh_eles(i) && S->mesh_eles(i)->get_n_eles() != 0)
       if (S->mesh_eles(i)->mv_all_cpu_gpu(S->ctx)) { S->err = S->mesh_eles(i)->last_error(); return 1; }
@@ -430,6 +431,13 @@ int MoveToDevice(solution *S, int device)
     if (S->mesh_bdy_inters(i).mv_all_cpu_gpu(S->ctx, S)) { S->err = S->mesh_bdy_inters(i).last_error(); return 1; }
   for (int i = 0; i < S->n_mpi_inter_types; i++)
     if (S->mesh_mpi_inters(i).mv_all_cpu_gpu(S->ctx, S)) { S->err = S->mesh_mpi_inters(i).last_error(); return 1; }
+  return 0;
+}
+
+int SetDeferred(solution *S, bool on)
+{
+  S->deferred = on;
+  if (S->ctx && hfx_ctx_set_option(S->ctx, "deferred", on ? 1 : 0)) { S->err = hfx_last_error(); return 1; }
   return 0;
 }
 
@@ -521,9 +529,10 @@ int calc_time_step(solution *FlowSol)
       if (hfx_eles_calc_dt_local(FlowSol->mesh_eles(j)->device(), in.CFL, &v)) { FlowSol->err = hfx_last_error(); return 1; }
       if (v < dt_min) dt_min = v;
     }
-  if (FlowSol->nproc > 1 && in.dt_type == 1)
+  if (FlowSol->nproc > 1)
   {
-    // MPI_Allreduce(MIN) over the ranks (src/solver.cpp:511): without it every rank would advance with its own minimum
+    // MPI_Allreduce(MIN) over the ranks for dt_type 1 (src/solver.cpp:511) AND 2 (src/solver.cpp:540-547: run_input.dt, which
+    // advances `time`, is the global minimum of the local steps): without it every rank would go on with its own minimum
     if (FlowSol->comm)
     {
       if (hfx_comm_allreduce(FlowSol->comm, &dt_min, 1, 0)) { FlowSol->err = hfx_last_error(); return 1; }
@@ -532,7 +541,7 @@ int calc_time_step(solution *FlowSol)
       dt_min = FlowSol->reduce_min(FlowSol->reduce_user, dt_min);
     else
     {
-      FlowSol->err = "calc_time_step: dt_type 1 on more than one rank needs a MIN reduction over the ranks (SetComm or SetReduceMin)";
+      FlowSol->err = "calc_time_step: dt_type 1 / 2 on more than one rank needs a MIN reduction over the ranks (SetComm or SetReduceMin)";
       return 1;
     }
   }
@@ -575,6 +584,9 @@ int RunSteps(solution *FlowSol, int n_steps)
     FlowSol->run_input.time = FlowSol->time;
     if (advance_ramp(FlowSol)) return 1;
   }
+  // (deferred execution: the last stage's record is still pending here, on purpose -- what the caller asks for next decides how
+  // it runs: the state alone -> the fused stage; the gradient arrays, as the reference's CopyGPUCPU does before its
+  // diagnostics -> call by call.  An error in it is reported by that next call.)
   for (int j = 0; j < FlowSol->n_ele_types; j++)
     if (FlowSol->mesh_eles(j) && FlowSol->mesh_eles(j)->failed())
     {

@@ -35,6 +35,9 @@ struct solution
   double (*reduce_min)(void *user, double v) = nullptr; // MPI_Allreduce(MIN) of calc_time_step, supplied by the caller
   void *reduce_user = nullptr;
   hfx_comm *comm = nullptr; // the library's RCCL transport (SetComm); takes the place of `exchange` and `reduce_min`
+  // deferred execution (include/hfx.h): the method calls of CalcResidual + AdvanceSolution below are recorded by libhfx and
+  // a whole stage runs as one fused stage -- the call sequence itself is the reference's, unchanged.  On by default.
+  bool deferred = true;
   std::string err;
   ~solution();
 };
@@ -71,6 +74,8 @@ int GeoPreprocess_box(solution *FlowSol, const box_mesh &mesh);
 int InitSolution(solution *FlowSol);
 // move everything to the device (the reference's mv_all_cpu_gpu calls, src/geometry.cpp:310-320,552-557)
 int MoveToDevice(solution *FlowSol, int device);
+// switch deferred execution on / off (before or after MoveToDevice)
+int SetDeferred(solution *FlowSol, bool on);
 
 void CalcResidual(int in_file_num, int in_rk_stage, solution *FlowSol);
 // RK loop of src/HiFiLES.cpp:194-221 through the mirrored class methods

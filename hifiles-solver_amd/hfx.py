@@ -110,6 +110,12 @@ def _f(a):
     return a
 
 
+def deferred_stats(ctx_handle):
+    nf, nr, why = C.c_long(0), C.c_long(0), C.c_char_p()
+    check(lib().hfx_ctx_deferred_stats(ctx_handle, C.byref(nf), C.byref(nr), C.byref(why)))
+    return nf.value, nr.value, (why.value or b"").decode()
+
+
 class Context:
     def __init__(self, device=0):
         self.h = C.c_void_p()
@@ -138,6 +144,14 @@ class Context:
 
     def synchronize(self):
         check(lib().hfx_ctx_synchronize(self.h))
+
+    def flush(self):
+        """deferred execution: run what has been recorded (no-op otherwise)"""
+        check(lib().hfx_ctx_flush(self.h))
+
+    def deferred_stats(self):
+        """(stages run fused, records replayed call by call, why the last replay was one)"""
+        return deferred_stats(self.h)
 
     @property
     def stream(self):

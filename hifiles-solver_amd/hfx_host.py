@@ -228,6 +228,10 @@ class Case:
         check(lib().hfxh_case_mpi_handle(self.h, C.byref(f)))
         return f
 
+    def set_deferred(self, on):
+        """deferred execution of the mirrored method calls (default on): whole stages run as fused stages"""
+        check(lib().hfxh_case_set_deferred(self.h, C.c_int(1 if on else 0)))
+
     def run_partitioned(self, n_steps):
         check(lib().hfxh_case_run_partitioned(self.h, C.c_int(n_steps)))
 

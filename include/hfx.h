@@ -124,9 +124,35 @@ int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
  * hfx_run_steps_partitioned launches the one-sided partition-face kernels on the communication stream), "flux_stamps" (0; n >= 1: cycle
  * stamps of iteration max(n, 2) of one workgroup of the flux kernels, printed by the hfx_time_* entry points), "tensor_ops" (1),
  * "general_waves" (0 = by LDS image | 3 | 4 | 8), "dense_waves" (0 = by the operator's rows | 4 | 8) and "dense_split" (0 | 1 | 2 | 4:
- * shape of the dense MFMA contraction's workgroup) -- see hfx_ctx::Options in csrc/hfx_internal.hpp;
+ * shape of the dense MFMA contraction's workgroup) -- see hfx_ctx::Options in csrc/hfx_internal.hpp; and "deferred" (0), which is
+ * not a measurement knob: see below;
  * tests/test_gpu_fused.py::test_split3_variant_knobs_agree holds the variants to each other. */
 int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value);
+/* ---- deferred execution: the reference's UNCHANGED call sequence on the fused stages --------------------------------
+ * hfx_ctx_set_option(ctx, "deferred", 1).  From then on the per-method entry points below -- exactly the calls
+ * CalcResidual (src/solver.cpp:59-221) and the RK loop (src/HiFiLES.cpp:201-217) make: hfx_eles_extrapolate_solution ...
+ * hfx_eles_calculate_corrected_divergence, hfx_eles_calc_sgs_terms, hfx_eles_extrapolate_sgsFlux,
+ * hfx_int_inters_calculate_common_*, hfx_bdy_inters_evaluate_boundaryConditions_*, hfx_mpi_inters_send_* / receive_* /
+ * calculate_common_*, hfx_eles_AdvanceSolution, hfx_eles_shock_capture -- RECORD the call and return.  The record runs
+ * when the next stage begins (the first call behind an AdvanceSolution / shock_capture) or when any other entry point needs
+ * the device state (upload, download, monitors, calc_dt_local, new parameters, synchronize, hfx_ctx_flush ...):
+ *   - a record that is one whole stage in CalcResidual's order (every method over every block it belongs to, phases in
+ *     the reference's order, one stage number) runs as ONE fused stage: the split stage for a tensor-product block
+ *     (= hfx_run_steps(..., 3), or 2 with an LES closure / fused mode 2), the partitioned split stage when the block has
+ *     partition faces whose send_* / receive_* calls name one hfx_comm (= hfx_run_steps_partitioned), the general stage
+ *     for tetrahedra / prisms / mixed meshes (= hfx_run_steps_blocks(..., 4));
+ *   - anything else -- a partial stage, another order, a block the fused stages refuse, the packing halves
+ *     hfx_mpi_inters_pack_* of a caller-side transport -- is replayed call by call: the per-method path, unchanged.
+ * Results are those of hfx_run_steps* (1e-11 of the per-method path).  The fused stages leave disu_upts(0),
+ * disu_upts(1), disu_fpts of the new state, and div_tconf_upts at the last stage of a step (where the monitors read it,
+ * src/output.cpp:2166) or when a pending stage is flushed by a request for it.  A download of any OTHER array that arrives
+ * while a whole stage is pending makes that stage run call by call, so that the caller sees the reference's values (a
+ * monitor that reads grad_disu_upts after a step, src/eles.cpp:5485, costs one per-method stage); once the next stage has
+ * begun such an array is stale and its download FAILS rather than return older values.
+ * An error in a recorded call surfaces at the entry point that makes the record run. */
+int hfx_ctx_flush(hfx_ctx *ctx); /* run what has been recorded (asynchronously, on the context's stream); no-op otherwise */
+/* stages run fused / records replayed call by call since the context was created, and why the last replay was one */
+int hfx_ctx_deferred_stats(hfx_ctx *ctx, long *n_fused, long *n_replayed, const char **why_last_replay);
 /* run_input.dt as the last calc_time_step left it (dt_type 1), or as set (dt_type 0) */
 int hfx_ctx_get_dt(hfx_ctx *ctx, double *dt);
 int hfx_ctx_synchronize(hfx_ctx *ctx);
@@ -179,8 +205,9 @@ int hfx_int_inters_calculate_common_viscFlux(hfx_inters *f); /* int_inters::calc
  *   out/in_buffer_grad_disu (fpt, field, dim, inter), filled in loop order inter -> [dim ->] field -> fpt
  *   (src/mpi_inters.cpp:56-66,225-229,284-289).  Faces of one neighbour rank are contiguous, in the
  *   order both ranks agreed on (src/geometry.cpp:1184-1239), so a message is one contiguous slice.
- * The exchange itself is the caller's (RCCL send/recv through torch.distributed, or MPI): it moves
- *   out_buffer slices to the neighbours' in_buffer slices between `pack` and `calculate_common_*`. */
+ * The exchange moves out_buffer slices to the neighbours' in_buffer slices between `pack` and `calculate_common_*`:
+ *   either inside the library (hfx_comm_*, hfx_mpi_inters_send_* / receive_* below: grouped ncclSend / ncclRecv on the
+ *   library's communication stream) or by the caller (the hfx_mpi_inters_pack_* halves + its own transport). */
 int hfx_mpi_inters_create(hfx_ctx *ctx, hfx_eles *left, int n_inters, int n_fpts_per_inter, const int *L,
                           const int *Rlut, hfx_inters **out);
 /* the packing half of mpi_inters::send_solution / send_corrected_gradient (src/mpi_inters.cpp:218-229,278-289) */

@@ -141,6 +141,10 @@ int hfxh_simplex_destroy(hfxh_simplex *s);
 
 /* device */
 int hfxh_case_to_device(hfxh_case *c, int device);
+/* deferred execution of the mirrored method calls (hfx.h, option "deferred"): ON by default -- hfxh_case_CalcResidual / hfxh_case_run
+ * make the reference's calls one by one, libhfx records them and runs every whole stage as one fused stage.  0: every call
+ * launches its own kernels (the per-method path).  May be called before or after hfxh_case_to_device. */
+int hfxh_case_set_deferred(hfxh_case *c, int on);
 int hfxh_case_handles(hfxh_case *c, hfx_ctx **ctx, hfx_eles **e, hfx_inters ***faces, int *n_face_blocks);
 int hfxh_case_CalcResidual(hfxh_case *c); /* the mirrored CalcResidual (src/solver.cpp:50-223) */
 int hfxh_case_run(hfxh_case *c, int n_steps); /* the mirrored RK loop (src/HiFiLES.cpp:194-221) */
