@@ -152,7 +152,7 @@ def cpu_model():
 
 def rocprof_kernel_ms(mode, kernel):
     """average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this workload"""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.txt" % (rnd, mode))
         if os.path.exists(path):
             for line in open(path):
@@ -297,16 +297,63 @@ def general_workload(args):
     return 0
 
 
+ALSO_LEGS = [
+    # (name, what it is, extra arguments)
+    ("mixed_p3_channel", "BASELINE.json configs[3]: mixed tetrahedron / prism channel, P3, general fused stage", ["--workload", "mixed"]),
+    ("config5_overint_shock", "BASELINE.json configs[4]'s ingredients on one GPU: 32^3 P4 hexes, over-integration (7 points per direction) + "
+     "shock capturing after every stage", ["--over-int-order", "6", "--shock-s0", "1e-3"]),
+    ("les_wale", "32^3 P4 hexes, LES with the WALE closure (SURVEY 8f rank 4)", ["--les-cs", "0.325"]),
+    ("self_partition", "the 2x2x2 rank's share: 32^3 P4 with all 6 144 wrap-around faces as partition faces, exchanged over RCCL with the "
+     "rank itself", ["--self-partition"]),
+]
+
+
+def also_legs(args):
+    """Short legs of the other configurations as CHILD processes of the default run, after its timed region: each is this
+    script with --steps 4 --reps 3 --no-cpu --no-also and prints its own line, of which the summary goes into `also`."""
+    out = {}
+    for name, what, extra in ALSO_LEGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--reps", "3", "--no-cpu", "--no-also", "--no-api-path"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("HFX_BENCH_ALSO_TIMEOUT", "90")))
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timed out", "what": what}
+            continue
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+        if r.returncode != 0 or not lines:
+            out[name] = {"error": "exit code %d: %s" % (r.returncode, r.stderr[-300:]), "what": what}
+            continue
+        d = json.loads(lines[-1])
+        roof = d.get("roofline") or {}
+        out[name] = {"what": what, "ms_per_rk_stage": d["ms_per_rk_stage"], "dof_updates_per_s": d["value"],
+                     "dominant_kernel": roof.get("kernel"), "frac": roof.get("frac"), "dominant_kernel_ms": roof.get("kernel_ms"),
+                     "path": d["config"].get("path"), "steps": d["steps"], "reps": d["timing"]["reps"],
+                     "leg_wall_s": round(time.perf_counter() - t0, 1)}
+        if d.get("partitioned_stage_ms"):
+            out[name]["partitioned_stage_ms"] = d["partitioned_stage_ms"]
+    return out
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children of THIS process, which has not
     touched (and never touches) a GPU, and relay rank 0's JSON line.  Transports are tried in order: libhfx's own RCCL
     communicator, RCCL through torch.distributed, gloo with host staging."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
     order = [os.environ["HFX_BENCH_TRANSPORT"]] if os.environ.get("HFX_BENCH_TRANSPORT") else ["rccl", "torch", "gloo"]
-    s.close()
     last = ""
-    for transport in order:
+    # time limits: the whole chain must fit the driver's limit for one bench run (600 s) with room for the line to be
+    # relayed -- 540 s in all; the first transport (which also pays the first `import torch` of N processes on a fresh box)
+    # gets up to 300 s, every later one at most 150 s of what is left.  HFX_BENCH_CHILD_TIMEOUT overrides the per-leg limit.
+    t_start = time.perf_counter()
+    total = float(os.environ.get("HFX_BENCH_TOTAL_TIMEOUT", "540"))
+    for k, transport in enumerate(order):
+        left = total - (time.perf_counter() - t_start)
+        limit = float(os.environ["HFX_BENCH_CHILD_TIMEOUT"]) if os.environ.get("HFX_BENCH_CHILD_TIMEOUT") else (300.0 if k == 0 else 150.0)
+        limit = min(limit, left)
+        if limit < 20.0:
+            last += "transport %s: not tried, %.0f s left of %.0f s\n" % (transport, left, total)
+            sys.stderr.write(last)
+            break
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -315,9 +362,10 @@ def launch_ranks(args, argv):
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
         env = dict(os.environ, HFX_BENCH_TRANSPORT=transport)
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("HFX_BENCH_CHILD_TIMEOUT", "420")))
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
         except subprocess.TimeoutExpired as e:
-            last = "transport %s: timed out\n%s" % (transport, (e.stderr or "")[-2000:] if isinstance(e.stderr, str) else "")
+            err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+            last = "transport %s: TIMED OUT after %.0f s (leg %d of %d)\n%s" % (transport, limit, k + 1, len(order), err[-2000:])
             sys.stderr.write(last + "\n")
             continue
         lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
@@ -352,6 +400,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="hfx_ctx_set_option knob for A/B runs (split_grid_per_cu, xcd_order, dictionary_rows, flux_waves, "
                          "buffer_addressing, loader_wave, flux_stamps, tensor_ops); echoed into config.options")
+    ap.add_argument("--no-api-path", action="store_true", help="skip the timing of the mirrored CalcResidual + AdvanceSolution loop")
+    ap.add_argument("--no-also", action="store_true", help="skip the short legs of the other workloads (the `also` block of the default run)")
     ap.add_argument("--self-partition", action="store_true", help="N=1 only: the box's wrap-around faces become partition faces "
                     "to the rank itself, i.e. the partitioned stage with its RCCL exchanges priced on one GPU")
     args = ap.parse_args()
@@ -548,16 +598,37 @@ def main():
     ms_per_stage = ms_per_step / n_stages
 
     phases = None
+    rccl_info = None
+    part_roof = None
     if partitioned and fused and transport == "rccl":
-        # per-phase and per-exchange times of the partitioned stage (HIP events on the compute / communication streams);
-        # collective: every rank runs it, rank 0 reports its own
+        # per-phase and per-exchange times of the partitioned stage (HIP events on the compute / communication streams) in
+        # its SERIALISED schedule (every kernel on the compute stream so that the events bracket the phases; the timed run
+        # above puts the one-sided partition-face kernels on the communication stream); collective: every rank runs it,
+        # rank 0 reports its own
         phases = case.time_partitioned(10)
+        phases["schedule"] = "serialised (all kernels on the compute stream); `value` is timed on the overlapped schedule"
+        # what RCCL itself reports for every rank's communicator: N ranks on N different devices
+        mine = case.comm_info()
+        if dist is not None:
+            allinfo = [None] * world
+            dist.all_gather_object(allinfo, mine)
+        else:
+            allinfo = [mine]
+        rccl_info = {"rccl_nranks": mine["nranks"], "ranks": allinfo,
+                     "distinct_devices": len({i["pci_bus_id"] for i in allinfo})}
+        if rank == 0 and phases.get("flux_kernel", 0.0) > 0.0:
+            share = (C.c_double * 8)()
+            hfx.check(lib.hfx_fused_kernel_bytes(e, share))
+            ach = share[1] / (phases["flux_kernel"] * 1e-3) / 1e9
+            part_roof = dict(bound="hbm", kernel="split_flux_tensor_kernel (rank 0, partitioned stage)", achieved=ach, peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None, algorithmic_bytes=share[1], kernel_ms=phases["flux_kernel"],
+                             kernel_ms_source="HIP events around the kernel inside hfx_time_partitioned, this run")
 
     # ---- the reference's UNCHANGED call sequence: the mirrored CalcResidual + AdvanceSolution loop (csrc/host/solver.cpp makes
     # the seventeen method calls of src/solver.cpp:59-221 + src/HiFiLES.cpp:201-217 one by one through the C ABI), timed with
     # libhfx deferring them (whole stages run as the fused stage) and with every call launching its own kernels
     api_path = None
-    if not partitioned and fused:
+    if not partitioned and fused and not args.no_api_path:
         api_path = {}
         for label, on, nsteps in (("deferred", True, args.steps), ("per_method", False, max(2, args.steps // 4))):
             case.set_deferred(on)
@@ -594,7 +665,7 @@ def main():
             # rocprofv3 runs by tools/profile_round.sh and committed under profiles/); only valid for the
             # workload it was measured on
             traffic, traffic_source = None, None
-            for rnd in ("r02", "r01"):
+            for rnd in ("r03", "r02", "r01"):
                 tfile = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, mode))
                 if os.path.exists(tfile) and args.n == 32 and args.order == 4 and not extra:
                     traffic = json.load(open(tfile)).get(dom, {}).get("traffic_bytes_corrected")
@@ -649,6 +720,11 @@ def main():
                 cpu = dict(value=cb["allcores"]["value"], unit="DOF-updates/s", cores=threads, cpu_model=cpu_model(), kind="port",
                            sample=port_note, value_1core=cb["1core"]["value"])
 
+    also = None
+    if (rank == 0 and world == 1 and not args.no_also and not partitioned and not extra and args.n == 32 and args.order == 4
+            and args.mode == "auto" and not args.opt):
+        also = also_legs(args)
+
     if rank == 0:
         knobs = {k: v for k, v in os.environ.items() if k.startswith("HFX_") and k != "HFX_BENCH_CHILD_TIMEOUT"}
         tname = {"rccl": "RCCL p2p (grouped ncclSend / ncclRecv on libhfx's communication stream, hfx_run_steps_partitioned)",
@@ -676,6 +752,8 @@ def main():
                        "multi_gpu": mg, "options": options, "env_knobs": knobs},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if also is not None:
+            line["also"] = also
         if api_path is not None:
             line["api_path_ms_per_rk_stage"] = {k: v["ms_per_rk_stage"] for k, v in api_path.items()}
             line["api_path"] = dict(api_path, note="the reference's unchanged call sequence (mirrored CalcResidual + AdvanceSolution, one C-ABI "
@@ -684,6 +762,11 @@ def main():
                                     "hfx_run_steps, the same fused stages without the per-call recording")
         if phases is not None:
             line["partitioned_stage_ms"] = phases
+        if rccl_info is not None:
+            line["rccl"] = rccl_info
+            line["rccl_nranks"] = rccl_info["rccl_nranks"]
+        if part_roof is not None and roof is None:
+            line["roofline"] = part_roof
         print(json.dumps(line))
     if ex is not None:
         ex.close()

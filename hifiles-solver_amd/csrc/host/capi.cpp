@@ -268,6 +268,12 @@ extern "C" int hfxh_case_run_partitioned(hfxh_case *c, int n_steps)
   return 0;
 }
 
+extern "C" int hfxh_case_comm_info(hfxh_case *c, int *nranks, int *rank, int *device, char pci_bus_id[32])
+{
+  if (CommInfo(&c->S, nranks, rank, device, pci_bus_id)) { g_err = c->S.err; return 1; }
+  return 0;
+}
+
 extern "C" int hfxh_case_set_deferred(hfxh_case *c, int on)
 {
   if (SetDeferred(&c->S, on != 0)) { g_err = c->S.err; return 1; }

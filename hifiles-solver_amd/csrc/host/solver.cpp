@@ -677,6 +677,13 @@ int TimePartitioned(solution *FlowSol, int reps, double ms[8])
   return 0;
 }
 
+int CommInfo(solution *FlowSol, int *nranks, int *rank, int *device, char pci_bus_id[32])
+{
+  if (!FlowSol->comm) { FlowSol->err = "CommInfo: needs the library's communicator (SetComm)"; return 1; }
+  if (hfx_comm_info(FlowSol->comm, nranks, rank, device, pci_bus_id)) { FlowSol->err = hfx_last_error(); return 1; }
+  return 0;
+}
+
 int RunStepsPartitionedFused(solution *FlowSol, int n_steps)
 {
   eles *E;

@@ -93,3 +93,5 @@ void SetReduceMin(solution *FlowSol, double (*fn)(void *user, double v), void *u
 int SetComm(solution *FlowSol, const char *unique_id);
 // per-phase / per-exchange times of the partitioned fused stage (hfx_time_partitioned)
 int TimePartitioned(solution *FlowSol, int reps, double ms[8]);
+// what RCCL reports for the communicator (hfx_comm_info)
+int CommInfo(solution *FlowSol, int *nranks, int *rank, int *device, char pci_bus_id[32]);

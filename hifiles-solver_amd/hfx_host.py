@@ -216,7 +216,14 @@ class Case:
         ms = (C.c_double * 8)()
         check(lib().hfxh_case_time_partitioned(self.h, C.c_int(reps), ms))
         return dict(zip(("phase1_interior_ldg", "phase2_gradient_flux", "phase3_interior_common_flux", "phase4_update",
-                         "exchange_solution", "exchange_flux", "stage"), list(ms)[:7]))
+                         "exchange_solution", "exchange_flux", "stage", "flux_kernel"), list(ms)[:8]))
+
+    def comm_info(self):
+        """what RCCL reports for the case's communicator: {nranks, rank, device, pci_bus_id}"""
+        n, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        bus = C.create_string_buffer(32)
+        check(lib().hfxh_case_comm_info(self.h, C.byref(n), C.byref(r), C.byref(d), bus))
+        return {"nranks": n.value, "rank": r.value, "device": d.value, "pci_bus_id": bus.value.decode()}
 
     def set_exchange(self, fn):
         """fn(kind, phase): kind 0 solution / 1 corrected gradient, phase 0 start / 1 wait."""

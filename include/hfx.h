@@ -389,6 +389,9 @@ typedef struct hfx_comm hfx_comm;
 int hfx_comm_get_unique_id(char id[HFX_COMM_ID_BYTES]);
 int hfx_comm_create(hfx_ctx *ctx, const char id[HFX_COMM_ID_BYTES], int nranks, int rank, hfx_comm **out);
 int hfx_comm_destroy(hfx_comm *c);
+/* what RCCL reports for this communicator: ncclCommCount, ncclCommUserRank, ncclCommCuDevice, and that device's PCI bus id
+ * (hipDeviceGetPCIBusId) -- evidence in a benchmark line that N ranks on N different devices took part */
+int hfx_comm_info(hfx_comm *c, int *nranks, int *rank, int *device, char pci_bus_id[32]);
 /* MPI_Allreduce(MIN / MAX / SUM) of a few doubles (calc_time_step's dt, src/solver.cpp:511,543; the monitors'
  * reductions); op 0 min, 1 max, 2 sum.  Synchronises the host with the communication stream. */
 int hfx_comm_allreduce(hfx_comm *c, double *values, int n, int op);
@@ -422,7 +425,10 @@ int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_i
                               hfx_comm *comm, int n_steps);
 /* Average durations (ms, HIP events) over `reps` stages of the same loop: ms[0..3] phases 1-4 on the compute stream,
  * ms[4] solution exchange and ms[5] flux / gradient exchange on the communication stream (from the moment their
- * data is packed to the last byte received), ms[6] the whole stage.  The state advances by reps stages. */
+ * data is packed to the last byte received), ms[6] the whole stage, ms[7] the element kernel of phase 2 alone (the split flux
+ * kernel; 0 for inviscid runs and fused mode 2).  This is the SERIALISED schedule: every kernel on the compute stream so that
+ * the events bracket the phases -- hfx_run_steps_partitioned itself puts the one-sided partition-face kernels on the
+ * communication stream (option "comm_stream_faces") and is timed as a whole by the caller.  The state advances by reps stages. */
 int hfx_time_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                          hfx_comm *comm, int reps, double ms[8]);
 

@@ -124,6 +124,8 @@ int hfxh_case_set_reduce_min(hfxh_case *c, hfxh_reduce_min_cb fn, void *user);
  * 128-byte id of hfx_comm_get_unique_id (made on rank 0, distributed by the launcher).  From then on send_* / receive_*,
  * hfxh_case_run_partitioned and calc_time_step's MIN reduction go through it instead of the hooks. */
 int hfxh_case_set_comm(hfxh_case *c, const char *unique_id);
+/* hfx_comm_info of the case's communicator (after hfxh_case_set_comm) */
+int hfxh_case_comm_info(hfxh_case *c, int *nranks, int *rank, int *device, char pci_bus_id[32]);
 /* hfx_time_partitioned on this case's blocks: ms[0..3] phases 1-4, ms[4] solution exchange, ms[5] flux exchange, ms[6] stage */
 int hfxh_case_time_partitioned(hfxh_case *c, int reps, double ms[8]);
 
