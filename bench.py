@@ -395,8 +395,8 @@ def main():
     # inviscid flux and shock capturing after every stage
     ap.add_argument("--over-int-order", type=int, default=-1, help="over_int 1 with this over_int_order (cubature points per direction - 1)")
     ap.add_argument("--shock-s0", type=float, default=-1.0, help="shock_cap 1 with this sensor threshold s0")
-    ap.add_argument("--les-cs", type=float, default=-1.0, help="LES 1 with the WALE closure and this C_s (runs the split path that "
-                    "keeps the corrected gradients, --mode split)")
+    ap.add_argument("--les-cs", type=float, default=-1.0, help="LES 1 with the WALE closure and this C_s (split3: the closure in the flux "
+                    "kernel; --mode split: the variant that keeps the corrected gradients in HBM for a pointwise closure kernel)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="hfx_ctx_set_option knob for A/B runs (split_grid_per_cu, xcd_order, dictionary_rows, flux_waves, "
                          "buffer_addressing, loader_wave, flux_stamps, tensor_ops); echoed into config.options")
@@ -451,8 +451,6 @@ def main():
         extra.update(shock_cap=1, s0=args.shock_s0, expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0)
     if args.les_cs >= 0:
         extra.update(LES=1, SGS_model=1, C_s=args.les_cs, filter_ratio=1.0)
-        if args.mode == "auto":
-            args.mode = "split"
     # the reference's own solution-point abscissae (the data/JacobiGQ.bin row, carried as data by the full-size fixture):
     # with them the LDG switch on this axis-aligned mesh falls as in the reference (tests/test_fullsize_vs_reference.py)
     nodes = None

@@ -230,8 +230,10 @@ int partitioned_stage(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_
 {
   hfx_ctx *ctx = e->ctx;
   const bool visc = ctx->params.viscous != 0;
+  if (split_deferred_prepare(e, int_faces, n_int, true)) return 1; // (the variant below depends on the block's fused tables)
   const bool projected = split_variant(e) == 3; // variant 3 sends the projected viscous flux
-  const bool les = e->les_ready;                // third message: the SGS flux (src/solver.cpp:168-178,203-206)
+  // third message: the SGS flux (src/solver.cpp:168-178,203-206) -- variant 2 only; in variant 3 it is part of the projected flux
+  const bool les = e->les_ready && !projected;
   hipStream_t st = ctx->stream, cs = comm->stream;
   auto phase = [&](int ph, int stage, int first) {
     return split_stage_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, ph, stage, first);

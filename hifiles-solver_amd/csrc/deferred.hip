@@ -208,13 +208,12 @@ static void make_plan(hfx_ctx *ctx, const std::vector<DeferCall> &log, DeferPlan
   }
   if (tensor)
   {
-    const int variant = split_variant(e0);
-    if (e0->over_int_ready && variant != 3) { P.why = "the split variant that keeps the gradients (LES, fused mode 2) has no over-integration"; return; }
     if (split_deferred_prepare(e0, P.faces.data(), (int)P.faces.size(), mpi))
     {
       P.why = hfx_last_error();
       return;
     }
+    if (e0->over_int_ready && split_variant(e0) != 3) { P.why = "the split variant that keeps the gradients (LES, fused mode 2) has no over-integration"; return; }
     P.kind = mpi ? 2 : 1;
     return;
   }

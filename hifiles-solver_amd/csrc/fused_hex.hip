@@ -520,23 +520,48 @@ static int element_grid(const hfx_eles *e, int threads, int per_cu, int cap = 1 
 }
 
 // launch of the loader-wave form, instantiated only for element sizes it fits (loader_wave_fits)
-template <int ND, int N, bool OI, bool GA, bool FITS>
+template <int ND, int N, bool OI, bool GA, bool LES, bool FITS>
 struct LoaderWaveLaunch
 {
   static void go(const hfx_eles *, int, hipStream_t, const Split2Args &, const double *, const int *) {}
 };
-template <int ND, int N, bool OI, bool GA>
-struct LoaderWaveLaunch<ND, N, OI, GA, true>
+template <int ND, int N, bool OI, bool GA, bool LES>
+struct LoaderWaveLaunch<ND, N, OI, GA, LES, true>
 {
   static void go(const hfx_eles *e, int per_cu, hipStream_t st, const Split2Args &e2, const double *coef, const int *idx)
   {
     constexpr int TB = SGeo<ND, N>::TB + 64;
     // (the over-integration form measured 3 % faster at sixteen workgroups per CU than at the two that are resident)
     if (OI && per_cu == 0) per_cu = 16;
-    const int grid = element_grid<split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA>>(e, TB, per_cu);
-    hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA>), dim3(grid), dim3(TB), 0, st, e2, coef, idx);
+    const int grid = element_grid<split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA, LES>>(e, TB, per_cu);
+    hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA, LES>), dim3(grid), dim3(TB), 0, st, e2, coef, idx);
   }
 };
+
+// runtime form of loader_wave_fits
+static bool loader_wave_fits_rt(int nd, int N)
+{
+#define HFX_LWF(ND_, N_) \
+  if (nd == ND_ && N == N_) return loader_wave_fits<ND_, N_>();
+  HFX_LWF(3, 2) HFX_LWF(3, 3) HFX_LWF(3, 4) HFX_LWF(3, 5) HFX_LWF(3, 6) HFX_LWF(2, 2) HFX_LWF(2, 3) HFX_LWF(2, 4) HFX_LWF(2, 5) HFX_LWF(2, 6)
+#undef HFX_LWF
+  return false;
+}
+
+// Can the LES closure of this block be evaluated inside the flux kernel of variant 3 (split_flux_tensor_kernel<..., LES>)?  It
+// is part of the loader-wave form of the sum-factorised kernel only; otherwise a block with a closure runs variant 2, which keeps
+// the corrected gradient in HBM for the pointwise closure kernel.  Needs the block's fused tables (fused_build).
+bool les_in_flux_kernel(const hfx_eles *e)
+{
+  const hfx_ctx::Options &opt = e->ctx->opt;
+  if (!e->les_ready || !e->ctx->params.viscous || e->over_int_ready || !opt.les_flux_kernel) return false;
+  if (!e->fused || !e->fused->built || !e->fused->tensor_ok) return false;
+  if (opt.dictionary_rows || !opt.loader_wave || !opt.buffer_addressing || opt.flux_waves != 2) return false;
+  if (!loader_wave_fits_rt(e->n_dims, tensor_n(e))) return false;
+  const double plane_most = (double)std::max<long>((long)e->n_fpts * e->n_eles, (long)e->n_upts * e->n_eles);
+  // every array the launch touches below 4 GiB (boundary blocks make it store the flux-point gradient array too)
+  return plane_most * e->n_fields * e->n_dims * 8.0 < 4294967296.0;
+}
 
 template <int ND, int N>
 static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, SplitEleArgs &ea, int which, int variant)
@@ -592,6 +617,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;
     e2.adv_type = ea.adv_type; e2.in_step = ea.in_step; e2.dt_local_on = ea.dt_local_on; e2.write_div = ea.write_div;
     e2.need_u1 = ea.need_u1; e2.dt = ea.dt; e2.rk_a = ea.rk_a; e2.rk_b = ea.rk_b;
+    e2.les = e->les; e2.wall_distance = e->wall_distance; e2.tdA_fpts = e->tdA_fpts;
   }
   // Will the flux kernel form the LDG corrections of the interior points itself?  (the loader-wave form of the sum-factorised
   // kernel only: same conditions as its selection below)
@@ -629,15 +655,18 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       hipLaunchKernelGGL((face_delta_kernel<ND>), dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
     }
   }
+  // which (timing only): 5 = the over-integration kernel of part 2 alone, 7 = part 2 without it; 6 = the SGS kernels of part 2
+  // (variant 2 with an LES closure) alone, 8 = part 2 without them
   if (variant == 3)
   {
-    if (which == 0 || which == 2)
+    if (which == 5 && e->over_int_ready && hfx_eles_evaluate_invFlux_over_int(e)) return 1;
+    if (which == 0 || which == 2 || which == 7)
     {
       e2.tdisf_in = nullptr;
       if (e->over_int_ready)
       {
         // polynomial de-aliasing (src/solver.cpp:82-91): tdisf_upts = over_int_filter . F(opp_over_int_cubpts . u)
-        if (hfx_eles_evaluate_invFlux_over_int(e)) return 1;
+        if (which != 7 && hfx_eles_evaluate_invFlux_over_int(e)) return 1;
         e2.tdisf_in = e->arr[HFX_TDISF_UPTS];
       }
       const bool dict_only = opt.dictionary_rows != 0;
@@ -661,17 +690,25 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       constexpr bool lw_fits = loader_wave_fits<ND, N>();
       const bool lw = lw_fits && buf && !no_lw && waves == 2;
       bool launched = false;
+      // a closure with an SGS flux (every model but the spectral vanishing viscosity, which only filters the state)
+      const bool les = e->les_ready && e->les.sgs_model != 3;
+      HFX_CHECK(!les || (lw && F->tensor_ok && !dict_only && !oi && P.viscous),
+                "split variant 3 with an LES closure needs the loader-wave flux kernel (les_in_flux_kernel): run variant 2");
       if (F->tensor_ok && !dict_only && lw)
       {
         const bool ga = e2.nbr != nullptr && P.viscous; // (the corrections formed in the kernel)
-        if (oi && ga)
-          LoaderWaveLaunch<ND, N, true, true, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
+        if (les && ga)
+          LoaderWaveLaunch<ND, N, false, true, true, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
+        else if (les)
+          LoaderWaveLaunch<ND, N, false, false, true, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
+        else if (oi && ga)
+          LoaderWaveLaunch<ND, N, true, true, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         else if (oi)
-          LoaderWaveLaunch<ND, N, true, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, true, false, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         else if (ga)
-          LoaderWaveLaunch<ND, N, false, true, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, false, true, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         else
-          LoaderWaveLaunch<ND, N, false, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
+          LoaderWaveLaunch<ND, N, false, false, false, lw_fits>::go(e, flux_per_cu, st, e2, F->t_coef, F->t_idx);
         launched = true;
       }
       if (launched)
@@ -691,12 +728,13 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
         hipLaunchKernelGGL((split_flux_kernel<ND, N>), dim3(element_grid<split_flux_kernel<ND, N>>(e, TB, per_cu)), dim3(TB), 0, st, e2);
     }
   }
-  else if (P.viscous && (which == 0 || which == 2))
+  else if (P.viscous && (which == 0 || which == 2 || which == 6 || which == 8))
   {
     ea.pk = F->pk_g;
     ea.tab = F->tab_g;
-    hipLaunchKernelGGL((split_gradient_kernel<ND, N>), dim3(element_grid<split_gradient_kernel<ND, N>>(e, TB, per_cu)), dim3(TB), 0, st, ea);
-    if (e->les_ready)
+    if (which != 6)
+      hipLaunchKernelGGL((split_gradient_kernel<ND, N>), dim3(element_grid<split_gradient_kernel<ND, N>>(e, TB, per_cu)), dim3(TB), 0, st, ea);
+    if (e->les_ready && which != 8)
     {
       // LES (eddy-viscosity closures): SGS flux at the solution points from the corrected gradient, its extrapolation to
       // the flux points (src/solver.cpp:162-167); the face kernel adds it to each side, the residual kernel to the total
@@ -814,9 +852,9 @@ int split_deferred_prepare(hfx_eles *e, hfx_inters *const *faces, int nfb, bool 
 
 int split_deferred_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_step, bool write_div, bool shock)
 {
-  const int variant = split_variant(e); // an LES closure reads the corrected gradients, which variant 3 keeps in registers
-  HFX_CHECK(!e->over_int_ready || variant == 3, "the split variant that keeps the gradients (fused 2, which LES selects) has no over-integration");
   if (split_deferred_prepare(e, faces, nfb, false)) return 1;
+  const int variant = split_variant(e);
+  HFX_CHECK(!e->over_int_ready || variant == 3, "the split variant that keeps the gradients (fused 2, which LES without the in-kernel closure selects) has no over-integration");
   if (split_stage(e, faces, nfb, in_step, write_div, 0, variant)) return 1;
   // the filter changes disu_upts(0) after the stage: redo the flux-point solution of the new state
   return shock ? shock_capture_keep_fpts(e) : 0;
@@ -825,11 +863,12 @@ int split_deferred_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_
 int split_run_steps(hfx_eles *e, hfx_inters *const *faces, int nfb, int n_steps, int variant)
 {
   HFX_CHECK(e->n_eles > 0, "fused path: empty element block");
-  // an LES closure reads the corrected gradients, which variant 3 keeps in registers: such a block runs variant 2
-  if (e->les_ready && variant == 3) variant = 2;
-  HFX_CHECK(!e->over_int_ready || variant == 3, "the split variant that keeps the gradients (fused 2, which LES selects) has no over-integration");
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
+  // an LES closure reads the corrected gradient: variant 3 evaluates it in the flux kernel where that kernel's loader-wave form
+  // runs (les_in_flux_kernel); otherwise such a block runs variant 2, which keeps the gradient in HBM for a pointwise kernel
+  if (e->les_ready && variant == 3 && !les_in_flux_kernel(e)) variant = 2;
+  HFX_CHECK(!e->over_int_ready || variant == 3, "the split variant that keeps the gradients (fused 2, which LES without the in-kernel closure selects) has no over-integration");
   if (n_steps <= 0) return 0;
   const int adv = e->ctx->params.adv_type;
   const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
@@ -863,36 +902,51 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
 {
   if (!e->fused || !e->fused->built)
     if (fused_build(e, faces, nfb)) return 1;
+  if (e->les_ready && variant == 3 && !les_in_flux_kernel(e)) variant = 2;
   const int adv = e->ctx->params.adv_type;
   const int nst = (adv == 0) ? 1 : (adv <= 2) ? 4 : (adv == 3) ? 5 : 14;
   hipStream_t st = e->ctx->stream;
   // one set of events per repetition and ONE synchronisation at the end: a host synchronisation per stage let the queue
   // run dry, and the first kernel after it (the flux kernel) then measured 10 % slower than in the running pipeline
-  std::vector<hipEvent_t> ev((size_t)reps * 5);
+  // the parts of a stage in launch order; part 2 in two pieces when the block de-aliases (variant 3: the over-integration kernel,
+  // then the flux kernel) or carries an LES closure (variant 2: the gradient kernel, then the SGS kernels) -- slot 4 of `ms`
+  const bool oi = variant == 3 && e->over_int_ready, sgs = variant == 2 && e->les_ready && e->ctx->params.viscous;
+  std::vector<int> parts = {1};
+  if (oi) { parts.push_back(5); parts.push_back(7); }
+  else if (sgs) { parts.push_back(8); parts.push_back(6); }
+  else parts.push_back(2);
+  parts.push_back(3);
+  parts.push_back(4);
+  const int np = (int)parts.size();
+  std::vector<hipEvent_t> ev((size_t)reps * (np + 1));
   for (auto &x : ev) HFX_HIP(hipEventCreate(&x));
   if (hfx_eles_extrapolate_solution(e)) return 1;
-  double acc[4] = {0, 0, 0, 0};
+  double acc[9] = {};
   for (int r = 0; r < reps; r++)
   {
     const int rk = r % nst;
-    for (int w = 1; w <= 4; w++)
+    for (int q = 0; q < np; q++)
     {
-      HFX_HIP(hipEventRecord(ev[5 * r + w - 1], st));
-      if (split_stage(e, faces, nfb, rk, rk == nst - 1, w, variant)) return 1;
+      HFX_HIP(hipEventRecord(ev[(np + 1) * r + q], st));
+      if (split_stage(e, faces, nfb, rk, rk == nst - 1, parts[q], variant)) return 1;
     }
-    HFX_HIP(hipEventRecord(ev[5 * r + 4], st));
+    HFX_HIP(hipEventRecord(ev[(np + 1) * r + np], st));
   }
   HFX_HIP(hipStreamSynchronize(st));
   for (int r = 0; r < reps; r++)
-    for (int w = 0; w < 4; w++)
+    for (int q = 0; q < np; q++)
     {
       float t = 0;
-      HFX_HIP(hipEventElapsedTime(&t, ev[5 * r + w], ev[5 * r + w + 1]));
-      acc[w] += t;
+      HFX_HIP(hipEventElapsedTime(&t, ev[(np + 1) * r + q], ev[(np + 1) * r + q + 1]));
+      acc[parts[q]] += t;
     }
   for (auto &x : ev) (void)hipEventDestroy(x);
   for (int i = 0; i < 8; i++) ms[i] = 0.0;
-  for (int w = 0; w < 4; w++) ms[w] = acc[w] / reps;
+  ms[0] = acc[1] / reps;
+  ms[1] = (acc[2] + acc[7] + acc[8]) / reps; // the element kernel of part 2 alone
+  ms[2] = acc[3] / reps;
+  ms[3] = acc[4] / reps;
+  ms[4] = (acc[5] + acc[6]) / reps;          // over-integration kernel | SGS kernels
   if (e->fused->stamps)
   {
     long long h[64];
@@ -911,15 +965,18 @@ int split_time_kernels(hfx_eles *e, hfx_inters *const *faces, int nfb, int reps,
     fprintf(stderr, "   (wait state | bar1 | issue state, wait metrics | bar2 | bar3 | issue metrics | bar4)  total %lld\n", h[3 * 16 + 7] - h[3 * 16]);
   }
   const bool tensor = e->fused->tensor_ok && !e->ctx->opt.dictionary_rows;
-  snprintf(names, names_len, "%s",
+  snprintf(names, names_len, "%s%s",
            variant == 3 ? (tensor ? "face_delta_kernel,split_flux_tensor_kernel,face_flux2_kernel,split_update_kernel"
                                   : "face_delta_kernel,split_flux_kernel,face_flux2_kernel,split_update_kernel")
-                        : "face_delta_kernel,split_gradient_kernel,face_flux_kernel,split_residual_kernel");
+                        : "face_delta_kernel,split_gradient_kernel,face_flux_kernel,split_residual_kernel",
+           oi ? (tensor_over_int_available(e) && e->ctx->contract_mode != HFX_CONTRACT_DENSE ? ",overint_tensor_kernel" : ",evaluate_invFlux_over_int (dense)")
+              : sgs ? ",sgsf_upts_kernel + ell_apply_kernel (SGS flux)" : "");
   return 0;
 }
 
 void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant)
 {
+  if (e->les_ready && variant == 3 && !les_in_flux_kernel(e)) variant = 2;
   // ALGORITHMIC HBM bytes per launch (doubles listed per element)
   const double nu = e->n_upts, nfp = e->n_fpts, nf = e->n_fields, nd = e->n_dims, ne = e->n_eles;
   for (int i = 0; i < 8; i++) bytes[i] = 0.0;
@@ -927,6 +984,9 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant)
   bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nf * nd); // + grad_fpts w
   bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf * nd + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp);   // disu, grad, normal(left), tdA r; tconf w
   bytes[3] = ne * 8.0 * (nu * nf + nu * (nd * nd + 1) + nfp * nf + 3 * nu * nf + nfp * nf);           // u, metrics, tconf, u1 r; u0,u1,disu w
+  if (variant == 2 && e->les_ready)
+    // SGS flux at the solution points (u, corrected gradient, metrics r; sgsf_upts w) and its extrapolation (sgsf_upts r, sgsf_fpts w)
+    bytes[4] = ne * 8.0 * (nu * nf + nu * nf * nd + nu * (nd * nd + 1) + 2 * nu * nf * nd + nfp * nf * nd);
   if (variant == 3)
   {
     // u, delta, volume + flux-point metrics, own normals r ; div, norm_tdisf, Fn w
@@ -935,6 +995,19 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant)
     bytes[1] = ne * 8.0 * (nu * nf + nfp * nf + nu * (nd * nd + 1) + nfp * (nd * nd + 1) + nfp * nd + nu * nf + nfp * nf + ntd);
     bytes[2] = ne * (8.0 * (nfp * nf + nfp * nf + 0.5 * nfp * nd + nfp + nfp * nf) + 4.0 * nfp); // disu, Fn, normal(left), tdA r; tconf w
     bytes[3] = ne * 8.0 * (3 * nu * nf + nu + nfp * nf + ntd + 2 * nu * nf + nfp * nf);          // u0,u1,div,detjac,tconf(,ntd) r; u0,u1,disu w
+    if (e->les_ready)
+    {
+      // the closure in the flux kernel: tdA at the flux points, the Leonard terms of the similarity models, the wall distance of
+      // the damped Smagorinsky model
+      const int m = e->les.sgs_model;
+      bytes[1] += ne * 8.0 * (nfp + ((m == 2 || m == 4) ? nu * (nd == 3 ? 9.0 : 5.0) : 0.0) + (m == 0 ? nu * nd : 0.0));
+    }
+    if (e->over_int_ready)
+    {
+      // the flux kernel reads the de-aliased flux too; the over-integration kernel: u, the metric tensors at the cubature points r, tdisf w
+      bytes[1] += ne * 8.0 * nu * nf * nd;
+      bytes[4] = ne * 8.0 * (nu * nf + nd * nd * e->n_cubpts + nu * nf * nd);
+    }
     if (e->fused && e->fused->gather_on)
     {
       // the flux kernel reads the partners' flux-point solution (as many doubles as the corrections it no longer reads) and

@@ -18,6 +18,8 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant = 2);
 // which split variant a partitioned block runs: 2 (the reference's gradient arrays kept) when the context asks for it or the
 // block has an LES closure, else 3
 int split_variant(const hfx_eles *e);
+// an LES closure evaluated inside the flux kernel of variant 3 (needs the block's fused tables)
+bool les_in_flux_kernel(const hfx_eles *e);
 // one phase of a split-path stage on a partitioned block (see hfx_stage_partitioned)
 int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                             int phase, int in_step, int first);

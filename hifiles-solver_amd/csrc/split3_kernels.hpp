@@ -63,6 +63,11 @@ struct Split2Args
   Phys P;
   int adv_type, in_step, dt_local_on, write_div, need_u1;
   double dt, rk_a, rk_b;
+  // LES closure evaluated in the flux kernel (split_flux_tensor_kernel<..., LES = true>): eles::calc_sgsf_upts at the solution
+  // points; wall_distance (n_upts,n_eles,n_dims) for the Smagorinsky damping; tdA_fpts to take the extrapolated SGS flux of a
+  // flux point from F~ . n~ to F . n
+  LesParams les;
+  const double *wall_distance, *tdA_fpts;
 };
 
 template <int ND, int N>
@@ -438,7 +443,17 @@ constexpr bool loader_wave_fits()
 // an LDS slot by buffer_load ... lds -- no registers, requested a whole element ahead and counted on the loader's own
 // vmcnt, so the compute waves never wait for them (the register prefetch of the LW = false form is issued in phase C
 // and still needs ~2 500 cycles at the top of the next iteration: the kernel is bound by bytes in flight per CU).
-template <int ND, int N, int WV, bool BUF, bool OI, bool LW, bool GA = false>
+// LES: the eddy-viscosity / similarity closure of an LES run (eles::calc_sgsf_upts, src/eles.cpp:2395-2650) is evaluated HERE,
+// on the corrected gradient the solution-point threads hold, instead of by a pointwise kernel on a gradient array in HBM:
+//   * solution points: F_sgs joins the total flux (evaluate_viscFlux adds it, src/eles.cpp:2360-2392);
+//   * flux points: the reference extrapolates the TRANSFORMED SGS flux (sgsf_fpts = opp_0 sgsf_upts), takes it back to
+//     physical space and adds it to each side's viscous flux in the common-flux sweep (src/eles.cpp:2817-2893,
+//     src/int_inters.cpp:299-313).  What the face kernel needs of it is F_sgs . n = (F~_sgs . n~) / tdA, and on a
+//     tensor-product element F~_sgs . n~ at a flux point is +- the 1-D extrapolation of ONE component along the point's pencil:
+//     a second, short pencil pass (two more barriers) over the transformed SGS flux the solution-point threads kept in
+//     registers, whose result joins Fn before it is stored.
+// So an LES stage moves the bytes of a plain one (+ tdA, the Leonard terms of the similarity models) in the same three launches.
+template <int ND, int N, int WV, bool BUF, bool OI, bool LW, bool GA = false, bool LES = false>
 __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_flux_tensor_kernel(const Split2Args a,
                                                                                                const double *coef_g,
                                                                                                const int *tidx)
@@ -452,6 +467,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
   constexpr int NUS = LW ? ((NU + 1) & ~1) : NU;
   constexpr int U_DW = 2 * NF * NUS, D_DW = 2 * NF * NFP, SLOT = (U_DW + D_DW) / 2;
   static_assert(!LW || BUF, "the loader wave addresses through buffer descriptors");
+  static_assert(!LES || (LW && !OI), "the in-kernel LES closure belongs to the loader-wave form without over-integration");
   __shared__ double sA[R1];      // su | sd, later st
   __shared__ double sB[NG * NU]; // sg, later the per-direction parts of the divergence
   __shared__ double s_in[LW ? 2 * SLOT : 1];
@@ -734,6 +750,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
           lstamp(kk, 6);
         }
         lds_barrier(); // 4
+        if constexpr (LES)
+        {
+          lds_barrier(); // 5: (the transformed SGS flux is in the work region)
+          lds_barrier(); // 6: (its pencil ends are in the correction region of the input slot)
+        }
         lstamp(kk, 7);
       }
 #undef HFX_VMCNT
@@ -809,6 +830,9 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     stamp(2);
     ef_cur = ef;
     double u[NF], uf[NF];
+    // LES: what outlives phase B -- the transformed SGS flux of this solution point, the projected viscous flux and the face
+    // Jacobian of this flux point
+    [[maybe_unused]] double tsg[LES ? NG : 1], tdA_f = 1.0, wall_y = 0.0, wd[LES ? ND : 1];
     double accg[GA ? ROUNDS : 1][N]; // GA: the pencils' D . u, formed in A0 while the partner values are waited for
     if constexpr (GA)
     {
@@ -1022,6 +1046,18 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       for (int l = 0; l < ND; l++) nr2[l] = ldsv(&s_met[O_NRM + l * NFPP + tf]);
       inv2[0] = ldsv(&s_met[O_DJU + tu]);
       inv2[1] = ldsv(&s_met[O_DJF + tf]);
+      [[maybe_unused]] const double dju_raw = inv2[0];
+      if constexpr (LES)
+      {
+        // requested here, used behind the paired physics
+        tdA_f = a.tdA_fpts[ef + tf];
+        wall_y = 0.0;
+        if (a.les.sgs_model == 0)
+        {
+#pragma unroll
+          for (int i = 0; i < ND; i++) wd[i] = a.wall_distance[eu + tu + i * plane_u];
+        }
+      }
       lds_barrier(); // 2b: the metric slot is free, the loader requests the next element's metrics
       inv2[0] = 1.0 / inv2[0];
       inv2[1] = 1.0 / inv2[1];
@@ -1074,7 +1110,20 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         for (int q = 0; q < NG; q++) g_gf.st(ef + q * plane_f, lf, g2[1][q]);
       calc_visf_pair<ND>(a.P, u2, g2, f2);
       // flux point: this side's viscous flux on its own normal
-      if (is_f)
+      if constexpr (LES)
+      {
+        // (parked in the correction region of this element's input slot, dead since phase A: the extrapolated SGS flux joins it
+        // behind phase C)
+#pragma unroll
+        for (int k = 0; k < NF; k++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < ND; l++) s += f2[1][k + NF * l] * nr2[l];
+          if (is_f) sd[k * NFP + tf] = s;
+        }
+      }
+      else if (is_f)
       {
 #pragma unroll
         for (int k = 0; k < NF; k++)
@@ -1101,6 +1150,36 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 #pragma unroll
           for (int q = 0; q < NG; q++) ft[q] += f2[0][q];
         }
+        if constexpr (LES)
+        {
+          // the closure on this point's corrected gradient (physical space); its flux, transformed, is kept for the pencil
+          // pass behind phase C and joins the total flux here.  (The physical flux waits in this thread's own st column
+          // meanwhile: the closure needs the registers.)
+#pragma unroll
+          for (int q = 0; q < NG; q++) st[q * NU + tu] = ft[q];
+          asm volatile("" ::: "memory");
+          double sgq[NG];
+          if (a.les.sgs_model == 0)
+          {
+            double y2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < ND; i++) y2 += wd[i] * wd[i];
+            wall_y = sqrt(y2);
+          }
+          calc_sgsf<ND, true>(a.P, a.les, u, g2[0], dju_raw, wall_y, eu + tu, plane_u, sgq);
+#pragma unroll
+          for (int k = 0; k < NF; k++)
+#pragma unroll
+            for (int l = 0; l < ND; l++)
+            {
+              double ts = 0.0;
+#pragma unroll
+              for (int m = 0; m < ND; m++) ts += jg2[0][l + ND * m] * sgq[k + NF * m];
+              tsg[k + NF * l] = ts;
+            }
+#pragma unroll
+          for (int q = 0; q < NG; q++) ft[q] = ldsv(&st[q * NU + tu]);
+        }
 #pragma unroll
         for (int k = 0; k < NF; k++)
 #pragma unroll
@@ -1109,6 +1188,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
             double s = OI ? td[k + NF * l] : 0.0;
 #pragma unroll
             for (int m = 0; m < ND; m++) s += jg2[0][l + ND * m] * ft[k + NF * m];
+            if constexpr (LES) s += tsg[k + NF * l];
             st[(k + NF * l) * NU + tu] = s;
           }
       }
@@ -1317,6 +1397,56 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         s += part[1][k];
         if (ND == 3) s += part[ND - 1][k];
         g_div.st(eu + k * plane_u, lu, s);
+      }
+    }
+    if constexpr (LES)
+    {
+      // ---- E: F_sgs . n at the flux points.  The transformed SGS flux goes where the total flux was (dead since barrier 4) ...
+      if (is_u)
+      {
+#pragma unroll
+        for (int q = 0; q < NG; q++) st[q * NU + tu] = tsg[q];
+      }
+      lds_barrier(); // 5
+      // ... every pencil item extrapolates its component to the pencil's two ends: +- L . F~_sgs,d = (F~_sgs . n~) there,
+      // left where the divergence parts were (read by phase D, before barrier 5) under the ends' flux-point numbers ...
+      {
+        double xs[ROUNDS][N];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+        {
+          const int d = it_dq[r];
+          const int srr = (d == 0) ? 1 : (d == 1 ? N : N * N);
+#pragma unroll
+          for (int m = 0; m < N; m++) xs[r][m] = ldsv(st + it_o[r] + m * srr);
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+        {
+          const int d = it_dq[r];
+          double na = 0.0, nb = 0.0;
+#pragma unroll
+          for (int m = 0; m < N; m++)
+          {
+            na += coef[T::C_LF + (d * 2 + 0) * N + m] * xs[r][m];
+            nb += coef[T::C_LF + (d * 2 + 1) * N + m] * xs[r][m];
+          }
+          na *= coef[T::C_L1 + (d * 2 + 0) * N];
+          nb *= coef[T::C_L1 + (d * 2 + 1) * N];
+          if (it_d[r] >= 0)
+          {
+            sp[it_fa[r]] = na;
+            sp[it_fb[r]] = nb;
+          }
+        }
+      }
+      lds_barrier(); // 6
+      // ... and joins this side's projected viscous flux: Fn = (F_v + F_sgs) . n
+      if (is_f)
+      {
+        const double itd = 1.0 / tdA_f;
+#pragma unroll
+        for (int k = 0; k < NF; k++) g_fn.st(ef + k * plane_f, lf, ldsv(&sd[k * NFP + tf]) + ldsv(&sp[k * NFP + tf]) * itd);
       }
     }
     stamp(9);

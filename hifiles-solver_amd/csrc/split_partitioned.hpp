@@ -23,9 +23,10 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
   a.out_disu = f->out_disu; a.out_grad = f->out_grad; a.in_disu = f->in_disu; a.in_grad = f->in_grad;
   a.fn = e->fused ? e->fused->fn_fpts : nullptr;
   a.P = e->ctx->phys();
-  if (e->les_ready)
+  if (e->les_ready && split_variant(e) == 2)
   {
     // the split path (variant 2) keeps sgsf_fpts in reference space: the partition-face kernels take it to physical space
+    // (variant 3: the SGS flux is part of the projected flux Fn the kernels move anyway)
     if (hfx_mpi_sgsf_buffers_internal(f)) return 1;
     a.sgsf = e->arr[HFX_SGSF_FPTS]; a.jac_fpts = e->Jacobian_fpts; a.detjac_fpts = e->detjac_fpts;
     a.out_sgsf = f->out_sgsf; a.in_sgsf = f->in_sgsf; a.sgs_ref = 1;
@@ -47,7 +48,8 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
   return 0;
 }
 
-int split_variant(const hfx_eles *e) { return (e->ctx->fused_mode == 2 || e->les_ready) ? 2 : 3; }
+// (with an LES closure: 3 where the flux kernel evaluates the closure itself -- needs the block's fused tables, fused_build)
+int split_variant(const hfx_eles *e) { return (e->ctx->fused_mode == 2 || (e->les_ready && !les_in_flux_kernel(e))) ? 2 : 3; }
 
 int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                             int phase, int in_step, int first)

@@ -89,7 +89,7 @@ def test_plot_point_interpolation(name):
     c.close()
 
 
-@pytest.mark.parametrize("mode", ["methods", 2])
+@pytest.mark.parametrize("mode", ["methods", "calls", 2, 3])
 @pytest.mark.parametrize("name,dims", [("hex_p2_les_wale", 3), ("quad_p3_les_wale", 2)])
 def test_les_wale_through_the_mirror(name, dims, mode):
     """LES (WALE closure) from the mesh and the input keys: the mirrored CalcResidual (evaluate_viscFlux +
@@ -100,18 +100,20 @@ def test_les_wale_through_the_mirror(name, dims, mode):
     n = meta["n"] if isinstance(meta["n"], list) else [meta["n"]] * dims
     c = H.Case(n + [1] * (3 - len(n)), xv=d["xv"], dims=dims, order=k["order"], LES=1, SGS_model=k["SGS_model"], C_s=k["C_s"],
                filter_ratio=k["filter_ratio"], T_c_ic=k["T_c_ic"])
+    if mode == "calls":
+        c.set_deferred(False)  # every mirrored call launches its own kernels: the per-method path
     c.to_device(0)
-    if mode == "methods":
-        c.run(1)
+    if mode in ("methods", "calls"):
+        c.run(1)  # "methods": deferred, i.e. the split stage with the closure in the flux kernel (variant 3)
     else:
-        c.run_steps_lib(1, fused=mode)
+        c.run_steps_lib(1, fused=mode)  # 2: the closure as a pointwise kernel on the gradient array; 3: in the flux kernel
     c.sync_host()
     last = int(d["sizes"][7]) - 1
     assert rel(c.array("disu_upts0"), d["u_step0_stage%d" % last]) < 1e-11
     c.close()
 
 
-@pytest.mark.parametrize("mode", ["methods", 2])
+@pytest.mark.parametrize("mode", ["methods", "calls", 2, 3])
 @pytest.mark.parametrize("name", ["hex_p2_les_wsm", "hex_p2_les_sim", "hex_p2_les_svv"])
 def test_les_filtered_closures_through_the_mirror(name, mode):
     """SGS_model 2 / 4 / 3 from the mesh and the input keys: the mirror builds filter_upts (compute_filter_upts),
@@ -123,8 +125,10 @@ def test_les_filtered_closures_through_the_mirror(name, mode):
     c = H.Case(n, xv=d["xv"], dims=3, order=k["order"], LES=1, SGS_model=k["SGS_model"], C_s=k["C_s"],
                filter_ratio=k["filter_ratio"], filter_type=k["filter_type"], T_c_ic=k["T_c_ic"])
     assert rel(c.array("filter_upts"), d["filter_upts"]) < 1e-12
+    if mode == "calls":
+        c.set_deferred(False)
     c.to_device(0)
-    if mode == "methods":
+    if mode in ("methods", "calls"):
         c.run(2)
     else:
         c.run_steps_lib(2, fused=mode)
