@@ -33,14 +33,16 @@ namespace hfx
 
 void fused_invalidate(hfx_eles *e)
 {
-  if (e && e->fused) e->fused->built = false;
+  if (!e || !e->fused) return;
+  e->fused->built = false;
+  if (e->fused->les_len2) { (void)hipFree(e->fused->les_len2); e->fused->les_len2 = nullptr; } // (follows the registered closure)
 }
 
 void fused_destroy(hfx_eles *e)
 {
   if (!e || !e->fused) return;
   FusedData *f = e->fused;
-  void *p[] = {f->meta, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim, f->nbr};
+  void *p[] = {f->meta, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim, f->nbr, f->les_len2};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete f;
@@ -538,6 +540,41 @@ struct LoaderWaveLaunch<ND, N, OI, GA, LES, true>
   }
 };
 
+// The squared length scale of the eddy-viscosity closures at every solution point, min(y^2 Kappa^2, C_s^2 Delta^2) for the damped
+// Smagorinsky model and C_s^2 Delta^2 for WALE (src/eles.cpp:2436-2520, Delta = filter_ratio vol^(1/n_dims) / (order + 1) with
+// vol = detjac * 2^n_dims): it depends on the metrics and the wall distance only, so the flux kernel reads it instead of
+// evaluating a cube root per point and stage.  Evaluated once on the host with the reference's own expression.
+static int les_len2_build(hfx_eles *e)
+{
+  FusedData *F = e->fused;
+  if (F->les_len2) return 0;
+  const long plane = (long)e->n_upts * e->n_eles;
+  std::vector<double> dj(plane), len2(plane), wd;
+  HFX_HIP(hipMemcpy(dj.data(), e->detjac_upts, sizeof(double) * plane, hipMemcpyDeviceToHost));
+  const int nd = e->n_dims;
+  if (e->les.sgs_model == 0)
+  {
+    HFX_CHECK(e->wall_distance, "the Smagorinsky closure needs wall_distance");
+    wd.resize((size_t)plane * nd);
+    HFX_HIP(hipMemcpy(wd.data(), e->wall_distance, sizeof(double) * wd.size(), hipMemcpyDeviceToHost));
+  }
+  for (long p = 0; p < plane; p++)
+  {
+    const double vol = dj[p] * (nd == 3 ? 8. : 4.);
+    const double delta = e->les.filter_ratio * std::pow(vol, 1. / nd) / (e->les.order + 1.);
+    double l2 = e->les.C_s * e->les.C_s * delta * delta;
+    if (e->les.sgs_model == 0)
+    {
+      double y = 0.0;
+      for (int i = 0; i < nd; i++) y += wd[p + (size_t)i * plane] * wd[p + (size_t)i * plane];
+      y = std::sqrt(y);
+      l2 = std::fmin(y * y * e->les.Kappa * e->les.Kappa, l2);
+    }
+    len2[p] = l2;
+  }
+  return upload((void **)&F->les_len2, len2.data(), sizeof(double) * plane);
+}
+
 // runtime form of loader_wave_fits
 static bool loader_wave_fits_rt(int nd, int N)
 {
@@ -617,7 +654,9 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;
     e2.adv_type = ea.adv_type; e2.in_step = ea.in_step; e2.dt_local_on = ea.dt_local_on; e2.write_div = ea.write_div;
     e2.need_u1 = ea.need_u1; e2.dt = ea.dt; e2.rk_a = ea.rk_a; e2.rk_b = ea.rk_b;
-    e2.les = e->les; e2.wall_distance = e->wall_distance; e2.tdA_fpts = e->tdA_fpts;
+    e2.les = e->les; e2.tdA_fpts = e->tdA_fpts;
+    if (e->les_ready && e->les.sgs_model != 3 && les_len2_build(e)) return 1;
+    e2.les_len2 = F->les_len2;
   }
   // Will the flux kernel form the LDG corrections of the interior points itself?  (the loader-wave form of the sum-factorised
   // kernel only: same conditions as its selection below)
@@ -997,10 +1036,9 @@ void split_kernel_bytes(const hfx_eles *e, double *bytes, int variant)
     bytes[3] = ne * 8.0 * (3 * nu * nf + nu + nfp * nf + ntd + 2 * nu * nf + nfp * nf);          // u0,u1,div,detjac,tconf(,ntd) r; u0,u1,disu w
     if (e->les_ready)
     {
-      // the closure in the flux kernel: tdA at the flux points, the Leonard terms of the similarity models, the wall distance of
-      // the damped Smagorinsky model
+      // the closure in the flux kernel: tdA at the flux points, the squared length scale, the Leonard terms of the similarity models
       const int m = e->les.sgs_model;
-      bytes[1] += ne * 8.0 * (nfp + ((m == 2 || m == 4) ? nu * (nd == 3 ? 9.0 : 5.0) : 0.0) + (m == 0 ? nu * nd : 0.0));
+      bytes[1] += ne * 8.0 * (nfp + nu + ((m == 2 || m == 4) ? nu * (nd == 3 ? 9.0 : 5.0) : 0.0)); // tdA, length scale, Leonard terms
     }
     if (e->over_int_ready)
     {

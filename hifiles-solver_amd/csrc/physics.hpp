@@ -449,9 +449,7 @@ struct LesParams
 };
 
 // p, plane: the point's offset and the (point, element) plane size of Lu / Le (similarity terms only)
-// FAST (the fused flux kernel): the reference's pow() calls with the exponents 1/3, 5/2, 5/4, 3/2 as cbrt / sqrt products and the
-// divisions by rho as one reciprocal -- the same quantities to rounding, a fifth of the instructions and registers
-template <int ND, bool FAST = false>
+template <int ND>
 __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, const double (&tu)[ND + 2],
                                           const double (&g)[(ND + 2) * ND], const double detjac, const double y, const long p,
                                           const long plane, double (&sg)[(ND + 2) * ND])
@@ -468,8 +466,7 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
   }
   const double inte = tu[NF - 1] / rho - ke;
   const double vol = detjac * (ND == 3 ? 8. : 4.); // calc_ele_vol of hexes / quads
-  const double delta = Lp.filter_ratio * (FAST ? (ND == 3 ? cbrt(vol) : sqrt(vol)) : pow(vol, 1. / ND)) / (Lp.order + 1.);
-  [[maybe_unused]] const double inv_rho = 1.0 / rho;
+  const double delta = Lp.filter_ratio * pow(vol, 1. / ND) / (Lp.order + 1.);
 #pragma unroll
   for (int i = 0; i < ND; i++)
   {
@@ -485,10 +482,10 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
 #pragma unroll
     for (int j = 0; j < ND; j++)
     {
-      du[i][j] = FAST ? (dmom[i][j] - u[j] * drho[i]) * inv_rho : (dmom[i][j] - u[j] * drho[i]) / rho;
+      du[i][j] = (dmom[i][j] - u[j] * drho[i]) / rho;
       dke[i] += rho * u[j] * du[i][j];
     }
-    de[i] = FAST ? (dene[i] - dke[i] - drho[i] * inte) * inv_rho : (dene[i] - dke[i] - drho[i] * inte) / rho;
+    de[i] = (dene[i] - dke[i] - drho[i] * inte) / rho;
   }
 #pragma unroll
   for (int i = 0; i < ND; i++)
@@ -543,16 +540,8 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
         num += Sq[i][j] * Sq[i][j];
         denom += S[i][j] * S[i][j];
       }
-    if (FAST)
-    {
-      denom = denom * denom * sqrt(denom) + num * sqrt(sqrt(num));
-      num = num * sqrt(num);
-    }
-    else
-    {
-      denom = pow(denom, 2.5) + pow(num, 1.25);
-      num = pow(num, 1.5);
-    }
+    denom = pow(denom, 2.5) + pow(num, 1.25);
+    num = pow(num, 1.5);
     mu_t = rho * Lp.C_s * Lp.C_s * delta * delta * num / (denom + 1.e-12);
   }
 #pragma unroll
@@ -580,6 +569,135 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
   {
     // src/eles.cpp:2602-2634; the off-diagonal momentum entries are filled from their transposes AFTER those received
     // their own term (and the eddy part), as the reference does
+#pragma unroll
+    for (int j = 0; j < ND; j++) sg[(NF - 1) + NF * j] += P.gamma * rho * Lp.Le[p + j * plane];
+    if (ND == 2)
+    {
+      sg[1 + NF * 0] += rho * Lp.Lu[p + 0 * plane];
+      sg[1 + NF * 1] += rho * Lp.Lu[p + 2 * plane];
+      sg[2 + NF * 0] += sg[1 + NF * 1];
+      sg[2 + NF * 1] += rho * Lp.Lu[p + 1 * plane];
+    }
+    else
+    {
+      sg[1 + NF * 0] += rho * Lp.Lu[p + 0 * plane];
+      sg[1 + NF * 1] += rho * Lp.Lu[p + 3 * plane];
+      sg[1 + NF * (ND - 1)] += rho * Lp.Lu[p + 4 * plane];
+      sg[2 + NF * 0] += sg[1 + NF * 1];
+      sg[2 + NF * 1] += rho * Lp.Lu[p + 1 * plane];
+      sg[2 + NF * (ND - 1)] += rho * Lp.Lu[p + 5 * plane];
+      sg[(NF - 2) + NF * 0] += sg[1 + NF * (ND - 1)];
+      sg[(NF - 2) + NF * 1] += sg[2 + NF * (ND - 1)];
+      sg[(NF - 2) + NF * (ND - 1)] += rho * Lp.Lu[p + 2 * plane];
+    }
+  }
+}
+
+// The same closure for the fused flux kernel (split_flux_tensor_kernel<..., LES>), where it runs as ONE dependency chain per
+// thread with nothing beside it: the squared length scale of the point -- min(y^2 Kappa^2, C_s^2 Delta^2) of the damped
+// Smagorinsky model, C_s^2 Delta^2 of WALE; it depends on the metrics and the wall distance only -- comes precomputed
+// (len2, evaluated once on the host exactly as above), the divisions by rho, 3 and Pr_t are multiplications by reciprocals and
+// the reference's pow() calls with the exponents 5/2, 5/4, 3/2 are sqrt products: the same quantities to rounding.
+template <int ND>
+__device__ __forceinline__ void calc_sgsf_fast(const Phys &P, const LesParams &Lp, const double (&tu)[ND + 2],
+                                               const double (&g)[(ND + 2) * ND], const double len2, const long p, const long plane,
+                                               double (&sg)[(ND + 2) * ND])
+{
+  constexpr int NF = ND + 2;
+  double u[ND], de[ND], du[ND][ND], S[ND][ND];
+  const double rho = tu[0], ir = 1.0 / rho, third = 1.0 / 3.0;
+  double ke = 0.;
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+  {
+    u[i] = tu[i + 1] * ir;
+    ke += 0.5 * (u[i] * u[i]);
+  }
+  const double inte = tu[NF - 1] * ir - ke;
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+  {
+    const double drho = g[0 + NF * i];
+    double dke = ke * drho;
+#pragma unroll
+    for (int j = 0; j < ND; j++)
+    {
+      du[i][j] = (g[(j + 1) + NF * i] - u[j] * drho) * ir;
+      dke += rho * u[j] * du[i][j];
+    }
+    de[i] = (g[(NF - 1) + NF * i] - dke - drho * inte) * ir;
+  }
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int j = 0; j < ND; j++) S[i][j] = (du[i][j] + du[j][i]) * 0.5;
+  const bool eddy = Lp.sgs_model <= 2, sim = Lp.sgs_model == 2 || Lp.sgs_model == 4;
+  double mu_t = 0.0;
+  if (!eddy)
+    ;
+  else if (Lp.sgs_model == 0)
+  {
+    double Smod = 0.0;
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++) Smod += 2.0 * S[i][j] * S[i][j];
+    mu_t = rho * len2 * sqrt(Smod);
+  }
+  else
+  {
+    double num = 0.0, den = 0.0, gT[ND][ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++)
+      {
+        double s = 0.;
+#pragma unroll
+        for (int l = 0; l < ND; l++) s += du[i][l] * du[l][j];
+        gT[i][j] = s;
+      }
+    double diag = 0.0;
+#pragma unroll
+    for (int i = 0; i < ND; i++) diag += gT[i][i] * third;
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++)
+      {
+        double sq = 0.5 * gT[j][i] + 0.5 * gT[i][j];
+        if (i == j) sq -= diag;
+        num += sq * sq;
+        den += S[i][j] * S[i][j];
+      }
+    const double sn = sqrt(num);
+    const double denom = den * den * sqrt(den) + num * sqrt(sn);
+    mu_t = rho * len2 * (num * sn) / (denom + 1.e-12);
+  }
+#pragma unroll
+  for (int q = 0; q < NF * ND; q++) sg[q] = 0.0;
+  if (eddy)
+  {
+    double diag = 0.;
+#pragma unroll
+    for (int i = 0; i < ND; i++) diag += S[i][i] * third;
+#pragma unroll
+    for (int i = 0; i < ND; i++) S[i][i] -= diag;
+    const double kt = -1.0 * P.gamma * mu_t / Lp.prandtl_t, m2 = 2.0 * mu_t;
+#pragma unroll
+    for (int j = 0; j < ND; j++)
+    {
+      double ef = kt * de[j];
+#pragma unroll
+      for (int k = 0; k < ND; k++) ef -= u[k] * m2 * S[k][j];
+      sg[(NF - 1) + NF * j] = ef;
+#pragma unroll
+      for (int i = 1; i < NF - 1; i++) sg[i + NF * j] = -m2 * S[i - 1][j];
+    }
+  }
+  if (sim)
+  {
+    // (src/eles.cpp:2602-2634, as in calc_sgsf: the off-diagonal momentum entries from their transposes AFTER those got their own)
 #pragma unroll
     for (int j = 0; j < ND; j++) sg[(NF - 1) + NF * j] += P.gamma * rho * Lp.Le[p + j * plane];
     if (ND == 2)

@@ -67,7 +67,7 @@ struct Split2Args
   // points; wall_distance (n_upts,n_eles,n_dims) for the Smagorinsky damping; tdA_fpts to take the extrapolated SGS flux of a
   // flux point from F~ . n~ to F . n
   LesParams les;
-  const double *wall_distance, *tdA_fpts;
+  const double *les_len2, *tdA_fpts; // les_len2 (n_upts,n_eles): the closure's squared length scale (calc_sgsf_fast)
 };
 
 template <int ND, int N>
@@ -271,12 +271,6 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_SPLIT2_WAVES) void split_flu
 // =======================================================================================
 #ifndef HFX_SPLIT2T_WAVES
 #define HFX_SPLIT2T_WAVES 2
-#endif
-#ifndef HFX_NO_PAIR
-#define HFX_NO_PAIR 0 // 1: the unpaired point physics also in the loader-wave kernel (A/B builds)
-#endif
-#ifndef HFX_FLUX_FMETRICS
-#define HFX_FLUX_FMETRICS 0
 #endif
 
 // constant address space: loads with a wave-uniform address are selected as scalar loads
@@ -636,8 +630,8 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     // waits for this (last issued) load and with it for the whole prefetch
     detjac_raw = g_dju.ld((long)NU * e, lu);
   };
-  // flux-point metrics of the current element (HFX_FLUX_FMETRICS: where they are requested -- 0: at their use in
-  // phase B, behind the solution-point block; 1: at the top of phase B; 2: at the top of phase A)
+  // flux-point metrics of the current element, requested at their use in phase B, behind the solution-point block (requested at
+  // the top of phase B or of phase A they cost registers and gained nothing: DESIGN.md 5.1)
   double JF[ND * ND], nrm[ND], djf_raw = 1.0;
   long ef_cur = 0;
   auto fetch_fmetrics = [&]() {
@@ -732,7 +726,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         lstamp(kk, 3);
         lds_barrier(); // 2: the compute waves may read the metric slot
         lstamp(kk, 4);
-        if (viscous && !HFX_NO_PAIR)
+        if (viscous)
         {
           // paired physics: the compute waves take their metrics into registers at the top of phase B and say so (2b):
           // the slot is refilled most of an iteration ahead of its next use
@@ -832,7 +826,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     double u[NF], uf[NF];
     // LES: what outlives phase B -- the transformed SGS flux of this solution point, the projected viscous flux and the face
     // Jacobian of this flux point
-    [[maybe_unused]] double tsg[LES ? NG : 1], tdA_f = 1.0, wall_y = 0.0, wd[LES ? ND : 1];
+    [[maybe_unused]] double tsg[LES ? NG : 1], tdA_f = 1.0, len2 = 0.0;
     double accg[GA ? ROUNDS : 1][N]; // GA: the pencils' D . u, formed in A0 while the partner values are waited for
     if constexpr (GA)
     {
@@ -897,9 +891,6 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       lds_barrier(); // 1b
       stamp(13);
     }
-#if HFX_FLUX_FMETRICS == 2
-    fetch_fmetrics();
-#endif
     // over-integration: the de-aliased inviscid flux of this point is requested here, a phase ahead of its use
     double td[OI ? NG : 1];
     if (OI && is_u)
@@ -1021,12 +1012,8 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 
 
     __builtin_amdgcn_sched_barrier(0);
-#if HFX_FLUX_FMETRICS == 1
-    fetch_fmetrics();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
-    if (LW && viscous && !HFX_NO_PAIR)
+    if (LW && viscous)
     {
       // PAIRED form (loader-wave kernel: registers to spare).  A thread's solution point and its flux point go through
       // metric transform and viscous flux together, statement by statement -- two independent dependency chains, so the
@@ -1046,17 +1033,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       for (int l = 0; l < ND; l++) nr2[l] = ldsv(&s_met[O_NRM + l * NFPP + tf]);
       inv2[0] = ldsv(&s_met[O_DJU + tu]);
       inv2[1] = ldsv(&s_met[O_DJF + tf]);
-      [[maybe_unused]] const double dju_raw = inv2[0];
       if constexpr (LES)
       {
         // requested here, used behind the paired physics
         tdA_f = a.tdA_fpts[ef + tf];
-        wall_y = 0.0;
-        if (a.les.sgs_model == 0)
-        {
-#pragma unroll
-          for (int i = 0; i < ND; i++) wd[i] = a.wall_distance[eu + tu + i * plane_u];
-        }
+        len2 = a.les_len2[eu + tu];
       }
       lds_barrier(); // 2b: the metric slot is free, the loader requests the next element's metrics
       inv2[0] = 1.0 / inv2[0];
@@ -1159,14 +1140,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
           for (int q = 0; q < NG; q++) st[q * NU + tu] = ft[q];
           asm volatile("" ::: "memory");
           double sgq[NG];
-          if (a.les.sgs_model == 0)
-          {
-            double y2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < ND; i++) y2 += wd[i] * wd[i];
-            wall_y = sqrt(y2);
-          }
-          calc_sgsf<ND, true>(a.P, a.les, u, g2[0], dju_raw, wall_y, eu + tu, plane_u, sgq);
+          calc_sgsf_fast<ND>(a.P, a.les, u, g2[0], len2, eu + tu, plane_u, sgq);
 #pragma unroll
           for (int k = 0; k < NF; k++)
 #pragma unroll
@@ -1259,10 +1233,8 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
     if (viscous && is_f)
     {
       double grf[NG], fq[NG];
-#if HFX_FLUX_FMETRICS == 0
       // flux-point metrics are fetched here, after the solution-point block has released its registers
       fetch_fmetrics();
-#endif
       const double inv_df = 1.0 / djf_raw;
 #pragma unroll
       for (int q = 0; q < NG; q++) grf[q] = 0.0;

@@ -29,6 +29,7 @@ struct FusedData
   double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)
   int *o1m_dim = nullptr;                    // (n_fpts) dimension slab of the merged opp_1 row
   int *nbr = nullptr;                        // (n_fpts, n_eles) partner of every interior flux point (split3_kernels.hpp, Split2Args::nbr)
+  double *les_len2 = nullptr;                // (n_upts, n_eles) squared length scale of the LES closure evaluated in the flux kernel
   bool gather_on = false;                    // the last stage formed the interior LDG corrections in the flux kernel (no face_delta launch)
   bool built = false;
 };
