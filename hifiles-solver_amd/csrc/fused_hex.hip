@@ -649,6 +649,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     e2.stamps = F->stamps;
     e2.stamp_it = std::max(2, opt.flux_stamps);
     e2.simd_roles = opt.simd_roles ? 1 : 0;
+    e2.light_short = opt.light_wave_short ? 1 : 0;
     e2.o3v = e->opp_3.ell_val; e2.o3i = e->opp_3.ell_idx; e2.o3w = std::max(e->opp_3.nnz_max, 1);
     e2.o0v = e->opp_0.ell_val; e2.o0i = e->opp_0.ell_idx; e2.o0w = std::max(e->opp_0.nnz_max, 1);
     e2.src = ea.src; e2.dt_local = ea.dt_local; e2.nan_flag = ea.nan_flag; e2.P = ea.P;

@@ -406,6 +406,7 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   else if (n == "flux_stamps") o.flux_stamps = value;
   else if (n == "simd_roles") o.simd_roles = value != 0;
   else if (n == "les_flux_kernel") o.les_flux_kernel = value != 0;
+  else if (n == "light_wave_short") o.light_wave_short = value != 0;
   else if (n == "tensor_ops") o.tensor_ops = value != 0;
   else if (n == "dense_waves") { HFX_CHECK(value == 0 || value == 4 || value == 8, "dense_waves must be 0, 4 or 8"); o.dense_waves = value; }
   else if (n == "dense_split") { HFX_CHECK(value == 0 || value == 1 || value == 2 || value == 4, "dense_split must be 0, 1, 2 or 4"); o.dense_split = value; }

@@ -136,6 +136,7 @@ struct hfx_ctx
     int tensor_ops = 1;         // sum-factorised over-integration / shock capturing on tensor-product classes
     int dense_waves = 0;        // waves per workgroup of the dense MFMA contraction: 0 by the operator's rows, else 4 or 8
     int dense_split = 0;        // column groups per 16-row tile dealt to the waves: 0 by the operator's rows, else 1, 2 or 4
+    int light_wave_short = 1;   // 1: a flux-kernel wave without solution points runs the flux-point physics alone (not the paired form)
     int les_flux_kernel = 1;    // 1: the LES closure is evaluated in the flux kernel of split variant 3 where its loader-wave form runs
     int general_waves = 0;      // waves per workgroup of the general flux kernel: 0 by the LDS image (4 or 8), else 3, 4 or 8
   } opt;

@@ -47,6 +47,7 @@ struct Split2Args
   const double *tdisf_in;        // over-integration: the transformed inviscid flux, already evaluated (NULL: computed here)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
   int simd_roles;    // 1: the waves' parts are dealt by SIMD (split_flux_tensor_kernel)
+  int light_short;   // 1: a wave without solution points runs the flux-point physics alone instead of the paired form on dummies
   // split_flux_tensor_kernel, loader-wave form: the LDG correction of a flux point is formed IN the kernel from the partner's
   // flux-point solution (nbr: (partner offset << 2) | (beta sign flipped) << 1 | (this point is the right side); -1: a boundary
   // or partition-face point, whose correction its one-sided kernel has left in `delta`).  NULL: `delta` holds all of them.
@@ -1013,7 +1014,11 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- B: gradient and projected viscous flux at the flux points; fluxes at the solution points
-    if (LW && viscous)
+    // (a wave that owns no solution point -- the third compute wave of a P4 hex: flux points 128..149 -- would run the paired
+    // form with a dummy solution-point chain: twice the FP64 instructions it needs, on a SIMD it shares with the other
+    // workgroup's heavy wave.  It takes the flux-point block of the unpaired form below instead.)
+    const bool wave_u = __builtin_amdgcn_readfirstlane((int)((t & ~63) < NU || !a.light_short)) != 0;
+    if (LW && viscous && wave_u)
     {
       // PAIRED form (loader-wave kernel: registers to spare).  A thread's solution point and its flux point go through
       // metric transform and viscous flux together, statement by statement -- two independent dependency chains, so the
@@ -1165,6 +1170,57 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
             if constexpr (LES) s += tsg[k + NF * l];
             st[(k + NF * l) * NU + tu] = s;
           }
+      }
+    }
+    else if (LW && viscous)
+    {
+      // ---- a wave without solution points: the flux-point physics alone, metrics from the slot into registers first (2b)
+      double JFl[NQ], nl[ND], grf[NG], fq[NG];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) JFl[q] = ldsv(&s_met[O_JGF + tf * NQ + q]);
+#pragma unroll
+      for (int l = 0; l < ND; l++) nl[l] = ldsv(&s_met[O_NRM + l * NFPP + tf]);
+      double inv_df = ldsv(&s_met[O_DJF + tf]);
+      if constexpr (LES) tdA_f = a.tdA_fpts[ef + tf];
+      lds_barrier(); // 2b
+      inv_df = 1.0 / inv_df;
+#pragma unroll
+      for (int q = 0; q < NG; q++) grf[q] = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; m++)
+      {
+        double x[NG];
+#pragma unroll
+        for (int q = 0; q < NG; q++) x[q] = ldsv(&sg[q * NU + am[m]]);
+#pragma unroll
+        for (int q = 0; q < NG; q++) grf[q] += Lrow[m] * x[q];
+      }
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double tg[ND], cg[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) tg[d] = grf[k + NF * d];
+        to_physical<ND>(inv_df, JFl, tg, cg);
+#pragma unroll
+        for (int d = 0; d < ND; d++) grf[k + NF * d] = cg[d];
+      }
+      if (a.grad_fpts && is_f && (a.meta == nullptr || (a.meta[ef + tf] & 4)))
+#pragma unroll
+        for (int q = 0; q < NG; q++) g_gf.st(ef + q * plane_f, lf, grf[q]);
+      calc_visf<ND, true>(a.P, uf, grf, fq);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < ND; l++) s += fq[k + NF * l] * nl[l];
+        if constexpr (LES)
+        {
+          if (is_f) sd[k * NFP + tf] = s; // (parked: the extrapolated SGS flux joins it behind phase C)
+        }
+        else if (is_f)
+          g_fn.st(ef + k * plane_f, lf, s);
       }
     }
     else

@@ -125,7 +125,7 @@ def test_split_paths_every_order_vs_methods(dims, order):
         c.close()
 
 
-@pytest.mark.parametrize("knob,value,exact", [("simd_roles", 0, True), ("gather_delta", 0, False), ("loader_wave", 0, False), ("dictionary_rows", 1, False),
+@pytest.mark.parametrize("knob,value,exact", [("simd_roles", 0, True), ("light_wave_short", 0, False), ("gather_delta", 0, False), ("loader_wave", 0, False), ("dictionary_rows", 1, False),
                                               ("buffer_addressing", 0, False), ("xcd_order", 0, True), ("split_grid_per_cu", 2, True), ("split_grid_per_cu", 16, True)])
 def test_split3_variant_knobs_agree(knob, value, exact):
     """hfx_ctx_set_option selects between forms of the split3 kernels (wave parts dealt by SIMD or by wave number, loader
