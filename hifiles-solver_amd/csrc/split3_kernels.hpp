@@ -1006,6 +1006,16 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         for (int k = 0; k < NF; k++) uf[k] += Lrow[m] * x[k];
       }
     }
+    if constexpr (OI && LW)
+    {
+      // the de-aliased flux requested at the top of this phase waits in this thread's own column of the (still unused) flux
+      // region instead of in 15 registers across the point physics of phase B
+      if (is_u)
+      {
+#pragma unroll
+        for (int q = 0; q < NG; q++) st[q * NU + tu] = td[q];
+      }
+    }
     stamp(3);
     lds_barrier(); // sg complete; su / sd are dead: their region becomes st
     stamp(4);
@@ -1164,7 +1174,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 #pragma unroll
           for (int l = 0; l < ND; l++)
           {
-            double s = OI ? td[k + NF * l] : 0.0;
+            double s = OI ? ldsv(&st[(k + NF * l) * NU + tu]) : 0.0; // (OI: parked there at the end of phase A)
 #pragma unroll
             for (int m = 0; m < ND; m++) s += jg2[0][l + ND * m] * ft[k + NF * m];
             if constexpr (LES) s += tsg[k + NF * l];

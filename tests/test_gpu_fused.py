@@ -180,6 +180,70 @@ def test_fused_full_size_conservation(mode):
     c.close(); m.close()
 
 
+def test_config5_ingredients_full_size_properties():
+    """BASELINE.json configs[4]'s ingredients at bench size (tools/bench_config5.sh, the `config5_overint_shock` leg of bench.py):
+    32^3 P4 hexes with over-integration (7 cubature points per direction) and shock capturing after every stage.  The split
+    fused stage (sum-factorised over-integration kernel, de-aliased flux into the flux kernel, shock filter + flux-point
+    refresh behind the update kernel) equals the per-method path on every element, both conserve the five integrals (the
+    projection and the modal filter leave element means alone), and the sensor filters elements in both alike."""
+    kw = dict(over_int=1, over_int_order=6, shock_cap=1, s0=1e-3, expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0)
+    c = H.Case(32, order=4, **kw)
+    u0 = c.array("disu_upts0").copy()
+    i0 = integrals(c, u0)
+    c.to_device(0)
+    c.run_steps_lib(2, fused=3)
+    c.sync_host()
+    u = c.array("disu_upts0").copy()
+    assert np.isfinite(u).all()
+    vol = (2 * np.pi) ** 3
+    scale = np.array([1.0, 1.0, 1.0, 1.0, u0[:, :, 4].max()]) * vol
+    assert np.all(np.abs(integrals(c, u) - i0) / scale < 1e-11)
+    m = H.Case(32, order=4, **kw)
+    m.set_deferred(False)
+    m.to_device(0)
+    m.run(2)  # the mirrored CalcResidual (evaluate_invFlux_over_int) + AdvanceSolution + shock_capture, call by call
+    m.sync_host()
+    assert relerr(u, m.array("disu_upts0")) < 1e-11
+    sens = [np.zeros(c.n_eles), np.zeros(c.n_eles)]
+    for k, case in enumerate((c, m)):
+        hfx.check(hfx.lib().hfx_eles_download(case.handles()[1], C.c_int(hfx.SENSOR), sens[k].ctypes.data_as(hfx.dp)))
+    assert np.array_equal(sens[0] >= 1e-3, sens[1] >= 1e-3)
+    assert relerr(sens[0], sens[1]) < 1e-7
+    c.close(); m.close()
+
+
+def test_les_full_size_closure_in_the_flux_kernel():
+    """32^3 P4 hexes, LES with the WALE closure (the `les_wale` leg of bench.py): split variant 3 with the closure evaluated in
+    the flux kernel, variant 2 (pointwise closure kernel on the gradient array) and the per-method path agree on every
+    element after two steps, through hfx_run_steps and through the deferred mirrored loop; all conserve."""
+    kw = dict(LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0)
+    res = {}
+    for mode in (3, 2, "calls", "deferred"):
+        c = H.Case(32, order=4, **kw)
+        if mode == "calls":
+            c.set_deferred(False)
+        u0 = c.array("disu_upts0").copy()
+        i0 = integrals(c, u0)
+        c.to_device(0)
+        if mode in ("calls", "deferred"):
+            c.run(2)
+        else:
+            c.run_steps_lib(2, fused=mode)
+        # (the state alone is read: the stage still pending in the deferred loop runs fused for it)
+        u = np.zeros(u0.shape, order="F")
+        hfx.check(hfx.lib().hfx_eles_download(c.handles()[1], C.c_int(hfx.DISU_UPTS0), u.ctypes.data_as(hfx.dp)))
+        if mode == "deferred":
+            nf, nr, why = hfx.deferred_stats(c.handles()[0])
+        res[mode] = u
+        vol = (2 * np.pi) ** 3
+        scale = np.array([1.0, 1.0, 1.0, 1.0, u0[:, :, 4].max()]) * vol
+        assert np.all(np.abs(integrals(c, res[mode]) - i0) / scale < 1e-12), mode
+        c.close()
+    assert (nf, nr) == (10, 0), why
+    for mode in (3, 2, "deferred"):
+        assert relerr(res[mode], res["calls"]) < 1e-11, mode
+
+
 @pytest.mark.parametrize("mode", [2, 3])
 def test_fused_full_size_residual_norms_vs_reference_stdout(mode):
     """the reference's own iteration-1 row for the 32^3 P4 TGV case."""
