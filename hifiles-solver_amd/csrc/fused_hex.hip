@@ -784,13 +784,18 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   }
   if (which == 0 || which == 3)
   {
+    // boundary faces on the side stream, beside the pairwise interior-face kernel: both need the flux kernel's results and
+    // write norm_tconf at disjoint points
+    bool any_bdy_faces = false;
+    for (int b = 0; b < nfb; b++) any_bdy_faces = any_bdy_faces || (faces[b]->is_bdy && faces[b]->n_inters > 0);
+    const bool beside = any_bdy_faces && opt.bdy_beside && e->ctx->mpi_stream == nullptr;
+    if (beside && side_stream_fork(e->ctx)) return 1;
+    for (int b = 0; b < nfb; b++)
+      if (faces[b]->is_bdy && hfx_bdy_launch_internal(faces[b], P.viscous ? 1 : 0, 1)) return 1;
+    if (beside && side_stream_join(e->ctx)) return 1;
     for (int b = 0; b < nfb; b++)
     {
-      if (faces[b]->is_bdy)
-      {
-        if (hfx_bdy_launch_internal(faces[b], P.viscous ? 1 : 0, 1)) return 1;
-        continue;
-      }
+      if (faces[b]->is_bdy) continue;
       const SplitFaceArgs a = face_args(faces[b]);
       if (a.npairs == 0) continue;
       const unsigned nb = (unsigned)((a.npairs + 255) / 256);
@@ -813,6 +818,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       else
         hipLaunchKernelGGL((face_flux_kernel<ND, 3>), dim3(nb), dim3(256), 0, st, a);
     }
+    if (beside && side_stream_wait(e->ctx)) return 1;
   }
   if (which == 0 || which == 4)
   {

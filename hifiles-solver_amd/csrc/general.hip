@@ -13,7 +13,7 @@
 //                        (opp_4, opp_5), its extrapolation to the flux points (opp_6), both point physics blocks, the
 //                        discontinuous divergence (opp_2) and normal flux (opp_1); leaves div_tdisf, norm_tdisf and
 //                        each side's viscous flux projected on its own normal (Fn, 5 instead of 15 doubles per point)
-//   gface_flux_kernel    thread per pair: Riemann + LDG common flux from u and Fn of both sides -> norm_tconf
+//   gface_flux_multi_kernel  thread per pair, all face blocks in one launch: Riemann + LDG common flux from u and Fn of both sides -> norm_tconf
 //   general_update_kernel  batch of 16 elements: opp_3 (norm_tconf - norm_tdisf), RK update, opp_0 of the new state
 //
 // Contractions run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).  A batch is 16 elements because 16 is the tile
@@ -804,11 +804,27 @@ __global__ __launch_bounds__(256) void gface_delta_kernel(const GFaceArgs a)
   }
 }
 
+// Riemann + LDG common flux of the interior pairs from u and Fn of both sides -> norm_tconf of both sides.
+// ALL interior-face blocks of a stage in ONE launch.  A mixed mesh has one block per (left class, right
+// class, face type) -- the channel four --, each a few tens of microseconds of work: launched one after the other every one
+// pays its own ramp-up and tail (4 x 45 us for 208 MB, i.e. 1.2 TB/s).  Workgroups are dealt to the blocks in whole numbers
+// (wg_start), so the block of a workgroup is uniform and its arguments come through scalar loads.
+constexpr int GFACE_MAX_BLOCKS = 8;
+struct GFaceMulti
+{
+  int nb;
+  unsigned wg_start[GFACE_MAX_BLOCKS + 1];
+  GFaceArgs blk[GFACE_MAX_BLOCKS];
+};
+
 template <int RS>
-__global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
+__global__ __launch_bounds__(256) void gface_flux_multi_kernel(const GFaceMulti m)
 {
   constexpr int NF = 5, ND = 3;
-  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  int b = 0;
+  while (b + 1 < m.nb && blockIdx.x >= m.wg_start[b + 1]) b++;
+  const GFaceArgs &a = m.blk[b];
+  const long q = (long)(blockIdx.x - m.wg_start[b]) * 256 + threadIdx.x;
   if (q >= a.npairs) return;
   const long il = a.L[q], ir = a.R[q];
   double ul[NF], ur[NF], n[ND], fn[NF];
@@ -819,11 +835,12 @@ __global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
     ur[k] = a.disu_r[ir + k * a.plane_r];
   }
 #pragma unroll
-  for (int m = 0; m < ND; m++) n[m] = a.norm_l[il + m * a.plane_l];
+  for (int mm = 0; mm < ND; mm++) n[mm] = a.norm_l[il + mm * a.plane_l];
   const double tl = a.tdA_l[il], tr = a.tdA_r[ir];
   double fl[NF], fr[NF];
-  const unsigned char mt = a.meta_l[il]; // with the other loads, not behind the Riemann solver
-  if (a.P.viscous)
+  const unsigned char mt = a.meta_l[il];
+  const bool viscous = a.P.viscous;
+  if (viscous)
   {
 #pragma unroll
     for (int k = 0; k < NF; k++)
@@ -833,27 +850,18 @@ __global__ __launch_bounds__(256) void gface_flux_kernel(const GFaceArgs a)
     }
   }
   riemann_flux_t<ND, RS, true>(a.P, ul, ur, n, fn);
-  if (a.P.viscous)
-  {
-    const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
+  const double beta = (mt & 2) ? -a.P.ldg_beta : a.P.ldg_beta;
 #pragma unroll
-    for (int k = 0; k < NF; k++)
+  for (int k = 0; k < NF; k++)
+  {
+    double fv = 0.0;
+    if (viscous)
     {
-      // (1/2+b) F_L.n + (1/2-b) F_R.n - tau (u_R - u_L), n the left normal = -(right normal)
-      double fv = (0.5 + beta) * fl[k] - (0.5 - beta) * fr[k];
+      fv = (0.5 + beta) * fl[k] - (0.5 - beta) * fr[k];
       fv -= a.P.ldg_tau * (ur[k] - ul[k]);
-      a.tconf_l[il + k * a.plane_l] = fn[k] * tl + fv * tl;
-      a.tconf_r[ir + k * a.plane_r] = -fn[k] * tr + -fv * tr;
     }
-  }
-  else
-  {
-#pragma unroll
-    for (int k = 0; k < NF; k++)
-    {
-      a.tconf_l[il + k * a.plane_l] = fn[k] * tl;
-      a.tconf_r[ir + k * a.plane_r] = -fn[k] * tr;
-    }
+    a.tconf_l[il + k * a.plane_l] = viscous ? fn[k] * tl + fv * tl : fn[k] * tl;
+    a.tconf_r[ir + k * a.plane_r] = viscous ? -fn[k] * tr + -fv * tr : -fn[k] * tr;
   }
 }
 
@@ -1174,23 +1182,42 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
         return 1;
     }
   if (which == 0 || which == 3)
+  {
+    // boundary faces beside the interior ones: both need the flux kernels' results and write norm_tconf at disjoint points
+    bool any_bdy = false;
+    for (int b = 0; b < nfb; b++) any_bdy = any_bdy || (faces[b]->is_bdy && faces[b]->n_inters > 0);
+    const bool beside = any_bdy && ctx->opt.bdy_beside;
+    if (beside && side_stream_fork(ctx)) return 1;
+    for (int b = 0; b < nfb; b++)
+      if (faces[b]->is_bdy && hfx_bdy_launch_internal(faces[b], P.viscous ? 1 : 0, 1)) return 1;
+    if (beside && side_stream_join(ctx)) return 1;
+    // all interior-face blocks in one launch (groups of GFACE_MAX_BLOCKS)
+    GFaceMulti m{};
+    auto flush = [&]() -> int {
+      if (m.nb == 0) return 0;
+      const dim3 grid(m.wg_start[m.nb]);
+      if (P.riemann == 0)
+        hipLaunchKernelGGL(gface_flux_multi_kernel<0>, grid, dim3(256), 0, st, m);
+      else if (P.riemann == 2)
+        hipLaunchKernelGGL(gface_flux_multi_kernel<2>, grid, dim3(256), 0, st, m);
+      else
+        hipLaunchKernelGGL(gface_flux_multi_kernel<3>, grid, dim3(256), 0, st, m);
+      m.nb = 0;
+      return 0;
+    };
     for (int b = 0; b < nfb; b++)
     {
-      if (faces[b]->is_bdy)
-      {
-        if (hfx_bdy_launch_internal(faces[b], P.viscous ? 1 : 0, 1)) return 1;
-        continue;
-      }
+      if (faces[b]->is_bdy) continue;
       const GFaceArgs a = gface_args(faces[b]);
       if (a.npairs == 0) continue;
-      const dim3 grid((unsigned)((a.npairs + 255) / 256));
-      if (P.riemann == 0)
-        hipLaunchKernelGGL(gface_flux_kernel<0>, grid, dim3(256), 0, st, a);
-      else if (P.riemann == 2)
-        hipLaunchKernelGGL(gface_flux_kernel<2>, grid, dim3(256), 0, st, a);
-      else
-        hipLaunchKernelGGL(gface_flux_kernel<3>, grid, dim3(256), 0, st, a);
+      if (m.nb == 0) m.wg_start[0] = 0;
+      m.blk[m.nb] = a;
+      m.wg_start[m.nb + 1] = m.wg_start[m.nb] + (unsigned)((a.npairs + 255) / 256);
+      if (++m.nb == GFACE_MAX_BLOCKS && flush()) return 1;
     }
+    if (flush()) return 1;
+    if (beside && side_stream_wait(ctx)) return 1;
+  }
   if (which == 0 || which == 4)
   {
     for (int i = 0; i < neb; i++)

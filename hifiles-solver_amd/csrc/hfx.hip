@@ -305,6 +305,32 @@ static int contract_multi_out(hfx_ctx *ctx, const Operator *const *ops, int no, 
 
 static inline unsigned nblocks(long n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// ---- the side stream of the boundary-face kernels (hfx_ctx::side_stream) ----
+int side_stream_fork(hfx_ctx *ctx)
+{
+  if (!ctx->side_stream)
+  {
+    HFX_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HFX_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+    HFX_HIP(hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
+  }
+  HFX_HIP(hipEventRecord(ctx->side_fork, ctx->stream));
+  HFX_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+  ctx->bdy_stream = ctx->side_stream;
+  return 0;
+}
+int side_stream_join(hfx_ctx *ctx)
+{
+  ctx->bdy_stream = nullptr;
+  HFX_HIP(hipEventRecord(ctx->side_done, ctx->side_stream));
+  return 0;
+}
+int side_stream_wait(hfx_ctx *ctx)
+{
+  HFX_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
+  return 0;
+}
+
 } // namespace hfx
 
 using namespace hfx;
@@ -337,6 +363,9 @@ int hfx_ctx_create(int device, hfx_ctx **out)
 int hfx_ctx_destroy(hfx_ctx *ctx)
 {
   if (!ctx) return 0;
+  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+  if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
@@ -406,6 +435,7 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   else if (n == "flux_stamps") o.flux_stamps = value;
   else if (n == "simd_roles") o.simd_roles = value != 0;
   else if (n == "les_flux_kernel") o.les_flux_kernel = value != 0;
+  else if (n == "bdy_beside") o.bdy_beside = value != 0;
   else if (n == "light_wave_short") o.light_wave_short = value != 0;
   else if (n == "tensor_ops") o.tensor_ops = value != 0;
   else if (n == "dense_waves") { HFX_CHECK(value == 0 || value == 4 || value == 8, "dense_waves must be 0, 4 or 8"); o.dense_waves = value; }
@@ -1377,7 +1407,7 @@ int hfx_bdy_launch_internal(hfx_inters *f, int visc, int fast)
   if (f->n_inters == 0) return 0;
   const BdyArgs a = bdy_args(f);
   const dim3 g((unsigned)((a.npts + 255) / 256)), b(256);
-  hipStream_t st = f->ctx->stream;
+  hipStream_t st = f->ctx->bdy_stream ? f->ctx->bdy_stream : f->ctx->stream;
   const int nd = f->left->n_dims;
 #define HFX_BDY(K)                                                             \
   if (nd == 2 && fast) hipLaunchKernelGGL((K<2, true>), g, b, 0, st, a);       \
@@ -1777,7 +1807,7 @@ int hfx_time_general_kernels(hfx_eles *const *eles, int neb, hfx_inters *const *
   HFX_CHECK(eles && neb > 0 && ms && names && reps > 0, "hfx_time_general_kernels: bad argument");
   HFX_IMMEDIATE(eles[0]->ctx, 0);
   HFX_CHECK(eles[0]->ctx->have_params, "parameters not set");
-  snprintf(names, 256, "gface_delta_kernel,general_flux_kernel,gface_flux_kernel,general_update_kernel");
+  snprintf(names, 256, "gface_delta_kernel,general_flux_kernel,gface_flux_multi_kernel,general_update_kernel");
   return general_time_kernels(eles, neb, faces, nfb, reps, ms);
 }
 

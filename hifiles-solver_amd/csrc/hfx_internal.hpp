@@ -112,6 +112,11 @@ struct hfx_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  // a second stream for the boundary-face kernels of the fused stages, which then run BESIDE the pairwise interior-face kernel
+  // (side_stream_fork: the side stream waits for what the main stream holds so far and boundary launches go there;
+  // side_stream_join: launches go to the main stream again; side_stream_wait: the main stream waits for the side stream)
+  hipStream_t side_stream = nullptr, bdy_stream = nullptr;
+  hipEvent_t side_fork = nullptr, side_done = nullptr;
   hipStream_t mpi_stream = nullptr; // when set: the one-sided partition-face kernels of the split path are launched here (hfx_run_steps_partitioned)
   hfx_params params{};
   bool have_params = false;
@@ -137,6 +142,7 @@ struct hfx_ctx
     int dense_waves = 0;        // waves per workgroup of the dense MFMA contraction: 0 by the operator's rows, else 4 or 8
     int dense_split = 0;        // column groups per 16-row tile dealt to the waves: 0 by the operator's rows, else 1, 2 or 4
     int light_wave_short = 1;   // 1: a flux-kernel wave without solution points runs the flux-point physics alone (not the paired form)
+    int bdy_beside = 0;         // 1: the fused stages' viscous boundary-face kernels run on a side stream beside the interior-face kernel (measured neutral: off)
     int les_flux_kernel = 1;    // 1: the LES closure is evaluated in the flux kernel of split variant 3 where its loader-wave form runs
     int general_waves = 0;      // waves per workgroup of the general flux kernel: 0 by the LDS image (4 or 8), else 3, 4 or 8
   } opt;
@@ -273,6 +279,9 @@ struct DeferBusy
   ~DeferBusy() { c->defer.busy = prev; }
 };
 inline void invalidate_fpts(hfx_eles *e) { e->fpts_valid = e->fpts_sent = false; }
+int side_stream_fork(hfx_ctx *ctx);
+int side_stream_join(hfx_ctx *ctx);
+int side_stream_wait(hfx_ctx *ctx);
 } // namespace hfx
 // a per-method entry point: recorded while the context defers (and is not replaying)
 #define HFX_DEFER(ctx_, method_, e_, f_, c_, i0_, i1_)  \
