@@ -15,7 +15,10 @@
 #include <algorithm>
 #include <cstring>
 
+#include <vector>
+
 #include "fused_hex.hpp"
+#include "general.hpp"
 #include "hfx_internal.hpp"
 
 namespace hfx
@@ -346,6 +349,65 @@ int partitioned_stage_deferred(hfx_eles *e, hfx_inters *const *int_faces, int n_
   return partitioned_stage(e, int_faces, n_int, mpi_faces, n_mpi, comm, rk, start, nullptr);
 }
 
+// ONE RK stage of the GENERAL fused stage (general.hip: tetrahedra, prisms, several element blocks) on partitioned blocks: the
+// stage's four parts with the one-sided partition-face kernels and the two exchanges between them, in CalcResidual's order
+// (src/solver.cpp:68-72,131-139,148-155,197-210; mpi_inters::set_mpi takes any element class, src/mpi_inters.cpp:154):
+//   [start: pack the flux-point solution, exchange]            interior LDG pairs / boundary ghost states
+//   wait; LDG corrections at the partition faces               flux kernels of all blocks
+//   pack each side's projected viscous flux Fn, exchange       interior common fluxes, boundary viscous fluxes
+//   wait; common fluxes at the partition faces                 update kernels (new flux-point solution)
+//   pack the new flux-point solution, exchange (for the next stage)
+int general_partitioned_stage(hfx_eles *const *eles, int neb, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
+                              int n_mpi, hfx_comm *comm, int rk, bool start)
+{
+  HFX_CHECK(neb > 0 && comm, "general partitioned stage: bad argument");
+  hfx_ctx *ctx = eles[0]->ctx;
+  HFX_CHECK(comm->ctx == ctx, "the communicator belongs to another context");
+  const bool visc = ctx->params.viscous != 0;
+  const int nst = n_rk_stages(ctx->params);
+  // the blocks' tables are built with ALL face blocks (every flux point needs its face)
+  std::vector<hfx_inters *> all(int_faces, int_faces + n_int);
+  for (int b = 0; b < n_mpi; b++)
+  {
+    const hfx_inters *f = mpi_faces[b];
+    HFX_CHECK(f->is_mpi, "bad partition-face block");
+    bool mine = false;
+    for (int i = 0; i < neb; i++) mine = mine || f->left == eles[i];
+    HFX_CHECK(mine, "a partition-face block belongs to an element block that is not part of this call");
+    int listed = 0;
+    for (int c : f->seg_count) listed += c;
+    HFX_CHECK(listed == f->n_inters, "partition-face block: %d of %d faces have a neighbour (hfx_mpi_inters_set_neighbours)", listed, f->n_inters);
+    all.push_back(mpi_faces[b]);
+  }
+  if (general_deferred_prepare(eles, neb, all.data(), (int)all.size())) return 1;
+  auto mpi_all = [&](int what) -> int {
+    for (int b = 0; b < n_mpi; b++)
+      if (mpi_launch_general(mpi_faces[b]->left, mpi_faces[b], what, general_fn_fpts(mpi_faces[b]->left))) return 1;
+    return 0;
+  };
+  auto part = [&](int which) { return general_stage_part(eles, neb, all.data(), (int)all.size(), rk, rk == nst - 1, which); };
+  if (start)
+  {
+    if (mpi_all(0)) return 1;
+    if (start_exchange(comm, mpi_faces, n_mpi, 0, false)) return 1;
+  }
+  if (part(1)) return 1;
+  if (wait_exchange(comm, 0)) return 1;
+  if (visc && mpi_all(1)) return 1;
+  if (part(2)) return 1;
+  if (visc)
+  {
+    if (mpi_all(5)) return 1;
+    if (start_exchange(comm, mpi_faces, n_mpi, 1, true)) return 1;
+  }
+  if (part(3)) return 1;
+  if (visc && wait_exchange(comm, 1)) return 1;
+  if (mpi_all(6)) return 1;
+  if (part(4)) return 1;
+  if (mpi_all(0)) return 1;
+  return start_exchange(comm, mpi_faces, n_mpi, 0, false);
+}
+
 // the loop of hfx_run_steps_partitioned / hfx_time_partitioned.  n_stages_total < 0: n_steps whole time steps
 static int run_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                            hfx_comm *comm, int n_steps, int n_stages_total, StageTimers *T)
@@ -567,6 +629,32 @@ int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_i
   HFX_CHECK(e->ctx->have_params, "parameters not set");
   HFX_IMMEDIATE(e->ctx, 0);
   return run_partitioned(e, int_faces, n_int, mpi_faces, n_mpi, comm, n_steps, -1, nullptr);
+}
+
+int hfx_run_steps_partitioned_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *int_faces, int n_int,
+                                     hfx_inters *const *mpi_faces, int n_mpi, hfx_comm *comm, int n_steps)
+{
+  HFX_CHECK(eles && n_ele_blocks > 0 && eles[0] && comm, "hfx_run_steps_partitioned_blocks: NULL argument");
+  hfx_ctx *ctx = eles[0]->ctx;
+  HFX_CHECK(ctx->have_params, "parameters not set");
+  HFX_IMMEDIATE(ctx, 0);
+  HFX_CHECK(ctx->params.dt_type == 0, "hfx_run_steps_partitioned_blocks: CFL time steps (dt_type 1 / 2) over several element blocks are the caller's "
+                                      "(hfx_eles_calc_dt_local per block + hfx_comm_allreduce, then one step at a time)");
+  const int nst = n_rk_stages(ctx->params);
+  for (int i = 0; i < n_ele_blocks; i++)
+    if (hfx_eles_extrapolate_solution(eles[i])) return 1;
+  bool start = true;
+  for (int s = 0; s < n_steps; s++)
+  {
+    for (int rk = 0; rk < nst; rk++)
+    {
+      if (general_partitioned_stage(eles, n_ele_blocks, int_faces, n_int, mpi_faces, n_mpi, comm, rk, start)) return 1;
+      start = false;
+    }
+    advance_ramp_counters(int_faces, n_int);
+  }
+  // (nothing in flight when the caller reads or changes the state)
+  return n_steps > 0 ? wait_exchange(comm, 0) : 0;
 }
 
 int hfx_time_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,

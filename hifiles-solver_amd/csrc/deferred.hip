@@ -201,7 +201,6 @@ static void make_plan(hfx_ctx *ctx, const std::vector<DeferCall> &log, DeferPlan
   const bool tensor = P.eles.size() == 1 && (e0->ele_type == 4 || e0->ele_type == 1);
   if (mpi)
   {
-    if (!tensor) { P.why = "partition faces: the fused stage takes one tensor-product element block"; return; }
     if (!P.comm) { P.why = "partition faces without the library's communicator"; return; }
     if (P.comm->ctx != ctx) { P.why = "the communicator belongs to another context"; return; }
     if (e0->les_ready && e0->les.sgs_model == 3) { P.why = "the SVV closure filters the state after its flux-point values have left for the neighbours"; return; }
@@ -218,12 +217,16 @@ static void make_plan(hfx_ctx *ctx, const std::vector<DeferCall> &log, DeferPlan
     return;
   }
   if (P.sgs_terms || P.shock) { P.why = "general fused stage: LES and shock capturing run per method"; return; }
-  if (general_deferred_prepare(P.eles.data(), (int)P.eles.size(), P.faces.data(), (int)P.faces.size()))
   {
-    P.why = hfx_last_error();
-    return;
+    std::vector<hfx_inters *> all = P.faces;
+    all.insert(all.end(), P.mpi_faces.begin(), P.mpi_faces.end());
+    if (general_deferred_prepare(P.eles.data(), (int)P.eles.size(), all.data(), (int)all.size()))
+    {
+      P.why = hfx_last_error();
+      return;
+    }
   }
-  P.kind = 3;
+  P.kind = mpi ? 4 : 3;
 }
 
 // arrays a fused stage of this kind leaves with the reference's values (given write_div)
@@ -298,6 +301,10 @@ static int run_fused(hfx_ctx *ctx, const DeferPlan &P, int in_step, bool write_d
   case 3:
     if (general_deferred_stage(P.eles.data(), (int)P.eles.size(), faces, nfb, in_step, write_div)) return 1;
     break;
+  case 4:
+    if (general_partitioned_stage(P.eles.data(), (int)P.eles.size(), faces, nfb, P.mpi_faces.data(), (int)P.mpi_faces.size(), P.comm, in_step, start))
+      return 1;
+    break;
   default:
     HFX_CHECK(false, "deferred execution: plan of unknown kind %d", P.kind);
   }
@@ -305,7 +312,7 @@ static int run_fused(hfx_ctx *ctx, const DeferPlan &P, int in_step, bool write_d
   for (hfx_eles *e : P.eles)
   {
     e->fpts_valid = true;
-    e->fpts_sent = P.kind == 2;
+    e->fpts_sent = P.kind == 2 || P.kind == 4;
     e->stale |= ~fresh & ((1u << HFX_N_ARRAYS) - 1u);
     e->stale &= ~fresh;
   }
@@ -369,7 +376,7 @@ int defer_flush(hfx_ctx *ctx, unsigned need)
       if (c.method == DM_ADVANCE_SOLUTION) in_step = c.i0;
     // div_tconf_upts is stored at the last stage of a step (where the monitors read it) or when this flush is for it
     // (the partitioned stage stores it at the last stage only)
-    const bool write_div = in_step == n_rk_stages(ctx->params) - 1 || (plan->kind != 2 && (need & (1u << HFX_DIV_TCONF_UPTS)) != 0);
+    const bool write_div = in_step == n_rk_stages(ctx->params) - 1 || (plan->kind != 2 && plan->kind != 4 && (need & (1u << HFX_DIV_TCONF_UPTS)) != 0);
     if ((need & ~fresh_after(*plan, write_div)) == 0)
     {
       d.n_fused++;

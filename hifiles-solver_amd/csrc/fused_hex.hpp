@@ -23,6 +23,9 @@ bool les_in_flux_kernel(const hfx_eles *e);
 // one phase of a split-path stage on a partitioned block (see hfx_stage_partitioned)
 int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                             int phase, int in_step, int first);
+// one of the one-sided partition-face kernels (kernels_mpi.hpp: 0 pack the solution, 1 LDG corrections, 5 pack Fn, 6 common flux
+// from u and Fn) on a block of the GENERAL fused stage, whose projected viscous flux is `fn`
+int mpi_launch_general(hfx_eles *e, hfx_inters *f, int what, const double *fn);
 // ---- the deferred scheduler's pieces (deferred.hip) ----
 // builds the block's fused tables for these face blocks unless they exist; non-zero (message in hfx_last_error) when the
 // block does not qualify for the split fused stage.  partitioned: flux points without a registered face are partition-face points
@@ -34,4 +37,7 @@ int split_deferred_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_
 // been sent yet
 int partitioned_stage_deferred(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                                hfx_comm *comm, int rk, bool start);
+// the general fused stage on partitioned element blocks (comm.hip)
+int general_partitioned_stage(hfx_eles *const *eles, int neb, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
+                              int n_mpi, hfx_comm *comm, int rk, bool start);
 } // namespace hfx

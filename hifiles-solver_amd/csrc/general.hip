@@ -954,7 +954,14 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_ele
   for (int b = 0; b < nfb; b++)
   {
     hfx_inters *f = faces[b];
-    HFX_CHECK(!f->is_mpi, "general fused stage: partition faces are not part of it (run per method)");
+    if (f->is_mpi)
+    {
+      // partition faces (hfx_run_steps_partitioned_blocks): the point's correction and common flux come from the one-sided
+      // kernels of kernels_mpi.hpp, like a boundary point's; what leaves for the neighbour is the point's Fn
+      if (f->left == e)
+        for (int o : f->hL) owned[o] = 1;
+      continue;
+    }
     if (f->is_bdy)
     {
       if (f->left != e) continue;
@@ -986,7 +993,7 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_ele
     for (int b = 0; b < nfb && fits; b++)
     {
       hfx_inters *f = faces[b];
-      if (f->is_bdy || (f->left != e && f->right != e)) continue;
+      if (f->is_bdy || f->is_mpi || (f->left != e && f->right != e)) continue;
       const int bl = block_of(f->left), br = block_of(f->right);
       if (bl < 0 || br < 0) { fits = false; break; }
       const long np = (long)f->n_inters * f->n_fpts_per_inter;
@@ -1159,6 +1166,7 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
         if (hfx_bdy_launch_internal(faces[b], 0, 1)) return 1; // ghost state -> inviscid common flux, LDG common solution
         continue;
       }
+      if (faces[b]->is_mpi) continue;
       {
         // both sides' flux kernels form these corrections themselves?
         auto own = [&](hfx_eles *x) {
@@ -1207,7 +1215,7 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
     };
     for (int b = 0; b < nfb; b++)
     {
-      if (faces[b]->is_bdy) continue;
+      if (faces[b]->is_bdy || faces[b]->is_mpi) continue;
       const GFaceArgs a = gface_args(faces[b]);
       if (a.npairs == 0) continue;
       if (m.nb == 0) m.wg_start[0] = 0;
@@ -1263,6 +1271,14 @@ static int general_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *fa
   }
   return 0;
 }
+
+// the pieces of a stage for the partitioned driver (comm.hip): which = 1 .. 4 as in general_time_kernels; `faces` may hold
+// partition-face blocks (they take part in the build -- every flux point needs its face -- and are skipped by the pairwise loops)
+int general_stage_part(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool write_div, int which)
+{
+  return general_stage(eles, neb, faces, nfb, in_step, write_div, which);
+}
+const double *general_fn_fpts(const hfx_eles *e) { return e->general ? ((const GeneralData *)e->general)->fn_fpts : nullptr; }
 
 int general_deferred_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb)
 {

@@ -18,5 +18,8 @@ void general_kernel_bytes(hfx_eles *const *eles, int neb, double *bytes);
 // ---- the deferred scheduler's pieces (deferred.hip): tables for these blocks (non-zero when a block does not qualify), and
 // ONE stage on blocks whose disu_fpts belong to the current state
 int general_deferred_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb);
+// pieces for the partitioned driver (comm.hip): one of the four parts of a stage; the projected viscous flux array of a block
+int general_stage_part(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool write_div, int which);
+const double *general_fn_fpts(const hfx_eles *e);
 int general_deferred_stage(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool write_div);
 } // namespace hfx

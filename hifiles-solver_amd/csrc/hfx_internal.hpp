@@ -90,7 +90,7 @@ struct DeferCall
 struct DeferPlan
 {
   std::vector<DeferCall> signature; // the record this plan was made for (methods and objects; stage number excluded)
-  int kind = 0;                     // 0 replay, 1 split fused stage, 2 partitioned split stage, 3 general fused stage
+  int kind = 0;                     // 0 replay, 1 split fused stage, 2 partitioned split stage, 3 general fused stage, 4 partitioned general stage
   std::string why;                  // kind 0: why the record is not run as a fused stage
   std::vector<hfx_eles *> eles;
   std::vector<hfx_inters *> faces, mpi_faces; // interior + boundary blocks | partition-face blocks

@@ -8,7 +8,7 @@
 // one-sided kernels of kernels_mpi.hpp; the caller exchanges the buffers between the phases
 // ---------------------------------------------------------------------------------------
 template <int ND>
-static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
+static int mpi_launch(hfx_eles *e, hfx_inters *f, int what, const double *fn_override = nullptr)
 {
   if (f->n_inters == 0) return 0;
   MpiArgs a{};
@@ -21,7 +21,7 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
   a.tconf = e->arr[HFX_NORM_TCONF_FPTS];
   a.delta = (what == 3) ? nullptr : e->arr[HFX_DELTA_DISU_FPTS];
   a.out_disu = f->out_disu; a.out_grad = f->out_grad; a.in_disu = f->in_disu; a.in_grad = f->in_grad;
-  a.fn = e->fused ? e->fused->fn_fpts : nullptr;
+  a.fn = fn_override ? fn_override : (e->fused ? e->fused->fn_fpts : nullptr);
   a.P = e->ctx->phys();
   if (e->les_ready && split_variant(e) == 2)
   {
@@ -49,6 +49,9 @@ static int mpi_launch(hfx_eles *e, hfx_inters *f, int what)
 }
 
 // (with an LES closure: 3 where the flux kernel evaluates the closure itself -- needs the block's fused tables, fused_build)
+// the one-sided partition-face kernels for a block of the general fused stage (three-dimensional; fn: that block's projected flux)
+int mpi_launch_general(hfx_eles *e, hfx_inters *f, int what, const double *fn) { return mpi_launch<3>(e, f, what, fn); }
+
 int split_variant(const hfx_eles *e) { return (e->ctx->fused_mode == 2 || (e->les_ready && !les_in_flux_kernel(e))) ? 2 : 3; }
 
 int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,

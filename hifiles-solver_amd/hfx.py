@@ -373,6 +373,17 @@ class MpiInters:
         """(device pointer, doubles) of 0 out_buffer_disu, 1 in_buffer_disu, 2 out_buffer_grad_disu, 3 in_buffer_grad_disu."""
         return mpi_buffer(self.h, which)
 
+    def set_neighbours(self, segments):
+        """segments: [(peer, send_first, recv_first, count)] (hfx_mpi_inters_set_neighbours)"""
+        a = [np.ascontiguousarray([s[i] for s in segments], dtype=np.int32) for i in range(4)]
+        check(lib().hfx_mpi_inters_set_neighbours(self.h, C.c_int(len(segments)), *[x.ctypes.data_as(ip) for x in a]))
+
+    # mpi_inters::send_* / receive_* over libhfx's RCCL transport (comm: hfx.Comm)
+    def send_solution(self, comm): check(lib().hfx_mpi_inters_send_solution(self.h, comm.h))
+    def receive_solution(self, comm): check(lib().hfx_mpi_inters_receive_solution(self.h, comm.h))
+    def send_corrected_gradient(self, comm): check(lib().hfx_mpi_inters_send_corrected_gradient(self.h, comm.h))
+    def receive_corrected_gradient(self, comm): check(lib().hfx_mpi_inters_receive_corrected_gradient(self.h, comm.h))
+
     def close(self):
         if self.h:
             lib().hfx_inters_destroy(self.h)
@@ -390,6 +401,15 @@ def run_steps_blocks(eles, faces, n_steps, fused=0):
     ea = (C.c_void_p * len(eles))(*[e.h for e in eles])
     fa = (C.c_void_p * max(1, len(faces)))(*[f.h for f in faces])
     check(lib().hfx_run_steps_blocks(ea, C.c_int(len(eles)), fa, C.c_int(len(faces)), C.c_int(n_steps), C.c_int(int(fused))))
+
+
+def run_steps_partitioned_blocks(eles, int_faces, mpi_faces, comm, n_steps):
+    """hfx_run_steps_partitioned_blocks: the general fused stage on partitioned element blocks"""
+    ea = (C.c_void_p * len(eles))(*[e.h for e in eles])
+    fa = (C.c_void_p * max(1, len(int_faces)))(*[f.h for f in int_faces])
+    ma = (C.c_void_p * max(1, len(mpi_faces)))(*[f.h for f in mpi_faces])
+    check(lib().hfx_run_steps_partitioned_blocks(ea, C.c_int(len(eles)), fa, C.c_int(len(int_faces)), ma, C.c_int(len(mpi_faces)), comm.h,
+                                                 C.c_int(n_steps)))
 
 
 def comm_unique_id():

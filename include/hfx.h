@@ -140,9 +140,10 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value);
  * the device state (upload, download, monitors, calc_dt_local, new parameters, synchronize, hfx_ctx_flush ...):
  *   - a record that is one whole stage in CalcResidual's order (every method over every block it belongs to, phases in
  *     the reference's order, one stage number) runs as ONE fused stage: the split stage for a tensor-product block
- *     (= hfx_run_steps(..., 3), or 2 with an LES closure / fused mode 2), the partitioned split stage when the block has
- *     partition faces whose send_* / receive_* calls name one hfx_comm (= hfx_run_steps_partitioned), the general stage
- *     for tetrahedra / prisms / mixed meshes (= hfx_run_steps_blocks(..., 4));
+ *     (= hfx_run_steps(..., 3), or 2 in fused mode 2 / with an LES closure the flux kernel cannot carry), the partitioned split
+ *     stage when the block has partition faces whose send_* / receive_* calls name one hfx_comm (= hfx_run_steps_partitioned),
+ *     the general stage for tetrahedra / prisms / mixed meshes (= hfx_run_steps_blocks(..., 4)), with partition faces
+ *     = hfx_run_steps_partitioned_blocks;
  *   - anything else -- a partial stage, another order, a block the fused stages refuse, the packing halves
  *     hfx_mpi_inters_pack_* of a caller-side transport -- is replayed call by call: the per-method path, unchanged.
  * Results are those of hfx_run_steps* (1e-11 of the per-method path).  The fused stages leave disu_upts(0),
@@ -425,6 +426,15 @@ int hfx_mpi_inters_receive_sgsf_fpts(hfx_inters *f, hfx_comm *c);
  * (src/HiFiLES.cpp:224-225). */
 int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces, int n_mpi,
                               hfx_comm *comm, int n_steps);
+/* The same for a mesh of SEVERAL element blocks and / or non-tensor classes (tetrahedra, prisms, mixed meshes): the general fused
+ * stage (hfx_run_steps_blocks(..., 4)) on partitioned blocks.  A partition-face block belongs to one element block
+ * (mpi_inters::set_mpi takes any in_ele_type_l, src/mpi_inters.cpp:154); int_faces holds the interior blocks (whose two sides may
+ * lie in different element blocks) and the boundary blocks.  Each stage: LDG corrections and common fluxes of the partition faces
+ * by the one-sided kernels, the flux-point solution and each side's projected viscous flux Fn as the two messages.  Fixed time
+ * step (dt_type 0) only; three-dimensional blocks without LES / over-integration / shock capturing, as hfx_run_steps_blocks(..., 4).
+ * With deferred execution the mirrored CalcResidual of such a mesh runs this stage when its send_* / receive_* name one hfx_comm. */
+int hfx_run_steps_partitioned_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *int_faces, int n_int,
+                                     hfx_inters *const *mpi_faces, int n_mpi, hfx_comm *comm, int n_steps);
 /* Average durations (ms, HIP events) over `reps` stages of the same loop: ms[0..3] phases 1-4 on the compute stream,
  * ms[4] solution exchange and ms[5] flux / gradient exchange on the communication stream (from the moment their
  * data is packed to the last byte received), ms[6] the whole stage, ms[7] the element kernel of phase 2 alone (the split flux

@@ -288,3 +288,103 @@ def test_general_fused_stage_at_bench_size_properties():
     for c in classes:
         Ea[c].close(); Eb[c].close()
     ctx.close()
+
+
+# ---- the mixed channel on PARTITIONED element blocks ----------------------------------------------------------------------
+def self_partition(ctx, E, faces):
+    """Every second face of every interior block that joins a class to ITSELF becomes a pair of one-sided partition faces whose
+    neighbour is the rank itself: -> (remaining interior blocks as (a, b, L, R), [hfx.MpiInters]).  The partition-face block
+    of a (class, face type) lists the left sides A_0..A_n-1, then the right sides B_0..B_n-1 (in the order of their own
+    offsets); Rlut is the slot of the partner's point in the mate's record; the two halves are each other's neighbour segment."""
+    import hfx
+    rest, mpi = [], []
+    for a, b, L, R in faces:
+        if a != b or L.shape[1] < 4:
+            rest.append((a, b, L, R))
+            continue
+        pick = np.zeros(L.shape[1], dtype=bool)
+        pick[::2] = True
+        rest.append((a, b, np.asfortranarray(L[:, ~pick]), np.asfortranarray(R[:, ~pick])))
+        La, Ra = L[:, pick], R[:, pick]
+        n = La.shape[1]
+        order = np.argsort(Ra, axis=0)            # order[j', i]: the A-point j whose partner is B's j'-th point
+        rank = np.argsort(order, axis=0)          # rank[j, i]: the slot of A-point j's partner in B's record
+        Lb = np.take_along_axis(Ra, order, axis=0)
+        Lm = np.asfortranarray(np.concatenate([La, Lb], axis=1).astype(np.int32))
+        Rlut = np.asfortranarray(np.concatenate([rank, order], axis=1).astype(np.int32))
+        f = hfx.MpiInters(ctx, E[a], Lm, Rlut)
+        f.set_neighbours([(0, 0, n, n), (0, n, 0, n)])
+        mpi.append(f)
+    return rest, mpi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["run_steps", "deferred"])
+def test_mixed_channel_on_partitioned_blocks(how):
+    """hfx_run_steps_partitioned_blocks (and the same stage through the deferred call sequence, send_* / receive_* included):
+    the mixed channel with half of its tetrahedron | tetrahedron and prism | prism faces turned into partition faces that the
+    rank exchanges with itself over libhfx's RCCL transport -- two element blocks, one partition-face block per (class, face
+    type) -- equals the genuine reference's undivided run after every step"""
+    import hfx
+    d = dict(np.load(os.path.join(GOLDEN, "mixed_p3_channel.npz")))
+    ctx = hfx.Context(0)
+    classes, per, faces, bdy = MU.split(d)
+    ctx.set_params(hfx.params_from(per[classes[0]]))
+    E = {}
+    for c in classes:
+        sz = [int(v) for v in per[c]["sizes"]]
+        E[c] = hfx.Eles(ctx, sz[:5], per[c], ele_type=sz[6], order=sz[5])
+        E[c].upload(hfx.DISU_UPTS0, per[c]["u_init"])
+    rest, M = self_partition(ctx, E, faces)
+    assert len(M) >= 2
+    F = [hfx.IntInters(ctx, E[a], E[b], L, R) for a, b, L, R in rest]
+    for a, L, ids in bdy:
+        F.append(hfx.BdyInters(ctx, E[a], L, ids, hfx.bc_records(d["bc_flags"], d["bc_params"]), float(np.ravel(d["bc_R_ref"])[0]),
+                               int(np.ravel(d["ramp_counter"])[0])))
+    comm = hfx.Comm(ctx.h, hfx.comm_unique_id(), 1, 0)
+    blocks = [E[c] for c in classes]
+    nstage = int(d["c2_sizes"][7])
+    adv = int(np.ravel(d["adv_type"])[0])
+    steps = sorted({int(k.split("_")[2][4:]) for k in d if k.startswith("c2_u_step")})
+    if how == "deferred":
+        ctx.set_option("deferred", 1)
+    for st in steps:
+        if how == "run_steps":
+            hfx.run_steps_partitioned_blocks(blocks, F, M, comm, 1)
+        else:
+            ints = [f for f in F if isinstance(f, hfx.IntInters)]
+            bdys = [f for f in F if isinstance(f, hfx.BdyInters)]
+            for rk in range(nstage):  # CalcResidual's order with the partition-face calls (src/solver.cpp:59-221)
+                for e in blocks: e.extrapolate_solution()
+                for f in M: f.send_solution(comm)
+                for e in blocks: e.calculate_gradient()
+                for e in blocks: e.evaluate_invFlux()
+                for f in ints: f.calculate_common_invFlux()
+                for f in bdys: f.evaluate_boundaryConditions_invFlux()
+                for f in M: f.receive_solution(comm)
+                for f in M: f.calculate_common_invFlux()
+                for e in blocks: e.correct_gradient()
+                for f in M: f.send_corrected_gradient(comm)
+                for e in blocks: e.evaluate_viscFlux()
+                for e in blocks: e.extrapolate_totalFlux()
+                for e in blocks: e.calculate_divergence()
+                for f in ints: f.calculate_common_viscFlux()
+                for f in bdys: f.evaluate_boundaryConditions_viscFlux()
+                for f in M: f.receive_corrected_gradient(comm)
+                for f in M: f.calculate_common_viscFlux()
+                for e in blocks: e.calculate_corrected_divergence()
+                for e in blocks: e.AdvanceSolution(rk, adv)
+        for c in classes:
+            k = "c%d_u_step%d_stage%d" % (c, st, nstage - 1)
+            assert relerr(E[c].download(hfx.DISU_UPTS0), d[k]) < 1e-11, k
+    if how == "deferred":
+        nf, nr, why = ctx.deferred_stats()
+        assert (nf, nr) == (len(steps) * nstage, 0), why
+    for c in classes:
+        assert E[c].check_nan() == -1
+    comm.close()
+    for f in F + M:
+        f.close()
+    for c in classes:
+        E[c].close()
+    ctx.close()
