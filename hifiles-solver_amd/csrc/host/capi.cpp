@@ -376,12 +376,20 @@ struct hfxh_simplex
 extern "C" int hfxh_simplex_create(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
                                    hfxh_simplex **out)
 {
+  return hfxh_simplex_create_vcjh(ele_type, order, viscous, n_eles, shape, loc_1d_upts, 1, 0.0, out);
+}
+
+extern "C" int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
+                                        int vcjh_scheme, double c, hfxh_simplex **out)
+{
   if (!out || !shape || n_eles <= 0) { g_err = "hfxh_simplex_create: bad argument"; return 1; }
   if (ele_type != 2 && ele_type != 3) { g_err = "hfxh_simplex_create: ele_type must be 2 (tetrahedra) or 3 (prisms)"; return 1; }
   hfxh_simplex *s = new hfxh_simplex();
   s->in.equation = 0;
   s->in.order = order;
   s->in.viscous = viscous;
+  s->in.vcjh_scheme_tet = s->in.vcjh_scheme_tri = vcjh_scheme;
+  s->in.c_tet = s->in.c_tri = c;
   if (loc_1d_upts)
   {
     s->in.loc_1d_upts_override.setup(order + 1);

@@ -13,9 +13,11 @@
 //    the collapsed square instead of the reference's fixed-order tables (cubature_tri(0,7), cubature_1d(0,10));
 //  * the point sets ARE data of the reference (data/tri_inter.bin, data/tet_inter.bin): read from
 //    data/simplex_points.txt (tools/export_point_tables.py).
-// Correction functions: the DG member of the VCJH family on triangles and tetrahedra (vcjh_scheme_tri / _tet 1, the only
-// one the shipped cases use); other members multiply the DG lifting by a filter matrix (src/eles_tets.cpp:1305) and are
-// refused.
+// Correction functions: the DG member of the VCJH family on triangles and tetrahedra (vcjh_scheme_tri / _tet 1, the one the
+// shipped cases use) is the lifting itself; the other members (0: c given, 2: SD-like, 3: Huynh-like, 4: c+) multiply it by
+// the filter matrix Filt = (I + M^-1 K)^-1, K = c sum_alpha binom(alpha) (D^alpha)^T D^alpha over the derivatives of order p
+// (src/eles_tets.cpp:1305-1503, src/funcs.cpp:717-880) -- built from the NODAL differentiation matrices and the inverse
+// nodal mass matrix V V^T, neither of which depends on which orthonormal modal basis they are computed through.
 #include <dlfcn.h>
 
 #include <cmath>
@@ -230,6 +232,102 @@ bool invert(std::vector<double> &A, int n)
   return true;
 }
 
+// ---- the VCJH filter matrix of a simplex point set ---------------------------------------------------------------------
+double factorial(int n)
+{
+  double f = 1.0;
+  for (int i = 2; i <= n; i++) f *= i;
+  return f;
+}
+
+// c of the scheme (src/eles_tets.cpp:1336-1390, src/funcs.cpp:744-795): 0 the user's value, 1 DG (0), 2 SD-like, 3 Huynh-like,
+// 4 c+; the c+ values are tabulated for orders 2..5 (tetrahedra) / 2..4 (triangles)
+bool vcjh_c_simplex(int nd, int scheme, int order, double c_user, double &c, std::string &err)
+{
+  const double ap = 1. / std::pow(2.0, order) * factorial(2 * order) / (factorial(order) * factorial(order));
+  const double c_sd_1d = (2 * order) / ((2 * order + 1) * (order + 1) * (factorial(order) * ap) * (factorial(order) * ap));
+  const double c_hu_1d = (2 * (order + 1)) / ((2 * order + 1) * order * (factorial(order) * ap) * (factorial(order) * ap));
+  double c_plus = 0.0, c_plus_1d = 1.0;
+  if (scheme > 1)
+  {
+    static const double cp1d[6] = {0, 0, 0.206, 3.80e-3, 4.67e-5, 4.28e-7};
+    static const double cp3d[6] = {0, 0, 3.07e-2, 5.44e-4, 9.92e-6, 1.10e-7};
+    static const double cp2d[6] = {0, 0, 3.13e-2, 4.67e-4, 6.55e-6, 0};
+    if (order < 2 || order > (nd == 3 ? 5 : 4)) { err = "C_plus scheme not implemented for this order"; return false; }
+    c_plus_1d = cp1d[order];
+    c_plus = nd == 3 ? cp3d[order] : cp2d[order];
+  }
+  if (scheme == 0) c = c_user;
+  else if (scheme == 1) c = 0.0;
+  else if (scheme == 2) c = (c_sd_1d / c_plus_1d) * c_plus;
+  else if (scheme == 3) c = (c_hu_1d / c_plus_1d) * c_plus;
+  else if (scheme == 4) c = c_plus;
+  else { err = nd == 3 ? "VCJH tetrahedral scheme not recognized" : "VCJH triangular scheme not recognized"; return false; }
+  return true;
+}
+
+typedef std::vector<double> Mat; // n x n, row-major
+static Mat matmul(const Mat &A, const Mat &B, int n)
+{
+  Mat C((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < n; k++)
+    {
+      const double a = A[(size_t)i * n + k];
+      if (a != 0.0)
+        for (int j = 0; j < n; j++) C[(size_t)i * n + j] += a * B[(size_t)k * n + j];
+    }
+  return C;
+}
+
+// Filt (n x n, row-major) from the nodal differentiation matrices D[d](i, j) = d l_j / d xi_d at node i and V(i, m) = psi_m(node i)
+bool vcjh_filter(int nd, int order, int n, const std::vector<Mat> &D, const Mat &V, double c, Mat &Filt)
+{
+  Mat K((size_t)n * n, 0.0), I((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) I[(size_t)i * n + i] = 1.0;
+  auto add = [&](const Mat &Dh, double coeff) {
+    // K += c coeff Dh^T Dh
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++)
+      {
+        double t = 0.0;
+        for (int k = 0; k < n; k++) t += Dh[(size_t)k * n + i] * Dh[(size_t)k * n + j];
+        K[(size_t)i * n + j] += c * coeff * t;
+      }
+  };
+  if (nd == 2)
+    for (int k = 0; k <= order; k++)
+    {
+      Mat Dh = I;
+      for (int q = 0; q < k; q++) Dh = matmul(Dh, D[1], n);
+      for (int q = 0; q < order - k; q++) Dh = matmul(Dh, D[0], n);
+      add(Dh, (1. / n) * (factorial(order) / (factorial(k) * factorial(order - k))));
+    }
+  else
+    for (int v = 1; v <= order + 1; v++)
+      for (int w = 1; w <= v; w++)
+      {
+        Mat Dh = I;
+        for (int q = 1; q <= order - v + 1; q++) Dh = matmul(Dh, D[0], n);
+        for (int q = 1; q <= v - w; q++) Dh = matmul(Dh, D[1], n);
+        for (int q = 1; q <= w - 1; q++) Dh = matmul(Dh, D[2], n);
+        add(Dh, (1. / n) * (factorial(order) / (factorial(v - 1) * factorial(order - (v - 1)))) *
+                    (factorial(v - 1) / (factorial(w - 1) * factorial((v - 1) - (w - 1)))));
+      }
+  // inverse nodal mass matrix V V^T, then (I + M^-1 K)^-1
+  Mat Minv((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++)
+    {
+      double t = 0.0;
+      for (int m = 0; m < n; m++) t += V[(size_t)i * n + m] * V[(size_t)j * n + m];
+      Minv[(size_t)i * n + j] = t;
+    }
+  Filt = matmul(Minv, K, n);
+  for (int i = 0; i < n; i++) Filt[(size_t)i * n + i] += 1.0;
+  return invert(Filt, n);
+}
+
 // Lagrange basis of a triangle point set: coefficients C[m][i] with l_i(r,s) = sum_m C[m][i] psi_m(r,s) (= V^-T)
 struct TriNodal
 {
@@ -325,7 +423,7 @@ int eles_tets::setup_ele_type_specific()
     fail("eles_tets: shock capturing, over-integration and the LES filters are built for the tensor-product classes only");
     return 1;
   }
-  if (run_input->vcjh_scheme_tet != 1) { fail("eles_tets: only the DG correction (vcjh_scheme_tet 1) is built; the VCJH filter matrix is not"); return 1; }
+  if (run_input->vcjh_scheme_tet < 0 || run_input->vcjh_scheme_tet > 4) { fail("VCJH tetrahedral scheme not recognized"); return 1; } /* src/eles_tets.cpp:1389 */
   if (run_input->upts_type_tet != 0 || run_input->fpts_type_tet != 0) { fail("eles_tets: point rule not implemented (rule 0, internal, is)"); return 1; }
   n_fields = 5;
   n_inters_per_ele = 4;
@@ -459,6 +557,35 @@ void eles_tets::fill_opp_3(hf_array<double> &o3)
       }
     }
   }
+  // the other members of the VCJH family: opp_3 = Filt . opp_3_dg (src/eles_tets.cpp:1144-1166)
+  double c = 0.0;
+  std::string err;
+  if (!vcjh_c_simplex(3, run_input->vcjh_scheme_tet, p, run_input->c_tet, c, err)) { fail(err); return; }
+  if (c == 0.0) return;
+  std::vector<Mat> D(3, Mat((size_t)n * n));
+  Mat V((size_t)n * n), Filt;
+  hf_array<double> loc(3);
+  for (int i = 0; i < n; i++)
+  {
+    for (int d = 0; d < 3; d++) loc(d) = loc_upts(d, i);
+    for (int j = 0; j < n; j++)
+    {
+      for (int d = 0; d < 3; d++) D[d][(size_t)i * n + j] = eval_d_nodal_basis(j, d, loc);
+      V[(size_t)i * n + j] = simplex3d(loc(0), loc(1), loc(2), mode_i[j], mode_j[j], mode_k[j]);
+    }
+  }
+  if (!vcjh_filter(3, p, n, D, V, c, Filt)) { fail("eles_tets: singular VCJH filter matrix"); return; }
+  const int nfp = n_fpts_per_ele;
+  std::vector<double> dg((size_t)n * nfp);
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < nfp; i++) dg[(size_t)j * nfp + i] = o3(j, i);
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < nfp; i++)
+    {
+      double t = 0.0;
+      for (int k = 0; k < n; k++) t += Filt[(size_t)j * n + k] * dg[(size_t)k * nfp + i];
+      o3(j, i) = t;
+    }
 }
 
 double eles_tets::eval_nodal_s_basis(int in_index, const hf_array<double> &loc, int in_n_spts)
@@ -500,7 +627,7 @@ int eles_pris::setup_ele_type_specific()
     fail("eles_pris: shock capturing, over-integration and the LES filters are built for the tensor-product classes only");
     return 1;
   }
-  if (run_input->vcjh_scheme_tri != 1) { fail("eles_pris: only the DG correction on the triangle (vcjh_scheme_tri 1) is built"); return 1; }
+  if (run_input->vcjh_scheme_tri < 0 || run_input->vcjh_scheme_tri > 4) { fail("VCJH triangular scheme not recognized"); return 1; } /* src/funcs.cpp:794 */
   if (run_input->upts_type_pri_tri != 0) { fail("eles_pris: point rule not implemented (rule 0, internal, is)"); return 1; }
   if (run_input->upts_type_pri_tri != run_input->fpts_type_tet) { fail("upts_type_pri_tri != fpts_type_tet"); return 1; }   /* src/eles_pris.cpp:116 */
   if (run_input->upts_type_pri_1d != run_input->upts_type_hexa) { fail("upts_type_pri_1d != upts_type_hexa"); return 1; } /* :120 */
@@ -608,6 +735,33 @@ void eles_pris::fill_opp_3(hf_array<double> &o3)
   const int p = order, N = p + 1, nt = n_upts_tri;
   std::vector<double> o3tri;
   tri_dg_lifting(p, impl->tri, impl->tr, impl->ts, loc_1d_upts, o3tri);
+  {
+    // the triangle's other VCJH members: opp_3_tri = Filt . opp_3_dg (get_opp_3_tri, src/funcs.cpp:629-641)
+    double c = 0.0;
+    std::string err;
+    if (!vcjh_c_simplex(2, run_input->vcjh_scheme_tri, p, run_input->c_tri, c, err)) { fail(err); return; }
+    if (c != 0.0)
+    {
+      std::vector<Mat> D(2, Mat((size_t)nt * nt));
+      Mat V((size_t)nt * nt), Filt;
+      for (int i = 0; i < nt; i++)
+        for (int j = 0; j < nt; j++)
+        {
+          impl->tri.gradient(j, impl->tr[i], impl->ts[i], D[0][(size_t)i * nt + j], D[1][(size_t)i * nt + j]);
+          V[(size_t)i * nt + j] = simplex2d(impl->tr[i], impl->ts[i], impl->tri.mi[j], impl->tri.mj[j]);
+        }
+      if (!vcjh_filter(2, p, nt, D, V, c, Filt)) { fail("eles_pris: singular VCJH filter matrix"); return; }
+      const int ne = 3 * N; // edge flux points of the triangle; o3tri(ut, i) = o3tri[ut + nt * i]
+      std::vector<double> dg = o3tri;
+      for (int j = 0; j < nt; j++)
+        for (int i = 0; i < ne; i++)
+        {
+          double t = 0.0;
+          for (int k = 0; k < nt; k++) t += Filt[(size_t)j * nt + k] * dg[(size_t)k + (size_t)nt * i];
+          o3tri[(size_t)j + (size_t)nt * i] = t;
+        }
+    }
+  }
   double eta = run_input->eta_pri;
   if (run_input->vcjh_scheme_pri_1d != 0 && !compute_eta(run_input->vcjh_scheme_pri_1d, p, eta)) { fail("Invalid VCJH scheme"); return; }
   for (int upt = 0; upt < n_upts_per_ele; upt++)

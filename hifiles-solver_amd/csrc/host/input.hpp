@@ -48,6 +48,7 @@ struct input
   int upts_type_tet = 0, fpts_type_tet = 0, vcjh_scheme_tet = 1;
   int upts_type_pri_tri = 0, upts_type_pri_1d = 0, vcjh_scheme_pri_1d = 1, vcjh_scheme_tri = 1;
   double eta_pri = 0.0;
+  double c_tet = 0.0, c_tri = 0.0; // vcjh_scheme_tet / _tri 0: the filter's c given (src/input.cpp:289,299)
   int upts_type_quad = 0, vcjh_scheme_quad = 1;
   double eta_quad = 0.0;
   // ---- gas

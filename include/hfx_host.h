@@ -138,6 +138,11 @@ int hfxh_case_time_partitioned(hfxh_case *c, int reps, double ms[8]);
 typedef struct hfxh_simplex hfxh_simplex;
 int hfxh_simplex_create(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
                         hfxh_simplex **out);
+/* the same with another member of the VCJH family on the tetrahedron / on the prism's triangle: vcjh_scheme_tet / vcjh_scheme_tri
+ * 0 (the filter's c given: c_tet / c_tri), 1 DG, 2 SD-like, 3 Huynh-like, 4 c+ (/root/reference/src/eles_tets.cpp:1305-1390,
+ * src/funcs.cpp:717-795) */
+int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
+                             int vcjh_scheme, double c, hfxh_simplex **out);
 int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const double **ptr, int dims[4]);
 int hfxh_simplex_destroy(hfxh_simplex *s);
 

@@ -129,6 +129,17 @@ CASES = [
     # a longer run: 40 time steps (200 RK stages) of the genuine reference, the state after every step -- rounding
     # differences between the paths must not grow
     case("hex_p2_long", amp=0.15, level=0, order=2, steps=40, keep_every=10),
+    # the other members of the VCJH family on tetrahedra (filter matrix of src/eles_tets.cpp:1305) and on the prism's triangle
+    # (src/funcs.cpp:717): SD-like, Huynh-like, c+, and a c given by the user
+    case("tet_p2_vcjh_sd", n=2, amp=0.1, level=1, order=2, steps=1, tets=True,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=2, eta_tet=0.0),
+    case("tet_p3_vcjh_cplus", n=2, amp=0.1, level=1, order=3, steps=1, tets=True,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=4, eta_tet=0.0),
+    case("tet_p2_vcjh_c", n=2, amp=0.1, level=1, order=2, steps=1, tets=True,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=0, c_tet=0.02, eta_tet=0.0),
+    case("pri_p2_vcjh_hu", n=2, amp=0.1, level=1, order=2, steps=1, tets="prisms",
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
+         vcjh_scheme_tri=3, c_tri=0.0),
     # BASELINE.json configs[3]'s order: P3 tetrahedra and prisms (operators of the size the mixed channel case runs with)
     case("tet_p3_n2_deformed", n=2, amp=0.1, level=1, order=3, steps=1, tets=True,
          upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),

@@ -221,6 +221,29 @@ def test_simplex_operators_and_metrics_vs_reference(name, pre):
     S.close()
 
 
+@pytest.mark.parametrize("name,scheme,c", [("tet_p2_vcjh_sd", 2, 0.0), ("tet_p3_vcjh_cplus", 4, 0.0), ("tet_p2_vcjh_c", 0, 0.02),
+                                           ("pri_p2_vcjh_hu", 3, 0.0)])
+def test_simplex_vcjh_members_vs_reference(name, scheme, c):
+    """The members of the VCJH family other than DG on tetrahedra (vcjh_scheme_tet 0 / 2 / 4) and on the prism's triangle
+    (vcjh_scheme_tri 3): opp_3 = Filt . opp_3_dg with the filter matrix of src/eles_tets.cpp:1305-1503 / src/funcs.cpp:717-880,
+    built here from the nodal differentiation matrices and V V^T -- equal to the genuine reference's opp_3 to 1e-11 of its
+    scale (the filter involves products of up to p differentiation matrices and one inverse), and different from the DG one."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    sz = [int(v) for v in d["sizes"]]
+    ele_type, order = sz[6], sz[5]
+    x1 = d["loc_upts"][2, ::(order + 1) * (order + 2) // 2] if ele_type == 3 else None
+    shp = d["shape"][:, :(4 if ele_type == 2 else 6), :]
+    S = H.Simplex(ele_type, order, shp, viscous=1, loc_1d_upts=x1, vcjh_scheme=scheme, c=c)
+    got, want = S.array("opp_3"), d["opp_3"]
+    assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()
+    for k in ("opp_0", "opp_1_0", "opp_2_1", "opp_5_2", "opp_6"):
+        assert np.abs(S.array(k) - d[k]).max() <= 1e-12 * np.abs(d[k]).max(), k
+    S.close()
+    dg = H.Simplex(ele_type, order, shp, viscous=1, loc_1d_upts=x1)
+    assert np.abs(dg.array("opp_3") - want).max() > 1e-3 * np.abs(want).max()
+    dg.close()
+
+
 def test_simplex_classes_refuse_what_they_do_not_build():
     d = dict(np.load(os.path.join(GOLDEN, "tet_p2_n2_deformed.npz")))
     with pytest.raises(Exception):
