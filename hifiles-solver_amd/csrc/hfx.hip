@@ -41,6 +41,14 @@ static int make_operator(Operator &op, const double *host, int m, int k)
   op.m = m;
   op.k = k;
   if (dev_alloc_copy(&op.dense, host, (long)m * k)) return 1;
+  {
+    op.mpad = (m + 15) & ~15;
+    op.kpad = (k + 3) & ~3;
+    std::vector<double> pad((size_t)op.mpad * op.kpad, 0.0);
+    for (int c = 0; c < k; c++)
+      for (int r = 0; r < m; r++) pad[r + (size_t)op.mpad * c] = host[r + (long)m * c];
+    if (dev_alloc_copy(&op.dense_pad, pad.data(), (long)pad.size())) return 1;
+  }
   // ELL: exact non-zeros, ascending column
   int nnz_max = 0;
   long total = 0;
@@ -86,6 +94,7 @@ static int make_operator(Operator &op, const double *host, int m, int k)
 static void free_operator(Operator &op)
 {
   if (op.dense) (void)hipFree(op.dense);
+  if (op.dense_pad) (void)hipFree(op.dense_pad);
   if (op.ell_val) (void)hipFree(op.ell_val);
   if (op.ell_idx) (void)hipFree(op.ell_idx);
   op = Operator();
@@ -169,6 +178,8 @@ static int launch_dense(hfx_ctx *ctx, const Operator &op, const double *B, doubl
   a.ncols = ncols;
   a.beta = beta;
   a.A = op.dense;
+  a.Ap = op.dense_pad;
+  a.mpad = op.mpad;
   a.B = B;
   a.C = C;
   a.sub = sub;

@@ -43,6 +43,10 @@ struct Operator
 {
   int m = 0, k = 0;
   double *dense = nullptr; // (m,k) column-major
+  // the same zero-padded to whole MFMA tiles, (mpad, kpad) column-major with mpad = 16 ceil(m/16), kpad = 4 ceil(k/4): the
+  // dense contraction kernels read operator fragments from it without bounds checks
+  double *dense_pad = nullptr;
+  int mpad = 0, kpad = 0;
   // ELL form: exact non-zeros of every row in ASCENDING column order (the
   // reference dgemm sums l ascending, src/funcs.cpp:110-117), padded with
   // (val 0, col = first column of the row).  Row-interleaved: entry q of row r

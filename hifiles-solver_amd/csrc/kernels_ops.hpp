@@ -136,7 +136,9 @@ struct DenseArgs
   int m, k;
   long ncols;
   int beta;
-  const double *A; // (m,k) col-major
+  const double *A;  // (m,k) col-major
+  const double *Ap; // the same zero-padded to (mpad, kpad), mpad = 16 ceil(m/16), kpad = 4 ceil(k/4)
+  int mpad;
   const double *B; // (k,ncols)
   double *C;       // (m,ncols)
   const double *sub;
@@ -145,6 +147,40 @@ struct DenseArgs
 };
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// The k loop of one unit of work (a 16-row tile of the operator x NS 16-column sub-tiles of the B tile in LDS), branch-free:
+// operator fragments from the zero-padded copy (no bounds checks), whole groups of UK k-steps with every load of the group
+// requested before its first MFMA, then the remaining k-steps one by one.  (Written with per-load predicates and a per-step
+// "past the end?" test the loop compiled to a branch per load and `ds_read; s_waitcnt; v_mfma` per step.)
+template <int NS, int LDB>
+__device__ __forceinline__ void dense_unit_kloop(const double *__restrict__ Ap, int mpad, int kpad, const double *bt, int row, int lk,
+                                                 int li, int s0, f64x4 (&acc)[NS])
+{
+  constexpr int UK = 8;
+  const double *ap = Ap + row + (long)mpad * lk;
+  const double *bp = bt + lk * LDB + s0 * 16 + li;
+  int kb = 0;
+  for (; kb + 4 * UK <= kpad; kb += 4 * UK)
+  {
+    double av[UK], bv[UK][NS];
+#pragma unroll
+    for (int u = 0; u < UK; u++) av[u] = ap[(long)mpad * (kb + 4 * u)];
+#pragma unroll
+    for (int u = 0; u < UK; u++)
+#pragma unroll
+      for (int s = 0; s < NS; s++) bv[u][s] = bp[(kb + 4 * u) * LDB + s * 16];
+#pragma unroll
+    for (int u = 0; u < UK; u++)
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u][s], av[u], acc[s], 0, 0, 0);
+  }
+  for (; kb < kpad; kb += 4)
+  {
+    const double av = ap[(long)mpad * kb];
+#pragma unroll
+    for (int s = 0; s < NS; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(bp[kb * LDB + s * 16], av, acc[s], 0, 0, 0);
+  }
+}
 
 constexpr int DENSE_CT = 64; // columns per workgroup (32 / 16 for operators with many columns: the B tile holds all of k)
 
@@ -260,32 +296,7 @@ __global__ __launch_bounds__(64 * NW) void dense_mfma_kernel(const DenseArgs a)
         acc[s][rg] = (a.beta && row_ok && ocol < ncl) ? a.C[(c0 + ocol) * m + row] : 0.0;
       }
     }
-    // the operator fragments of UK k-steps are fetched together (L2-resident A, one latency per UK MFMA groups)
-    constexpr int UK = 8;
-    for (int kb = 0; kb < kpad; kb += 4 * UK)
-    {
-      double av[UK];
-#pragma unroll
-      for (int u = 0; u < UK; u++)
-      {
-        const int kk = kb + 4 * u + lk;
-        av[u] = (row_ok && kk < k) ? a.A[row + (long)m * kk] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < UK; u++)
-      {
-        const int kk = kb + 4 * u + lk;
-        if (kb + 4 * u < kpad)
-        {
-#pragma unroll
-          for (int s = 0; s < NS; s++)
-          {
-            const double bv = btile[kk * LDB + (s0 + s) * 16 + li];
-            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av[u], acc[s], 0, 0, 0);
-          }
-        }
-      }
-    }
+    dense_unit_kloop<NS, LDB>(a.Ap, a.mpad, kpad, btile, row, lk, li, s0, acc);
 #pragma unroll
     for (int s = 0; s < NS; s++)
     {
