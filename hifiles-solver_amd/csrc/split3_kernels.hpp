@@ -1166,6 +1166,10 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
               for (int m = 0; m < ND; m++) ts += jg2[0][l + ND * m] * sgq[k + NF * m];
               tsg[k + NF * l] = ts;
             }
+          // (its first direction waits in the state region of this element's input slot, dead since phase A -- five registers
+          // fewer across phase C)
+#pragma unroll
+          for (int k = 0; k < NF; k++) su[k * NUS + tu] = tsg[k];
 #pragma unroll
           for (int q = 0; q < NG; q++) ft[q] = ldsv(&st[q * NU + tu]);
         }
@@ -1443,7 +1447,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       if (is_u)
       {
 #pragma unroll
-        for (int q = 0; q < NG; q++) st[q * NU + tu] = tsg[q];
+        for (int q = 0; q < NG; q++) st[q * NU + tu] = (q < NF) ? ldsv(&su[q * NUS + tu]) : tsg[q];
       }
       lds_barrier(); // 5
       // ... every pencil item extrapolates its component to the pencil's two ends: +- L . F~_sgs,d = (F~_sgs . n~) there,
