@@ -633,6 +633,24 @@ int hfx_eles_download(hfx_eles *e, int id, double *host)
   return 0;
 }
 
+int hfx_eles_is_current(hfx_eles *e, int id, int *current)
+{
+  HFX_CHECK(e && current, "hfx_eles_is_current: NULL argument");
+  HFX_CHECK(id >= 0 && id < HFX_N_ARRAYS, "hfx_eles_is_current: bad array id %d", id);
+  // (a pending record is not run for this question)
+  const hfx::Deferred &d = e->ctx->defer;
+  if (!(d.on && (e->stale & (1u << id))))
+    *current = 1;
+  else
+  {
+    // stale now -- but a pending stage that a request for this array would turn into a replay refreshes it
+    bool pending_stage = false;
+    for (const hfx::DeferCall &c : d.log) pending_stage = pending_stage || (c.method == hfx::DM_CORRECTED_DIVERGENCE && c.e == e);
+    *current = pending_stage ? 2 : 0;
+  }
+  return 0;
+}
+
 int hfx_eles_device_ptr(hfx_eles *e, int id, double **dev)
 {
   HFX_CHECK(e && dev, "hfx_eles_device_ptr: NULL argument");

@@ -346,7 +346,11 @@ extern "C" int hfxh_case_sync_host(hfxh_case *c)
   eles *E = the_eles(c);
   // the gradient first: with deferred execution a pending stage then runs call by call and leaves every array of the
   // reference behind (asked for the state first it would run fused and keep the gradient on chip)
-  if (E->viscous && E->cp_grad_disu_upts_gpu_cpu()) { g_err = E->last_error(); return 1; }
+  // (... unless an earlier request has already made the last stage run fused: the gradient then stays what it was, as
+  // hfx_run_steps(..., 3) leaves it)
+  int grad_current = 1;
+  if (E->viscous && E->device() && hfx_eles_is_current(E->device(), HFX_GRAD_DISU_UPTS, &grad_current)) { g_err = hfx_last_error(); return 1; }
+  if (E->viscous && grad_current && E->cp_grad_disu_upts_gpu_cpu()) { g_err = E->last_error(); return 1; }
   if (E->cp_disu_upts_gpu_cpu() || E->cp_div_tconf_upts_gpu_cpu() || E->cp_array_gpu_cpu(HFX_DISU_UPTS1, E->disu_upts(1)))
   {
     g_err = E->last_error();

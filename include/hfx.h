@@ -168,6 +168,10 @@ int hfx_eles_destroy(hfx_eles *e);
 /* replaces hf_array::cp_cpu_gpu / cp_gpu_cpu (include/hf_array.h:541-580) */
 int hfx_eles_upload(hfx_eles *e, int array_id, const double *host);
 int hfx_eles_download(hfx_eles *e, int array_id, double *host);
+/* deferred execution: *current = 1 when the array holds the last stage's values; 2 when it does not yet but a whole stage is
+ * pending that a download of this array would run call by call (and so refresh it); 0 when the fused stage that ran last did
+ * not refresh it and nothing pending will (its download would fail) */
+int hfx_eles_is_current(hfx_eles *e, int array_id, int *current);
 /* raw device pointer of an array (for zero-copy interop with a resident caller) */
 int hfx_eles_device_ptr(hfx_eles *e, int array_id, double **dev);
 

@@ -184,12 +184,20 @@ def test_monitors_after_a_step(ctx):
     assert relerr(e.download(hfx.DISU_UPTS0), d["u_step0_stage0"]) < RTOLS
     nf, nr, _ = ctx.deferred_stats()
     assert (nf, nr) == (1, 0)
-    # the gradient of that stage was kept on chip: reading it now fails loudly
+    # the gradient of that stage was kept on chip: reading it now fails loudly (and hfx_eles_is_current says so beforehand)
+    import ctypes as C
+    cur = C.c_int(-1)
+    hfx.check(hfx.lib().hfx_eles_is_current(e.h, C.c_int(hfx.GRAD_DISU_UPTS), C.byref(cur)))
+    assert cur.value == 0
+    hfx.check(hfx.lib().hfx_eles_is_current(e.h, C.c_int(hfx.DISU_UPTS0), C.byref(cur)))
+    assert cur.value == 1
     with pytest.raises(hfx.HfxError, match="not materialised"):
         e.download(hfx.GRAD_DISU_UPTS)
     # ... whereas a stage that is still pending when the gradient is asked for runs call by call and leaves it
     calc_residual_calls([e], faces, True, 1)
     e.AdvanceSolution(1, adv)
+    hfx.check(hfx.lib().hfx_eles_is_current(e.h, C.c_int(hfx.GRAD_DISU_UPTS), C.byref(cur)))
+    assert cur.value == 2  # (a whole stage is pending: asking for the gradient makes it run call by call)
     g = e.download(hfx.GRAD_DISU_UPTS)
     assert np.isfinite(g).all() and np.abs(g).max() > 0
     nf, nr, why = ctx.deferred_stats()
