@@ -272,13 +272,17 @@ int partitioned_stage(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_
     HFX_HIP(hipEventRecord(comm->received[1], cs));
     if (phase(3, rk, 0)) return 1; // interior common fluxes                                  | compute stream
     HFX_HIP(hipStreamWaitEvent(st, comm->received[1], 0));
-    if (phase(9, rk, 0)) return 1; // update (+ shock capturing)
+    // the update: first the elements with partition-face points, whose new flux-point solution is packed and sent (communication
+    // stream) while the others are updated -- the exchange the next stage's flux kernel waits for is hidden behind them
+    const bool split_update = ctx->opt.split_update && !e->shock_ready && n_mpi > 0;
+    if (split_update ? phase(11, rk, 0) : phase(9, rk, 0)) return 1; // update (+ shock capturing)
     HFX_HIP(hipEventRecord(comm->packed[0], st));
     HFX_HIP(hipStreamWaitEvent(cs, comm->packed[0], 0));
     ctx->mpi_stream = cs;
     rc = phase(10, rk, 0); // pack the new flux-point solution
     if (!rc) rc = start_exchange(comm, mpi_faces, n_mpi, 0, false, true);
     ctx->mpi_stream = nullptr;
+    if (!rc && split_update) rc = phase(12, rk, 0);
     return rc;
   }
   if (T) HFX_HIP(hipEventRecord(T->ph[0], st));

@@ -42,7 +42,8 @@ void fused_destroy(hfx_eles *e)
 {
   if (!e || !e->fused) return;
   FusedData *f = e->fused;
-  void *p[] = {f->meta, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim, f->nbr, f->les_len2};
+  void *p[] = {f->meta, f->disu_alt, f->fn_fpts, f->t_coef, f->t_idx, f->pk_g, f->pk_r, f->tab_g, f->tab_r, f->o1m_dim, f->nbr, f->les_len2,
+               f->upd_list_b, f->upd_list_i};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete f;
@@ -469,6 +470,24 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
     for (long o = 0; o < plane_f; o++)
       HFX_CHECK(paired[o], "fused path: flux point %ld belongs to no registered face (partition faces need "
                            "hfx_stage_partitioned / hfx_run_steps_partitioned)", o);
+  for (int **q : {&F->upd_list_b, &F->upd_list_i})
+    if (*q) { (void)hipFree(*q); *q = nullptr; }
+  F->n_list_b = F->n_list_i = 0;
+  if (allow_unpaired)
+  {
+    // the elements with a partition-face point, and the others (split update launch of hfx_run_steps_partitioned)
+    std::vector<int> lb, li;
+    for (int el = 0; el < e->n_eles; el++)
+    {
+      bool any = false;
+      for (int j = 0; j < nfp && !any; j++) any = !paired[(long)nfp * el + j];
+      (any ? lb : li).push_back(el);
+    }
+    F->n_list_b = (long)lb.size();
+    F->n_list_i = (long)li.size();
+    if (!lb.empty() && upload((void **)&F->upd_list_b, lb.data(), sizeof(int) * lb.size())) return 1;
+    if (!li.empty() && upload((void **)&F->upd_list_i, li.data(), sizeof(int) * li.size())) return 1;
+  }
   if (upload((void **)&F->meta, meta.data(), plane_f)) return 1;
   {
     // partner of every interior flux point for the flux kernel that forms the LDG corrections itself:
@@ -820,17 +839,34 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
     }
     if (beside && side_stream_wait(e->ctx)) return 1;
   }
-  if (which == 0 || which == 4)
+  if (which == 0 || which == 4 || which == 41 || which == 42)
   {
     if (variant == 3)
     {
+      // 41 / 42: the update on the elements with partition-face points / on the others (two launches: the first one's
+      // flux-point solution leaves for the neighbours while the second runs); 42 comes behind the buffer swap of 41
+      e2.ele_list = nullptr;
+      e2.n_list = 0;
+      if (which == 41) { e2.ele_list = F->upd_list_b; e2.n_list = F->n_list_b; }
+      if (which == 42) { e2.ele_list = F->upd_list_i; e2.n_list = F->n_list_i; e2.disu_next = e->arr[HFX_DISU_FPTS]; }
+      HFX_CHECK(which < 41 || e2.ele_list != nullptr || e2.n_list == 0, "split update: no element lists (the block was not built as a partitioned one)");
       // buffer-descriptor addressing needs 32-bit byte offsets
       const bool nobuf = !opt.buffer_addressing;
       const bool small = (double)std::max<long>(plane_f, (long)e->n_upts * e->n_eles) * e->n_fields * 8.0 < 4294967296.0;
-      if (small && !nobuf)
-        hipLaunchKernelGGL((split_update_kernel<ND, N, true>), dim3(element_grid<split_update_kernel<ND, N, true>>(e, TB, per_cu, 3)), dim3(TB), 0, st, e2);
-      else
-        hipLaunchKernelGGL((split_update_kernel<ND, N, false>), dim3(element_grid<split_update_kernel<ND, N, false>>(e, TB, per_cu, 3)), dim3(TB), 0, st, e2);
+      const long n_work = which >= 41 ? e2.n_list : (long)e->n_eles;
+      if (n_work > 0)
+      {
+        if (small && !nobuf)
+        {
+          const int g = (int)std::min<long>(n_work, element_grid<split_update_kernel<ND, N, true>>(e, TB, per_cu, 3));
+          hipLaunchKernelGGL((split_update_kernel<ND, N, true>), dim3(g), dim3(TB), 0, st, e2);
+        }
+        else
+        {
+          const int g = (int)std::min<long>(n_work, element_grid<split_update_kernel<ND, N, false>>(e, TB, per_cu, 3));
+          hipLaunchKernelGGL((split_update_kernel<ND, N, false>), dim3(g), dim3(TB), 0, st, e2);
+        }
+      }
     }
     else
     {
@@ -876,7 +912,8 @@ static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_st
   HFX_SPLIT_CASE(2, 2) HFX_SPLIT_CASE(2, 3) HFX_SPLIT_CASE(2, 4) HFX_SPLIT_CASE(2, 5) HFX_SPLIT_CASE(2, 6)
 #undef HFX_SPLIT_CASE
   if (rc) return 1;
-  if (which == 0 || which == 4) std::swap(e->arr[HFX_DISU_FPTS], e->fused->disu_alt);
+  // (the buffer swap: behind the whole update, or behind its first part -- the second part then writes the new buffer by name)
+  if (which == 0 || which == 4 || which == 41) std::swap(e->arr[HFX_DISU_FPTS], e->fused->disu_alt);
   return 0;
 }
 

@@ -67,6 +67,10 @@ struct Split2Args
   // LES closure evaluated in the flux kernel (split_flux_tensor_kernel<..., LES = true>): eles::calc_sgsf_upts at the solution
   // points; wall_distance (n_upts,n_eles,n_dims) for the Smagorinsky damping; tdA_fpts to take the extrapolated SGS flux of a
   // flux point from F~ . n~ to F . n
+  // update kernel on a LIST of elements (partitioned blocks: the elements that own partition-face points first, so that their
+  // new flux-point solution can leave for the neighbours while the rest is updated); NULL: all elements
+  const int *ele_list;
+  long n_list;
   LesParams les;
   const double *les_len2, *tdA_fpts; // les_len2 (n_upts,n_eles): the closure's squared length scale (calc_sgsf_fast)
 };
@@ -1634,7 +1638,12 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
   }
   else if (a.adv_type != 0)
     rk_form = 2;
-  for (long kk = 0, e = order.at(0); e >= 0; kk++, e = order.at(kk))
+  auto element = [&](long kk) -> long {
+    if (a.ele_list == nullptr) return order.at(kk);
+    const long q = blockIdx.x + kk * gridDim.x;
+    return q < a.n_list ? (long)a.ele_list[q] : -1;
+  };
+  for (long kk = 0, e = element(0); e >= 0; kk++, e = element(kk))
   {
     const long eu = (long)NU * e, ef = (long)NFP * e;
     double u[NF], dvin[NF], u1v[NF], tcv[NF], sv[NF];

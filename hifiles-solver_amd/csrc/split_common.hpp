@@ -29,6 +29,9 @@ struct FusedData
   double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)
   int *o1m_dim = nullptr;                    // (n_fpts) dimension slab of the merged opp_1 row
   int *nbr = nullptr;                        // (n_fpts, n_eles) partner of every interior flux point (split3_kernels.hpp, Split2Args::nbr)
+  // partitioned blocks: the elements that own a flux point without a registered face (= a partition-face point), and the rest
+  int *upd_list_b = nullptr, *upd_list_i = nullptr;
+  long n_list_b = 0, n_list_i = 0;
   double *les_len2 = nullptr;                // (n_upts, n_eles) squared length scale of the LES closure evaluated in the flux kernel
   bool gather_on = false;                    // the last stage formed the interior LDG corrections in the flux kernel (no face_delta launch)
   bool built = false;

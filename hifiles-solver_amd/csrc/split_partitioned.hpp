@@ -127,6 +127,10 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
     if (e->shock_ready && shock_capture_keep_fpts(e)) return 1;
     return 0;
   case 10: return mpi_all(0); // pack the new flux-point solution
+  // the update in two launches (no shock capturing: its filter follows the WHOLE update): the elements with partition-face
+  // points, whose new flux-point solution then leaves while the others are updated
+  case 11: return (variant == 3 && !e->shock_ready) ? split_stage(e, int_faces, n_int, in_step, last, 41, variant) : 1;
+  case 12: return (variant == 3 && !e->shock_ready) ? split_stage(e, int_faces, n_int, in_step, last, 42, variant) : 1;
   default:
     HFX_CHECK(false, "hfx_stage_partitioned: phase %d out of range", phase);
   }
