@@ -259,8 +259,13 @@ int partitioned_stage(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_
     ctx->mpi_stream = nullptr;
     if (r5) return 1;
     HFX_HIP(hipEventRecord(comm->received[0], cs));
+    // the flux kernel in three launches (option split_flux): half of the elements WITHOUT partition-face points first -- they
+    // need nothing from the neighbours, so the solution exchange runs beside them --, then the elements with, whose projected
+    // fluxes then leave beside the other half (and the interior common-flux kernel)
+    const bool split_flux = ctx->opt.split_flux && !e->over_int_ready && n_mpi > 0;
+    if (split_flux && phase(13, rk, 0)) return 1;
     HFX_HIP(hipStreamWaitEvent(st, comm->received[0], 0));
-    if (phase(6, rk, 0)) return 1; // gradient + flux kernel
+    if (split_flux ? phase(14, rk, 0) : phase(6, rk, 0)) return 1; // gradient + flux kernel
     HFX_HIP(hipEventRecord(comm->packed[1], st));
     HFX_HIP(hipStreamWaitEvent(cs, comm->packed[1], 0));
     ctx->mpi_stream = cs;
@@ -270,6 +275,7 @@ int partitioned_stage(hfx_eles *e, hfx_inters *const *int_faces, int n_int, hfx_
     ctx->mpi_stream = nullptr;
     if (rc) return 1;
     HFX_HIP(hipEventRecord(comm->received[1], cs));
+    if (split_flux && phase(15, rk, 0)) return 1;
     if (phase(3, rk, 0)) return 1; // interior common fluxes                                  | compute stream
     HFX_HIP(hipStreamWaitEvent(st, comm->received[1], 0));
     // the update: first the elements with partition-face points, whose new flux-point solution is packed and sent (communication

@@ -485,6 +485,7 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
     }
     F->n_list_b = (long)lb.size();
     F->n_list_i = (long)li.size();
+    F->n_list_i1 = F->n_list_i / 2;
     if (!lb.empty() && upload((void **)&F->upd_list_b, lb.data(), sizeof(int) * lb.size())) return 1;
     if (!li.empty() && upload((void **)&F->upd_list_i, li.data(), sizeof(int) * li.size())) return 1;
   }
@@ -554,7 +555,8 @@ struct LoaderWaveLaunch<ND, N, OI, GA, LES, true>
     constexpr int TB = SGeo<ND, N>::TB + 64;
     // (the over-integration form measured 3 % faster at sixteen workgroups per CU than at the two that are resident)
     if (OI && per_cu == 0) per_cu = 16;
-    const int grid = element_grid<split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA, LES>>(e, TB, per_cu);
+    int grid = element_grid<split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA, LES>>(e, TB, per_cu);
+    if (e2.ele_list != nullptr) grid = (int)std::max<long>(1, std::min<long>(grid, e2.n_list));
     hipLaunchKernelGGL((split_flux_tensor_kernel<ND, N, 2, true, OI, true, GA, LES>), dim3(grid), dim3(TB), 0, st, e2, coef, idx);
   }
 };
@@ -719,7 +721,18 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   if (variant == 3)
   {
     if (which == 5 && e->over_int_ready && hfx_eles_evaluate_invFlux_over_int(e)) return 1;
-    if (which == 0 || which == 2 || which == 7)
+    // 21 / 22 / 23: the flux kernel on a part of the elements (partitioned blocks, hfx_run_steps_partitioned): the first half of
+    // the elements without partition-face points, those with, the second half -- the solution exchange runs beside the
+    // first launch, the exchange of the projected fluxes beside the third
+    const bool flux_part = which >= 21 && which <= 23;
+    e2.ele_list = nullptr;
+    e2.n_list = 0;
+    if (which == 21) { e2.ele_list = F->upd_list_i; e2.n_list = F->n_list_i1; }
+    if (which == 22) { e2.ele_list = F->upd_list_b; e2.n_list = F->n_list_b; }
+    if (which == 23) { e2.ele_list = F->upd_list_i ? F->upd_list_i + F->n_list_i1 : nullptr; e2.n_list = F->n_list_i - F->n_list_i1; }
+    if (flux_part && e2.n_list == 0) return 0;
+    HFX_CHECK(!flux_part || (e2.ele_list != nullptr && !e->over_int_ready), "split flux kernel on element lists: no lists, or over-integration (which runs on all elements first)");
+    if (which == 0 || which == 2 || which == 7 || flux_part)
     {
       e2.tdisf_in = nullptr;
       if (e->over_int_ready)

@@ -444,6 +444,7 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   else if (n == "fold_general") o.fold_general = value != 0;
   else if (n == "comm_stream_faces") o.comm_stream_faces = value != 0;
   else if (n == "split_update") o.split_update = value != 0;
+  else if (n == "split_flux") o.split_flux = value != 0;
   else if (n == "flux_stamps") o.flux_stamps = value;
   else if (n == "simd_roles") o.simd_roles = value != 0;
   else if (n == "les_flux_kernel") o.les_flux_kernel = value != 0;

@@ -136,6 +136,7 @@ struct hfx_ctx
     int dictionary_rows = 0;    // 1: the dictionary-row flux kernel even when the operators are tensor products
     int flux_waves = 2;         // waves per SIMD the sum-factorised flux kernel is launched for (2 or 3)
     int buffer_addressing = 1;  // buffer-descriptor addressing where every array is below 4 GiB
+    int split_flux = 1;         // hfx_run_steps_partitioned: the flux kernel in three launches (half of the elements without partition-face points | those with | the other half)
     int split_update = 1;       // hfx_run_steps_partitioned: the update kernel in two launches, partition-face elements first (their exchange hidden behind the rest)
     int comm_stream_faces = 1;  // hfx_run_steps_partitioned: partition-face kernels on the communication stream, beside the interior ones
     int fold_general = 1;       // general fused stage: opp_3 norm_tdisf folded into the divergence operator (no norm_tdisf traffic)

@@ -67,8 +67,8 @@ struct Split2Args
   // LES closure evaluated in the flux kernel (split_flux_tensor_kernel<..., LES = true>): eles::calc_sgsf_upts at the solution
   // points; wall_distance (n_upts,n_eles,n_dims) for the Smagorinsky damping; tdA_fpts to take the extrapolated SGS flux of a
   // flux point from F~ . n~ to F . n
-  // update kernel on a LIST of elements (partitioned blocks: the elements that own partition-face points first, so that their
-  // new flux-point solution can leave for the neighbours while the rest is updated); NULL: all elements
+  // flux / update kernel on a LIST of elements (partitioned blocks: the elements that own partition-face points in a launch of
+  // their own, so that the exchanges of their data run beside the work on the others); NULL: all elements
   const int *ele_list;
   long n_list;
   LesParams les;
@@ -311,7 +311,10 @@ struct EleOrder
   long ne, chunk;
   int per, slot, xcd;
   bool remap;
-  __device__ __forceinline__ EleOrder(long n_eles, bool want) : ne(n_eles)
+  const int *list; // optional: the launch works on list[0 .. n_list) instead of all elements (partitioned blocks)
+  long n_list;
+  __device__ __forceinline__ EleOrder(long n_eles, bool want, const int *ele_list = nullptr, long n_ele_list = 0)
+      : ne(n_eles), list(ele_list), n_list(n_ele_list)
   {
     remap = want && (gridDim.x % 8 == 0);
     per = gridDim.x / 8;
@@ -322,6 +325,11 @@ struct EleOrder
   // k-th element of this workgroup, -1 past the end
   __device__ __forceinline__ long at(long k) const
   {
+    if (list != nullptr)
+    {
+      const long q = blockIdx.x + k * gridDim.x; // (uniform: a scalar load)
+      return q < n_list ? (long)list[q] : -1;
+    }
     if (!remap)
     {
       const long e = blockIdx.x + k * gridDim.x;
@@ -660,7 +668,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       for (int m = 0; m < ND; m++) nrm[m] = g_nrm.ld(ef_cur + m * plane_f, lf);
     }
   };
-  const EleOrder order(ne, a.xcd_order != 0);
+  const EleOrder order(ne, a.xcd_order != 0, a.ele_list, a.n_list);
   if constexpr (LW)
   {
     if (t >= TB)
@@ -1611,7 +1619,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
   const long tot_u = plane_u * NF, tot_f = plane_f * NF;
   const GArr<BUF> g_u0(a.u0, tot_u), g_u1(a.u1, tot_u), g_div(a.div, tot_u), g_src(a.src, tot_u), g_dj(a.detjac_upts, plane_u);
   const GArr<BUF> g_tc(a.tconf, tot_f), g_nt(a.ntd_fpts, tot_f), g_dn(a.disu_next, tot_f);
-  const EleOrder order(ne, a.xcd_order != 0);
+  const EleOrder order(ne, a.xcd_order != 0, a.ele_list, a.n_list);
   // the RK formula of this launch (uniform): 0: u -= dt/div (dd - s), 1: u = ca u + cb u1 + dt/div rhs, 2: low storage
   int rk_form = 0;
   double rk_div = 1.0, rk_ca = 0.0, rk_cb = 0.0;
@@ -1638,12 +1646,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB), HFX_UPD_WAVES) void split_update
   }
   else if (a.adv_type != 0)
     rk_form = 2;
-  auto element = [&](long kk) -> long {
-    if (a.ele_list == nullptr) return order.at(kk);
-    const long q = blockIdx.x + kk * gridDim.x;
-    return q < a.n_list ? (long)a.ele_list[q] : -1;
-  };
-  for (long kk = 0, e = element(0); e >= 0; kk++, e = element(kk))
+  for (long kk = 0, e = order.at(0); e >= 0; kk++, e = order.at(kk))
   {
     const long eu = (long)NU * e, ef = (long)NFP * e;
     double u[NF], dvin[NF], u1v[NF], tcv[NF], sv[NF];

@@ -32,6 +32,7 @@ struct FusedData
   // partitioned blocks: the elements that own a flux point without a registered face (= a partition-face point), and the rest
   int *upd_list_b = nullptr, *upd_list_i = nullptr;
   long n_list_b = 0, n_list_i = 0;
+  long n_list_i1 = 0; // the flux kernel takes the others in two parts: upd_list_i[0 .. n_list_i1) and the rest
   double *les_len2 = nullptr;                // (n_upts, n_eles) squared length scale of the LES closure evaluated in the flux kernel
   bool gather_on = false;                    // the last stage formed the interior LDG corrections in the flux kernel (no face_delta launch)
   bool built = false;

@@ -129,6 +129,11 @@ int split_stage_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_int
   case 10: return mpi_all(0); // pack the new flux-point solution
   // the update in two launches (no shock capturing: its filter follows the WHOLE update): the elements with partition-face
   // points, whose new flux-point solution then leaves while the others are updated
+  // the flux kernel in three launches: the first half of the elements without partition-face points (needs nothing from the
+  // neighbours), the elements with (behind the LDG corrections of the partition faces), the second half
+  case 13: return (variant == 3 && !e->over_int_ready) ? split_stage(e, int_faces, n_int, in_step, false, 21, 3) : 1;
+  case 14: return (variant == 3 && !e->over_int_ready) ? split_stage(e, int_faces, n_int, in_step, false, 22, 3) : 1;
+  case 15: return (variant == 3 && !e->over_int_ready) ? split_stage(e, int_faces, n_int, in_step, false, 23, 3) : 1;
   case 11: return (variant == 3 && !e->shock_ready) ? split_stage(e, int_faces, n_int, in_step, last, 41, variant) : 1;
   case 12: return (variant == 3 && !e->shock_ready) ? split_stage(e, int_faces, n_int, in_step, last, 42, variant) : 1;
   default:
