@@ -967,6 +967,11 @@ int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distanc
   HFX_CHECK(les->sgs_model != 0 || wall_distance, "hfx_eles_set_les: the Smagorinsky model needs wall_distance");
   HFX_CHECK(e->viscous_ops, "LES not supported with inviscid flow"); /* src/input.cpp:570 */
   e->les.sgs_model = les->sgs_model; e->les.order = e->order;
+  {
+    static const double ref_vol[5] = {2.0, 4.0, 8.0 / 6.0, 4.0, 8.0}; // tri, quad, tet, prism, hex
+    HFX_CHECK(e->ele_type >= 0 && e->ele_type <= 4, "hfx_eles_set_les: unknown element class %d", e->ele_type);
+    e->les.vol_factor = ref_vol[e->ele_type];
+  }
   e->les.C_s = les->C_s; e->les.filter_ratio = les->filter_ratio; e->les.Kappa = les->Kappa; e->les.prandtl_t = les->prandtl_t;
   e->les.Lu = e->arr[HFX_LU]; e->les.Le = e->arr[HFX_LE]; // NULL until hfx_eles_set_les_filter
   for (double **p : {&e->wall_distance, &e->Jacobian_fpts})

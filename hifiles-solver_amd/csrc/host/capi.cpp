@@ -386,6 +386,12 @@ extern "C" int hfxh_simplex_create(int ele_type, int order, int viscous, int n_e
 extern "C" int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
                                         int vcjh_scheme, double c, hfxh_simplex **out)
 {
+  return hfxh_simplex_create_les(ele_type, order, viscous, n_eles, shape, loc_1d_upts, vcjh_scheme, c, -1, 0, 1.0, out);
+}
+
+extern "C" int hfxh_simplex_create_les(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
+                                       int vcjh_scheme, double c, int SGS_model, int filter_type, double filter_ratio, hfxh_simplex **out)
+{
   if (!out || !shape || n_eles <= 0) { g_err = "hfxh_simplex_create: bad argument"; return 1; }
   if (ele_type != 2 && ele_type != 3) { g_err = "hfxh_simplex_create: ele_type must be 2 (tetrahedra) or 3 (prisms)"; return 1; }
   hfxh_simplex *s = new hfxh_simplex();
@@ -394,6 +400,13 @@ extern "C" int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, in
   s->in.viscous = viscous;
   s->in.vcjh_scheme_tet = s->in.vcjh_scheme_tri = vcjh_scheme;
   s->in.c_tet = s->in.c_tri = c;
+  if (SGS_model >= 0)
+  {
+    s->in.LES = 1;
+    s->in.SGS_model = SGS_model;
+    s->in.filter_type = filter_type;
+    s->in.filter_ratio = filter_ratio;
+  }
   if (loc_1d_upts)
   {
     s->in.loc_1d_upts_override.setup(order + 1);
@@ -442,6 +455,8 @@ extern "C" int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const d
   else if (n == "norm_fpts") a = &E->norm_fpts;
   else if (n == "pos_upts") a = &E->pos_upts;
   else if (n == "pos_fpts") a = &E->pos_fpts;
+  else if (n == "filter_upts" && E->filter_upts.get_dim(0) > 0) a = &E->filter_upts;
+  else if (n == "Jacobian_fpts" && E->Jacobian_fpts.get_dim(0) > 0) a = &E->Jacobian_fpts;
   if (!a) { g_err = "hfxh_simplex_get_array: unknown array " + n; return 1; }
   *ptr = a->get_ptr_cpu();
   for (int i = 0; i < 4; i++) dims[i] = a->get_dim(i);

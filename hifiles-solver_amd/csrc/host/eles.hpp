@@ -93,7 +93,7 @@ public:
   int calc_disu_ppts_all();                                         // every element at once, on the device
   void calc_disu_ppts(int in_ele, hf_array<double> &out_disu_ppts); // the reference's per-element accessor
   int set_shock_capture_operators(); // set_vandermonde1D/3D, calc_norm_basis, set_exp_filter
-  int compute_filter_upts();         // src/eles_hexas.cpp:583, src/eles_quads.cpp:428 (LES_filter)
+  virtual int compute_filter_upts(); // src/eles_hexas.cpp:583, src/eles_quads.cpp:428 (LES_filter); eles_tets overrides it
   hf_array<double> filter_upts_1D, filter_upts;
   int set_over_int();                // set_over_int (cubature points, interpolation, L2-projection filter)
   void tensor_modes(hf_array<int> &deg) const;
@@ -165,6 +165,7 @@ protected:
   void fill_opp_3(hf_array<double> &opp_3) override;
   double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
   void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
+  int compute_filter_upts() override; // src/eles_tets.cpp:576-690 (modal filter, element average)
   std::vector<int> mode_i, mode_j, mode_k; // the orthonormal modal basis the nodal one is computed through
   std::vector<double> vinv;                // inverse Vandermonde matrix, row-major
 };

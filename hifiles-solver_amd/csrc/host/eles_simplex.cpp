@@ -418,9 +418,9 @@ int eles_tets::setup_ele_type_specific()
   ele_type = 2;
   n_dims = 3;
   if (run_input->equation != 0) { fail("Equation not supported"); return 1; }
-  if (run_input->shock_cap || run_input->over_int || run_input->LES)
+  if (run_input->shock_cap || run_input->over_int)
   {
-    fail("eles_tets: shock capturing, over-integration and the LES filters are built for the tensor-product classes only");
+    fail("eles_tets: shock capturing and over-integration are built for the tensor-product classes only");
     return 1;
   }
   if (run_input->vcjh_scheme_tet < 0 || run_input->vcjh_scheme_tet > 4) { fail("VCJH tetrahedral scheme not recognized"); return 1; } /* src/eles_tets.cpp:1389 */
@@ -487,6 +487,63 @@ int eles_tets::setup_ele_type_specific()
     set_opp_6();
   }
   return failed() ? 1 : 0;
+}
+
+// The LES filter of the closures that filter the solution (SGS_model 2, 3, 4) on tetrahedra, src/eles_tets.cpp:576-690:
+//   filter_type 2: modal, V diag(exp(-(2 m / N)^2 / 48)) V^-1 with the modes numbered as the reference's Vandermonde matrix
+//     numbers them (src/funcs.cpp:1461-1497: by total degree, m the mode's position) -- the scaling of a mode cancels;
+//   filter_type 0, 1: the reference stops ("not implemented for tris");  otherwise the element average 1/N;
+//   then the reference's symmetrisation and row normalisation passes, statement by statement (they work in place).
+int eles_tets::compute_filter_upts()
+{
+  const int N = n_upts_per_ele, p = order;
+  const int type = run_input->filter_type;
+  if (type == 0) { fail("Vasilyev filters not implemented for tris. Exiting."); return 1; } /* src/eles_tets.cpp:610 */
+  if (type == 1) { fail("Gaussian filter not implemented for tris. Exiting."); return 1; }  /* src/eles_tets.cpp:615 */
+  filter_upts.setup(N, N);
+  filter_upts.initialize_to_zero();
+  if (type == 2)
+  {
+    // position of every mode in the reference's numbering
+    std::vector<int> ri, rj, rk;
+    for (int m = 0; m <= p; m++)
+      for (int n = 0; n <= m; n++)
+        for (int k = 0; k <= n; k++) { const int j = n - k; ri.push_back(m - j - k); rj.push_back(j); rk.push_back(k); }
+    std::vector<double> V((size_t)N * N), Vi;
+    for (int i = 0; i < N; i++)
+      for (int m = 0; m < N; m++) V[(size_t)i * N + m] = simplex3d(loc_upts(0, i), loc_upts(1, i), loc_upts(2, i), ri[m], rj[m], rk[m]);
+    Vi = V;
+    if (!invert(Vi, N)) { fail("eles_tets: singular Vandermonde matrix"); return 1; }
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++)
+      {
+        double t = 0.0;
+        for (int m = 0; m < N; m++)
+        {
+          const double eta = m / double(N);
+          t += V[(size_t)i * N + m] * std::exp(-std::pow(2.0 * eta, 2.0) / 48.0) * Vi[(size_t)m * N + j];
+        }
+        filter_upts(i, j) = t;
+      }
+  }
+  else
+    filter_upts.initialize_to_value(1.0 / N);
+  int N2 = N / 2;
+  if (N % 2 != 0) N2 += 1;
+  for (int i = 0; i < N2; i++)
+    for (int j = 0; j < N; j++)
+    {
+      filter_upts(i, j) = 0.5 * filter_upts(i, j) + filter_upts(N - i - 1, N - j - 1);
+      filter_upts(N - i - 1, N - j - 1) = filter_upts(i, j);
+    }
+  for (int i = 0; i < N2; i++)
+  {
+    double norm = 0.0;
+    for (int j = 0; j < N; j++) norm += filter_upts(i, j);
+    for (int j = 0; j < N; j++) filter_upts(i, j) /= norm;
+    for (int j = 0; j < N; j++) filter_upts(N - i - 1, N - j - 1) = filter_upts(i, j);
+  }
+  return 0;
 }
 
 double eles_tets::eval_nodal_basis(int in_index, const hf_array<double> &loc)
@@ -622,11 +679,14 @@ int eles_pris::setup_ele_type_specific()
   ele_type = 3;
   n_dims = 3;
   if (run_input->equation != 0) { fail("Equation not supported"); return 1; }
-  if (run_input->shock_cap || run_input->over_int || run_input->LES)
+  if (run_input->shock_cap || run_input->over_int)
   {
-    fail("eles_pris: shock capturing, over-integration and the LES filters are built for the tensor-product classes only");
+    fail("eles_pris: shock capturing and over-integration are built for the tensor-product classes only");
     return 1;
   }
+  // the reference's prism class builds no LES filter (src/eles_pris.cpp:134, commented out): the closures that filter the
+  // solution would multiply by an empty matrix there
+  if (run_input->LES && run_input->SGS_model >= 2) { fail("eles_pris: the reference builds no LES filter for prisms (SGS_model 0 or 1 only)"); return 1; }
   if (run_input->vcjh_scheme_tri < 0 || run_input->vcjh_scheme_tri > 4) { fail("VCJH triangular scheme not recognized"); return 1; } /* src/funcs.cpp:794 */
   if (run_input->upts_type_pri_tri != 0) { fail("eles_pris: point rule not implemented (rule 0, internal, is)"); return 1; }
   if (run_input->upts_type_pri_tri != run_input->fpts_type_tet) { fail("upts_type_pri_tri != fpts_type_tet"); return 1; }   /* src/eles_pris.cpp:116 */

@@ -445,6 +445,7 @@ struct LesParams
 {
   int sgs_model, order;
   double C_s, filter_ratio, Kappa, prandtl_t;
+  double vol_factor; // calc_ele_vol / detjac: the reference element's volume (hexes 8, quads 4, prisms 4, tetrahedra 8/6, triangles 2)
   const double *Lu, *Le;
 };
 
@@ -465,7 +466,7 @@ __device__ __forceinline__ void calc_sgsf(const Phys &P, const LesParams &Lp, co
     ke += 0.5 * (u[i] * u[i]);
   }
   const double inte = tu[NF - 1] / rho - ke;
-  const double vol = detjac * (ND == 3 ? 8. : 4.); // calc_ele_vol of hexes / quads
+  const double vol = detjac * Lp.vol_factor; // calc_ele_vol of the class (src/eles_hexas.cpp:1542, eles_pris.cpp:1525, eles_tets.cpp:1589)
   const double delta = Lp.filter_ratio * pow(vol, 1. / ND) / (Lp.order + 1.);
 #pragma unroll
   for (int i = 0; i < ND; i++)

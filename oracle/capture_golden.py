@@ -156,6 +156,19 @@ CASES = [
     case("hex_p2_les_wsm", amp=0.15, level=2, order=2, steps=2, LES=1, SGS_model=2, C_s=0.325, filter_ratio=2.0, filter_type=0),
     case("hex_p2_les_sim", amp=0.15, level=2, order=2, steps=2, LES=1, SGS_model=4, C_s=0.325, filter_ratio=2.0, filter_type=1),
     case("hex_p2_les_svv", amp=0.15, level=1, order=2, steps=2, LES=1, SGS_model=3, C_s=0.325, filter_ratio=2.0, filter_type=0),
+    # LES on the simplex classes (src/eles_tets.cpp:127,576-690: modal and average filters; the prism class builds none,
+    # src/eles_pris.cpp:134): WALE on tetrahedra and prisms, WALE + similarity with the modal filter and the similarity closure
+    # with the element average on tetrahedra
+    case("tet_p2_les_wale", n=2, amp=0.1, level=2, order=2, steps=1, tets=True, LES=1, SGS_model=1, C_s=0.325, filter_ratio=1.0,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p2_les_wale", n=2, amp=0.1, level=2, order=2, steps=1, tets="prisms", LES=1, SGS_model=1, C_s=0.325,
+         filter_ratio=1.0, upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
+         vcjh_scheme_tri=1, c_tri=0.0),
+    # (P3: at P2 the genuine reference aborts in its own set-up with "free(): invalid pointer" when a tetrahedral filter is asked for)
+    case("tet_p3_les_wsm", n=2, amp=0.1, level=2, order=3, steps=2, tets=True, LES=1, SGS_model=2, C_s=0.325, filter_ratio=2.0,
+         filter_type=2, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("tet_p3_les_sim", n=2, amp=0.1, level=1, order=3, steps=2, tets=True, LES=1, SGS_model=4, C_s=0.325, filter_ratio=2.0,
+         filter_type=3, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
     # the ASCII restart file of the final state (on-disk format either side of the path)
     case("hex_p2_restart", amp=0.15, level=0, order=2, steps=1, restart=True),
     case("quad_p3_restart", dims=2, n=4, amp=0.1, level=0, order=3, steps=1, restart=True),

@@ -583,7 +583,7 @@ void orc_calc_sgsf_upts(const orc_eles *e, const orc_params *P, const double *te
     y = sqrt(y);
   }
   for (int q = 0; q < nf * nd; q++) temp_sgsf[q] = 0.0;
-  const double vol = detjac * (nd == 3 ? 8. : 4.); /* calc_ele_vol of hexes / quads */
+  const double vol = detjac * e->les_vol_factor; /* calc_ele_vol of the class (src/eles_hexas.cpp:1542, eles_pris.cpp:1525, eles_tets.cpp:1589) */
   const double delta = e->filter_ratio * pow(vol, 1. / nd) / (e->order + 1.);
   for (int i = 0; i < nd; i++)
   {

@@ -68,6 +68,7 @@ typedef struct orc_eles
   int sgs_model;
   double C_s, filter_ratio, Kappa, prandtl_t;
   int order;                   /* run_input.order (filter width) */
+  double les_vol_factor;       /* calc_ele_vol / detjac of the class: hexes 8, quads 4, prisms 4, tetrahedra 8/6, triangles 2 (src/eles_*.cpp calc_ele_vol) */
   const double *wall_distance; /* (n_upts,n_eles,n_dims), model 0 */
   double *sgsf_upts;           /* (n_upts,n_eles,n_fields,n_dims) */
   double *sgsf_fpts;           /* (n_fpts,n_eles,n_fields,n_dims) */

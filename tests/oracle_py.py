@@ -30,7 +30,7 @@ class Eles(C.Structure):
         ("norm_tconf_fpts", dp), ("div_tconf_upts", dp), ("delta_disu_fpts", dp),
         ("grad_disu_upts", dp), ("grad_disu_fpts", dp), ("src_upts", dp), ("dt_local", dp),
         ("sgs_model", C.c_int), ("C_s", C.c_double), ("filter_ratio", C.c_double), ("Kappa", C.c_double),
-        ("prandtl_t", C.c_double), ("order_les", C.c_int), ("wall_distance", dp), ("sgsf_upts", dp), ("sgsf_fpts", dp), ("Jacobian_fpts", dp),
+        ("prandtl_t", C.c_double), ("order_les", C.c_int), ("les_vol_factor", C.c_double), ("wall_distance", dp), ("sgsf_upts", dp), ("sgsf_fpts", dp), ("Jacobian_fpts", dp),
         ("n_cub", C.c_int), ("opp_over_int_cubpts", dp), ("over_int_filter", dp), ("JGinv_over_int_cubpts", dp),
         ("filter_upts", dp), ("disuf_upts", dp), ("uu", dp), ("Lu", dp), ("ue", dp), ("Le", dp)]
 
@@ -119,6 +119,7 @@ class Case:
         g = lambda k: np.asfortranarray(np.array(data[k], dtype=np.float64))
         sz = [int(v) for v in data["sizes"]]
         self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims, self.order = sz[:6]
+        self.ele_type = sz[6] if len(sz) > 6 else (4 if sz[4] == 3 else 1)
         ne, nu, nfp, nf, nd = self.n_eles, self.n_upts, self.n_fpts, self.n_fields, self.n_dims
         self.viscous = int(np.ravel(data["viscous"])[0])
         self.arr = {}
@@ -226,6 +227,8 @@ class Case:
             e.sgs_model = self.les["sgs_model"]
             e.C_s, e.filter_ratio, e.Kappa, e.prandtl_t = (self.les[k] for k in ("C_s", "filter_ratio", "Kappa", "prandtl_t"))
             e.order_les = self.order
+            # calc_ele_vol: |J| times the reference element's volume (src/eles_*.cpp)
+            e.les_vol_factor = {0: 2.0, 1: 4.0, 2: 8.0 / 6.0, 3: 4.0, 4: 8.0}[self.ele_type]
             e.sgsf_upts, e.sgsf_fpts = fptr(a["sgsf_upts"]), fptr(a["sgsf_fpts"])
             e.Jacobian_fpts = fptr(a["Jacobian_fpts"])
             if e.sgs_model == 0:

@@ -280,3 +280,16 @@ def test_les_filter_vs_reference(name):
                SGS_model=k["SGS_model"], C_s=k["C_s"], filter_ratio=k["filter_ratio"], filter_type=k["filter_type"])
     assert np.abs(c.array("filter_upts") - d["filter_upts"]).max() < 1e-12 * np.abs(d["filter_upts"]).max()
     c.close()
+
+
+@pytest.mark.parametrize("name", ["tet_p3_les_wsm", "tet_p3_les_sim"])
+def test_tet_les_filter_vs_reference(name):
+    """eles_tets::compute_filter_upts (src/eles_tets.cpp:576-690): the modal filter and the element average, after the
+    reference's in-place symmetrisation and normalisation passes, from the host mirror's eles_tets"""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    k = json.loads(bytes(d["meta_json"]).decode())["keys"]
+    s = H.Simplex(2, k["order"], d["shape"], SGS_model=k["SGS_model"], filter_ratio=k["filter_ratio"], filter_type=k["filter_type"])
+    F = s.array("filter_upts")
+    assert F.shape == d["filter_upts"].shape
+    assert np.abs(F - d["filter_upts"]).max() < 1e-12 * np.abs(d["filter_upts"]).max()
+    s.close()

@@ -5,6 +5,7 @@ one residual) come from the GENUINE reference.  What is new against the single-c
 whose left and right sides belong to DIFFERENT element classes (/root/reference/src/int_inters.cpp:67-121, wired per
 (ctype(ic_l), ctype(ic_r)) in src/geometry.cpp:637-706) and CalcResidual over several element blocks
 (src/solver.cpp:50-223 loops every method over the classes)."""
+import json
 import os
 
 import numpy as np
@@ -235,6 +236,49 @@ def test_mixed_channel_from_the_host_mirrors_own_operators(fused):
     for c in classes:
         E[c].close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tet_p2_les_wale", "pri_p2_les_wale", "tet_p3_les_wsm", "tet_p3_les_sim"])
+def test_simplex_les_from_the_host_mirrors_own_operators(name):
+    """LES on tetrahedra and prisms (src/eles.cpp:2395 with the class's calc_ele_vol; src/eles_tets.cpp:576 for the filter of the
+    closures that filter the solution): operators, metrics, Jacobian_fpts and filter_upts from the host mirror's eles_tets /
+    eles_pris, the reference's call sequence through the per-method entry points (deferred execution replays it: the general
+    fused stage has no closure), states against the genuine reference after every step of the fixture"""
+    import hfx
+    import hfx_host as H
+    from test_gpu_methods_vs_golden import build
+    from test_gpu_deferred import calc_residual_calls, tag
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    k = json.loads(bytes(d["meta_json"]).decode())["keys"]
+    sz = [int(v) for v in d["sizes"]]
+    x1 = d["loc_upts"][2, ::(sz[5] + 1) * (sz[5] + 2) // 2] if sz[6] == 3 else None
+    S = H.Simplex(sz[6], sz[5], d["shape"][:, :(4 if sz[6] == 2 else 6), :], viscous=1, loc_1d_upts=x1, SGS_model=k["SGS_model"],
+                  filter_type=k.get("filter_type", 0), filter_ratio=k["filter_ratio"])
+    names = ["opp_0", "opp_3", "opp_6", "detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts", "Jacobian_fpts"] + \
+            ["opp_%d_%d" % (w, dd) for w in (1, 2, 4, 5) for dd in range(3)] + (["filter_upts"] if k["SGS_model"] >= 2 else [])
+    for n in names:
+        a = S.array(n)
+        assert a.shape == d[n].shape, n
+        d[n] = a
+    S.close()
+    nstage = int(d["sizes"][7])
+    steps = sorted({int(q.split("_")[1][4:]) for q in d if q.startswith("u_step")})
+    for deferred in (0, 1):
+        ctx = hfx.Context(0)
+        ctx.set_option("deferred", deferred)
+        e, faces = build(ctx, d)
+        tag(e, d)
+        adv = int(np.ravel(d["adv_type"])[0])
+        for st in steps:
+            for rk in range(nstage):
+                calc_residual_calls([e], faces, True, rk)
+                e.AdvanceSolution(rk, adv)
+            assert relerr(e.download(hfx.DISU_UPTS0), d["u_step%d_stage%d" % (st, nstage - 1)]) < 1e-11, (deferred, st)
+        for f in faces:
+            f.close()
+        e.close()
+        ctx.close()
 
 
 @pytest.mark.gpu
