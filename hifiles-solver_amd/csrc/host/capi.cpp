@@ -386,11 +386,12 @@ extern "C" int hfxh_simplex_create(int ele_type, int order, int viscous, int n_e
 extern "C" int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
                                         int vcjh_scheme, double c, hfxh_simplex **out)
 {
-  return hfxh_simplex_create_les(ele_type, order, viscous, n_eles, shape, loc_1d_upts, vcjh_scheme, c, -1, 0, 1.0, out);
+  return hfxh_simplex_create_les(ele_type, order, viscous, n_eles, 0, shape, loc_1d_upts, vcjh_scheme, c, -1, 0, 1.0, out);
 }
 
-extern "C" int hfxh_simplex_create_les(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
-                                       int vcjh_scheme, double c, int SGS_model, int filter_type, double filter_ratio, hfxh_simplex **out)
+extern "C" int hfxh_simplex_create_les(int ele_type, int order, int viscous, int n_eles, int n_spts, const double *shape,
+                                       const double *loc_1d_upts, int vcjh_scheme, double c, int SGS_model, int filter_type,
+                                       double filter_ratio, hfxh_simplex **out)
 {
   if (!out || !shape || n_eles <= 0) { g_err = "hfxh_simplex_create: bad argument"; return 1; }
   if (ele_type != 2 && ele_type != 3) { g_err = "hfxh_simplex_create: ele_type must be 2 (tetrahedra) or 3 (prisms)"; return 1; }
@@ -413,7 +414,13 @@ extern "C" int hfxh_simplex_create_les(int ele_type, int order, int viscous, int
     for (int i = 0; i <= order; i++) s->in.loc_1d_upts_override(i) = loc_1d_upts[i];
   }
   s->E = (ele_type == 2) ? (eles *)new eles_tets() : (eles *)new eles_pris();
-  const int ns = (ele_type == 2) ? 4 : 6;
+  const int ns = n_spts > 0 ? n_spts : ((ele_type == 2) ? 4 : 6);
+  if (ele_type == 2 ? (ns != 4 && ns != 10) : (ns != 6 && ns != 15))
+  {
+    g_err = "hfxh_simplex_create: shape nodes per element must be 4 or 10 (tetrahedra), 6 or 15 (prisms)";
+    delete s;
+    return 1;
+  }
   if (s->E->setup(n_eles, ns, &s->in)) { g_err = s->E->last_error(); delete s; return 1; }
   hf_array<double> pos(3);
   for (int e = 0; e < n_eles; e++)

@@ -645,20 +645,46 @@ void eles_tets::fill_opp_3(hf_array<double> &o3)
     }
 }
 
+// Shape functions of the straight-sided (4 nodes) and the quadratic (10 nodes) tetrahedron, src/eles_tets.cpp:1034-1141, through the
+// barycentric coordinates l_0 = -(r+s+t+1)/2, l_1 = (r+1)/2, l_2 = (s+1)/2, l_3 = (t+1)/2: vertex v -> l_v (2 l_v - 1), the node
+// on edge (a, b) -> 4 l_a l_b; the reference numbers the edge nodes 4 (0,1), 5 (0,2), 6 (0,3), 7 (1,2), 8 (2,3), 9 (3,1).
+static const int tet_edge[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {2, 3}, {3, 1}};
+static inline void tet_bary(const hf_array<double> &loc, double l[4])
+{
+  l[0] = -0.5 * (loc(0) + loc(1) + loc(2) + 1.);
+  for (int v = 1; v < 4; v++) l[v] = 0.5 * (loc(v - 1) + 1.);
+}
+static inline double tet_dbary(int v, int k) { return v == 0 ? -0.5 : (v - 1 == k ? 0.5 : 0.0); }
+
 double eles_tets::eval_nodal_s_basis(int in_index, const hf_array<double> &loc, int in_n_spts)
 {
-  if (in_n_spts != 4) { fail("Shape order not implemented yet, exiting"); return 0.0; } /* src/eles_tets.cpp:1075 */
-  if (in_index == 0) return -0.5 * (loc(0) + loc(1) + loc(2) + 1.);
-  return 0.5 * (loc(in_index - 1) + 1.);
+  double l[4];
+  tet_bary(loc, l);
+  if (in_n_spts == 4) return l[in_index];
+  if (in_n_spts != 10) { fail("Shape order not implemented yet, exiting"); return 0.0; } /* src/eles_tets.cpp:1075 */
+  if (in_index < 4) return l[in_index] * (2. * l[in_index] - 1.);
+  const int *e = tet_edge[in_index - 4];
+  return 4. * l[e[0]] * l[e[1]];
 }
 
-void eles_tets::eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &, int in_n_spts)
+void eles_tets::eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &loc, int in_n_spts)
 {
-  if (in_n_spts != 4) { fail("Shape order not implemented yet, exiting"); return; }
+  if (in_n_spts != 4 && in_n_spts != 10) { fail("Shape order not implemented yet, exiting"); return; }
+  double l[4];
+  tet_bary(loc, l);
   for (int k = 0; k < 3; k++)
   {
-    d(0, k) = -0.5;
-    for (int s = 1; s < 4; s++) d(s, k) = (s - 1 == k) ? 0.5 : 0.0;
+    if (in_n_spts == 4)
+    {
+      for (int v = 0; v < 4; v++) d(v, k) = tet_dbary(v, k);
+      continue;
+    }
+    for (int v = 0; v < 4; v++) d(v, k) = (4. * l[v] - 1.) * tet_dbary(v, k);
+    for (int q = 0; q < 6; q++)
+    {
+      const int a = tet_edge[q][0], b = tet_edge[q][1];
+      d(4 + q, k) = 4. * (l[a] * tet_dbary(b, k) + l[b] * tet_dbary(a, k));
+    }
   }
 }
 
@@ -845,8 +871,50 @@ void eles_pris::fill_opp_3(hf_array<double> &o3)
   }
 }
 
+// The 15-node prism of src/eles_pris.cpp:1115-1146 as products of triangle and line functions: with the triangle's barycentric
+// coordinates m_0 = -(r+s)/2, m_1 = (r+1)/2, m_2 = (s+1)/2 and the quadratic line functions q_-(t) = t (t-1)/2, q_0 = 1 - t^2,
+// q_+ = t (t+1)/2:  nodes 0-2 / 3-5 (vertices below / above): m_v (2 m_v - 1) q_-/+;  6-8 / 12-14 (edges (0,1), (1,2), (0,2) of
+// the lower / upper triangle): 4 m_a m_b q_-/+;  9-11 (mid-height of the vertical edges): m_v q_0.
+static const int pri_edge[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+static inline void pri15(const hf_array<double> &loc, int idx, double &tri, double dtri[2], double &lin, double &dlin)
+{
+  const double r = loc(0), s = loc(1), t = loc(2);
+  const double m[3] = {-0.5 * (r + s), 0.5 * (r + 1.), 0.5 * (s + 1.)};
+  const double dm[3][2] = {{-0.5, -0.5}, {0.5, 0.0}, {0.0, 0.5}};
+  const double q[3] = {0.5 * t * (t - 1.), 1. - t * t, 0.5 * t * (t + 1.)}, dq[3] = {t - 0.5, -2. * t, t + 0.5};
+  int level, kind, which; // level: 0 below, 1 mid-height, 2 above; kind 0 vertex, 1 edge
+  if (idx < 3) { level = 0; kind = 0; which = idx; }
+  else if (idx < 6) { level = 2; kind = 0; which = idx - 3; }
+  else if (idx < 9) { level = 0; kind = 1; which = idx - 6; }
+  else if (idx < 12) { level = 1; kind = 0; which = idx - 9; }
+  else { level = 2; kind = 1; which = idx - 12; }
+  lin = q[level]; dlin = dq[level];
+  if (level == 1)
+  {
+    tri = m[which];
+    for (int k = 0; k < 2; k++) dtri[k] = dm[which][k];
+  }
+  else if (kind == 0)
+  {
+    tri = m[which] * (2. * m[which] - 1.);
+    for (int k = 0; k < 2; k++) dtri[k] = (4. * m[which] - 1.) * dm[which][k];
+  }
+  else
+  {
+    const int a = pri_edge[which][0], b = pri_edge[which][1];
+    tri = 4. * m[a] * m[b];
+    for (int k = 0; k < 2; k++) dtri[k] = 4. * (m[a] * dm[b][k] + m[b] * dm[a][k]);
+  }
+}
+
 double eles_pris::eval_nodal_s_basis(int in_index, const hf_array<double> &loc, int in_n_spts)
 {
+  if (in_n_spts == 15)
+  {
+    double tri, dtri[2], lin, dlin;
+    pri15(loc, in_index, tri, dtri, lin, dlin);
+    return tri * lin;
+  }
   if (in_n_spts != 6) { fail("Shape order not implemented yet, exiting"); return 0.0; }
   const double r = loc(0), s = loc(1), t = loc(2);
   switch (in_index) /* src/eles_pris.cpp:1100-1112 */
@@ -862,6 +930,16 @@ double eles_pris::eval_nodal_s_basis(int in_index, const hf_array<double> &loc, 
 
 void eles_pris::eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &loc, int in_n_spts)
 {
+  if (in_n_spts == 15)
+  {
+    for (int i = 0; i < 15; i++)
+    {
+      double tri, dtri[2], lin, dlin;
+      pri15(loc, i, tri, dtri, lin, dlin);
+      d(i, 0) = dtri[0] * lin; d(i, 1) = dtri[1] * lin; d(i, 2) = tri * dlin;
+    }
+    return;
+  }
   if (in_n_spts != 6) { fail("Shape order not implemented yet, exiting"); return; }
   const double r = loc(0), s = loc(1), t = loc(2);
   // derivatives of the six functions above

@@ -345,18 +345,18 @@ class Case:
 
 class Simplex:
     """eles_tets (ele_type 2) / eles_pris (3) of the host mirror as producers of operators and metrics for the given
-    straight-sided elements: shape (3, n_spts, n_eles)."""
+    elements: shape (3, n_spts, n_eles), n_spts 4 / 6 (straight-sided) or 10 / 15 (quadratic)."""
 
     def __init__(self, ele_type, order, shape, viscous=1, loc_1d_upts=None, vcjh_scheme=1, c=0.0, SGS_model=-1, filter_type=0,
                  filter_ratio=1.0):
         """vcjh_scheme: vcjh_scheme_tet / vcjh_scheme_tri (0: c given, 1 DG, 2 SD-like, 3 Huynh-like, 4 c+); SGS_model >= 0: a
         run with an LES closure (Jacobian_fpts, and filter_upts on tetrahedra for the closures that filter the solution)"""
         shp = np.asfortranarray(np.array(shape, dtype=np.float64))
-        assert shp.shape[0] == 3 and shp.shape[1] == (4 if ele_type == 2 else 6)
+        assert shp.shape[0] == 3 and shp.shape[1] in ((4, 10) if ele_type == 2 else (6, 15))
         x1 = None if loc_1d_upts is None else np.ascontiguousarray(np.array(loc_1d_upts, dtype=np.float64))
         self.h = C.c_void_p()
         check(lib().hfxh_simplex_create_les(C.c_int(ele_type), C.c_int(order), C.c_int(viscous), C.c_int(shp.shape[2]),
-                                            shp.ctypes.data_as(dp), None if x1 is None else x1.ctypes.data_as(dp),
+                                            C.c_int(shp.shape[1]), shp.ctypes.data_as(dp), None if x1 is None else x1.ctypes.data_as(dp),
                                             C.c_int(vcjh_scheme), C.c_double(c), C.c_int(SGS_model), C.c_int(filter_type),
                                             C.c_double(filter_ratio), C.byref(self.h)))
 

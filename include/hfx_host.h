@@ -146,9 +146,13 @@ int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, int n_eles, c
 /* the same for a run with an LES closure (run_input.LES = 1; SGS_model < 0: none): set_transforms also fills Jacobian_fpts
  * (what hfx_eles_set_les takes), and for the closures that filter the solution (SGS_model 2, 3, 4) eles_tets builds
  * filter_upts (/root/reference/src/eles_tets.cpp:576-690: filter_type 2 modal, 3 element average; 0 and 1 stop as the reference
- * does).  The reference's prism class builds no filter (src/eles_pris.cpp:134): SGS_model >= 2 is refused there. */
-int hfxh_simplex_create_les(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
-                            int vcjh_scheme, double c, int SGS_model, int filter_type, double filter_ratio, hfxh_simplex **out);
+ * does).  The reference's prism class builds no filter (src/eles_pris.cpp:134): SGS_model >= 2 is refused there.
+ * n_spts: shape nodes per element -- 0 for the straight-sided shapes, else 4 or 10 (the quadratic tetrahedron of
+ * src/eles_tets.cpp:1047-1069, nodes 4-9 on the edges (0,1) (0,2) (0,3) (1,2) (2,3) (3,1)), 6 or 15 (the quadratic prism of
+ * src/eles_pris.cpp:1115-1146); shape is then (3, n_spts, n_eles). */
+int hfxh_simplex_create_les(int ele_type, int order, int viscous, int n_eles, int n_spts, const double *shape,
+                            const double *loc_1d_upts, int vcjh_scheme, double c, int SGS_model, int filter_type,
+                            double filter_ratio, hfxh_simplex **out);
 int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const double **ptr, int dims[4]);
 int hfxh_simplex_destroy(hfxh_simplex *s);
 

@@ -54,11 +54,12 @@ BASE = dict(
 BASE.update(TGV_FLUID)
 
 
-def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, tets=False, keep_every=1, ppts=False, **over):
+def case(name, n=3, dims=3, amp=0.0, steps=1, level=1, bcs=None, restart=False, tets=False, keep_every=1, ppts=False, curve=None,
+         **over):
     d = dict(BASE)
     d.update(over)
     return dict(name=name, n=n, dims=dims, amp=amp, steps=steps, level=level, keys=d, bcs=bcs, restart=restart, tets=tets,
-                keep_every=keep_every, ppts=ppts)
+                keep_every=keep_every, ppts=ppts, curve=curve)
 
 
 # boundary groups for the bdy_inters fixtures: states near the TGV initial state (rho 8.42e-4, T 300, Mach 0.1)
@@ -169,6 +170,13 @@ CASES = [
          filter_type=2, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
     case("tet_p3_les_sim", n=2, amp=0.1, level=1, order=3, steps=2, tets=True, LES=1, SGS_model=4, C_s=0.325, filter_ratio=2.0,
          filter_type=3, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    # curved elements: the quadratic tetrahedron (10 shape nodes, src/eles_tets.cpp:1047) and the quadratic prism (15,
+    # src/eles_pris.cpp:1115) with every mid-edge node moved off its edge
+    case("tet_p2_curved", n=2, amp=0.1, level=1, order=2, steps=1, tets=True, curve=0.06,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p2_curved", n=2, amp=0.1, level=1, order=2, steps=1, tets="prisms", curve=0.06,
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0,
+         vcjh_scheme_tri=1, c_tri=0.0),
     # the ASCII restart file of the final state (on-disk format either side of the path)
     case("hex_p2_restart", amp=0.15, level=0, order=2, steps=1, restart=True),
     case("quad_p3_restart", dims=2, n=4, amp=0.1, level=0, order=3, steps=1, restart=True),
@@ -249,9 +257,9 @@ def run_case(c):
         if c.get("tets") == "mixed":
             xv = write_neu_mixed(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])
         elif c.get("tets") == "prisms":
-            xv = write_neu_prisms(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])
+            xv = write_neu_prisms(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"], curve=c.get("curve"))
         elif c.get("tets"):
-            xv = write_neu_tets(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"])
+            xv = write_neu_tets(os.path.join(td, "mesh.neu"), c["n"], amp=c["amp"], curve=c.get("curve"))
         else:
             xv = write_neu(os.path.join(td, "mesh.neu"), c["n"], c["dims"], amp=c["amp"], bcs=c.get("bcs"))
         keys = dict(c["keys"])

@@ -142,7 +142,31 @@ def write_neu(path, n, dims=3, length=2.0 * math.pi, amp=0.0, bcname="Cyclic", b
     return xv
 
 
-def write_neu_tets(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
+def add_edge_nodes(xv, lat, n, cells, edges, length, curve):
+    """Mid-edge nodes of quadratic elements: one node per edge (keyed by its two vertices), at the edge's midpoint moved by
+    curve * (cell size) * a smooth vector field that is PERIODIC in the lattice coordinates, so that the periodic images of a
+    curved face coincide under the box translation.  -> (all node coordinates, per cell the list of its edge-node ids)."""
+    h = length / max(n)
+    nodes = [x for x in xv]
+    ids = {}
+    per_cell = []
+    for v in cells:
+        mine = []
+        for a, b in edges:
+            key = (min(v[a], v[b]), max(v[a], v[b]))
+            if key not in ids:
+                m = 0.5 * (lat[v[a]] + lat[v[b]])
+                ph = [2.0 * math.pi * m[d] / n[d] for d in range(3)]
+                bump = np.array([math.sin(ph[1] + 1.0) * math.cos(ph[2]), math.sin(ph[2] + 2.0) * math.cos(ph[0]),
+                                 math.sin(ph[0] + 3.0) * math.cos(ph[1])])
+                ids[key] = len(nodes)
+                nodes.append(0.5 * (xv[v[a]] + xv[v[b]]) + curve * h * bump)
+            mine.append(ids[key])
+        per_cell.append(mine)
+    return np.array(nodes), per_cell
+
+
+def write_neu_tets(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic", curve=None):
     """Periodic box of tetrahedra: every cube of the n^3 grid is cut into the 6 Kuhn tetrahedra (one per ordering
     of the axes, all sharing the cube's main diagonal), which makes the triangulation conforming across cubes and
     across the periodic images.  Gambit tets are element type 6 with 4 nodes; the reference's local faces are
@@ -189,6 +213,13 @@ def write_neu_tets(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
                 if (c[:, d] == 0).all() or (c[:, d] == n[d]).all():
                     bfaces.append((e + 1, 6, to_k[f]))
     ne = len(tets)
+    cells = tets
+    if curve is not None:
+        # quadratic tetrahedra: 10 nodes in Gambit's order v0 e01 v1 e02 e12 v2 e03 e13 e23 v3 (src/mesh_reader.cpp:219-223 maps
+        # them to the shape nodes 0 4 1 5 7 2 6 9 8 3)
+        xv, en = add_edge_nodes(xv, lat, n, tets, [(0, 1), (0, 2), (1, 2), (0, 3), (1, 3), (2, 3)], length, curve)
+        nv = xv.shape[0]
+        cells = [[v[0], m[0], v[1], m[1], m[2], v[2], m[3], m[4], m[5], v[3]] for v, m in zip(tets, en)]
     with open(path, "w") as f:
         f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\nperiodic_box_tets\n")
         f.write("PROGRAM:                Gambit     VERSION:  2.3.16\n\n")
@@ -198,8 +229,8 @@ def write_neu_tets(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
         for i in range(nv):
             f.write("%10d" % (i + 1) + "".join(" %.17e" % c for c in xv[i]) + "\n")
         f.write("ENDOFSECTION\n      ELEMENTS/CELLS 2.3.16\n")
-        for e, v in enumerate(tets):
-            f.write("%8d %2d %2d " % (e + 1, 6, 4) + "".join("%8d" % (q + 1) for q in v) + "\n")
+        for e, v in enumerate(cells):
+            f.write("%8d %2d %2d " % (e + 1, 6, len(v)) + "".join("%8d" % (q + 1) for q in v) + "\n")
         f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
         f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n" % (1, ne, 2, 1))
         f.write("                           fluid\n       0\n")
@@ -214,7 +245,7 @@ def write_neu_tets(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
     return xv
 
 
-def write_neu_prisms(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
+def write_neu_prisms(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic", curve=None):
     """Periodic box of triangular prisms: every cube is cut along the (x,y) diagonal into two prisms extruded in z.
     Gambit prisms are element type 5 with 6 nodes (0,1,2 bottom triangle, 3,4,5 above them); local faces f0 (0,2,1),
     f1 (3,4,5), f2 (0,1,4,3), f3 (1,2,5,4), f4 (2,0,3,5) (src/mesh.cpp get_corner_vlist_face); Gambit face k maps to
@@ -250,6 +281,13 @@ def write_neu_prisms(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
                 if (c[:, d] == 0).all() or (c[:, d] == n[d]).all():
                     bfaces.append((e + 1, 5, to_k[f]))
     ne = len(pris)
+    cells = pris
+    if curve is not None:
+        # quadratic prisms: 15 nodes in Gambit's order, which src/mesh_reader.cpp:233 maps to the shape nodes
+        # 0 6 1 8 7 2 | 9 10 11 | 3 12 4 14 13 5 (6-8 / 12-14: edges (0,1) (1,2) (0,2) below / above, 9-11: the vertical edges)
+        xv, en = add_edge_nodes(xv, lat, n, pris, [(0, 1), (1, 2), (0, 2), (0, 3), (1, 4), (2, 5), (3, 4), (4, 5), (3, 5)], length, curve)
+        nv = xv.shape[0]
+        cells = [[v[0], m[0], v[1], m[2], m[1], v[2], m[3], m[4], m[5], v[3], m[6], v[4], m[8], m[7], v[5]] for v, m in zip(pris, en)]
     with open(path, "w") as f:
         f.write("        CONTROL INFO 2.3.16\n** GAMBIT NEUTRAL FILE\nperiodic_box_prisms\n")
         f.write("PROGRAM:                Gambit     VERSION:  2.3.16\n\n")
@@ -259,8 +297,8 @@ def write_neu_prisms(path, n, length=2.0 * math.pi, amp=0.0, bcname="Cyclic"):
         for i in range(nv):
             f.write("%10d" % (i + 1) + "".join(" %.17e" % c for c in xv[i]) + "\n")
         f.write("ENDOFSECTION\n      ELEMENTS/CELLS 2.3.16\n")
-        for e, v in enumerate(pris):
-            f.write("%8d %2d %2d " % (e + 1, 5, 6) + "".join("%8d" % (q + 1) for q in v) + "\n")
+        for e, v in enumerate(cells):
+            f.write("%8d %2d %2d " % (e + 1, 5, len(v)) + "".join("%8d" % (q + 1) for q in v) + "\n")
         f.write("ENDOFSECTION\n       ELEMENT GROUP 2.3.16\n")
         f.write("GROUP: %10d ELEMENTS: %10d MATERIAL: %10d NFLAGS: %10d\n" % (1, ne, 2, 1))
         f.write("                           fluid\n       0\n")

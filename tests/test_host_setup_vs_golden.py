@@ -192,7 +192,9 @@ def test_les_jacobian_vs_reference():
 
 # ---- tetrahedra and triangular prisms: operators and metrics ------------------------------------
 SIMPLEX = [("tet_p2_n2_deformed", ""), ("tet_p3_n2_deformed", ""), ("pri_p2_n2_deformed", ""), ("pri_p3_n2_deformed", ""),
-           ("mixed_p3_channel", "c2_"), ("mixed_p3_channel", "c3_"), ("mixed_p2_channel", "c2_"), ("mixed_p2_channel", "c3_")]
+           ("mixed_p3_channel", "c2_"), ("mixed_p3_channel", "c3_"), ("mixed_p2_channel", "c2_"), ("mixed_p2_channel", "c3_"),
+           # curved: the quadratic tetrahedron (10 shape nodes) and the quadratic prism (15), every mid-edge node off its edge
+           ("tet_p2_curved", ""), ("pri_p2_curved", "")]
 
 
 @pytest.mark.parametrize("name,pre", SIMPLEX)
@@ -208,7 +210,14 @@ def test_simplex_operators_and_metrics_vs_reference(name, pre):
     x1 = None
     if ele_type == 3:  # the prism's line direction: the reference's own Gauss abscissae (data/JacobiGQ.bin)
         x1 = g("loc_upts")[2, ::(order + 1) * (order + 2) // 2]
-    shp = g("shape")[:, :(4 if ele_type == 2 else 6), :]
+    shp = g("shape")
+    if "curved" in name:
+        assert shp.shape[1] == (10 if ele_type == 2 else 15)
+        # the elements ARE curved: the Jacobian determinant varies inside an element (constant on straight-sided tetrahedra)
+        dj = g("detjac_upts")
+        assert (dj.max(axis=0) - dj.min(axis=0)).max() > 1e-3 * np.abs(dj).max()
+    else:
+        shp = shp[:, :(4 if ele_type == 2 else 6), :]
     S = H.Simplex(ele_type, order, shp, viscous=1, loc_1d_upts=x1)
     names = ["loc_upts", "tloc_fpts", "tnorm_fpts", "opp_0", "opp_3", "opp_6", "detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts",
              "tdA_fpts", "norm_fpts", "pos_upts", "pos_fpts"]
