@@ -374,6 +374,7 @@ struct hfxh_simplex
 {
   input in;
   eles *E = nullptr;
+  hf_array<double> high_modes_d;
   ~hfxh_simplex() { delete E; }
 };
 
@@ -386,13 +387,17 @@ extern "C" int hfxh_simplex_create(int ele_type, int order, int viscous, int n_e
 extern "C" int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
                                         int vcjh_scheme, double c, hfxh_simplex **out)
 {
-  return hfxh_simplex_create_les(ele_type, order, viscous, n_eles, 0, shape, loc_1d_upts, vcjh_scheme, c, -1, 0, 1.0, out);
+  hfxh_simplex_keys k{};
+  k.vcjh_scheme = vcjh_scheme; k.c = c; k.SGS_model = -1;
+  return hfxh_simplex_create_keys(ele_type, order, viscous, n_eles, 0, shape, loc_1d_upts, &k, out);
 }
 
-extern "C" int hfxh_simplex_create_les(int ele_type, int order, int viscous, int n_eles, int n_spts, const double *shape,
-                                       const double *loc_1d_upts, int vcjh_scheme, double c, int SGS_model, int filter_type,
-                                       double filter_ratio, hfxh_simplex **out)
+extern "C" int hfxh_simplex_create_keys(int ele_type, int order, int viscous, int n_eles, int n_spts, const double *shape,
+                                        const double *loc_1d_upts, const hfxh_simplex_keys *keys, hfxh_simplex **out)
 {
+  if (!keys) { g_err = "hfxh_simplex_create_keys: NULL keys"; return 1; }
+  const int vcjh_scheme = keys->vcjh_scheme, SGS_model = keys->SGS_model, filter_type = keys->filter_type;
+  const double c = keys->c, filter_ratio = keys->filter_ratio;
   if (!out || !shape || n_eles <= 0) { g_err = "hfxh_simplex_create: bad argument"; return 1; }
   if (ele_type != 2 && ele_type != 3) { g_err = "hfxh_simplex_create: ele_type must be 2 (tetrahedra) or 3 (prisms)"; return 1; }
   hfxh_simplex *s = new hfxh_simplex();
@@ -407,6 +412,11 @@ extern "C" int hfxh_simplex_create_les(int ele_type, int order, int viscous, int
     s->in.SGS_model = SGS_model;
     s->in.filter_type = filter_type;
     s->in.filter_ratio = filter_ratio;
+  }
+  if (keys->shock_cap)
+  {
+    s->in.shock_cap = keys->shock_cap;
+    s->in.expf_fac = keys->expf_fac; s->in.expf_order = keys->expf_order; s->in.expf_cutoff = keys->expf_cutoff;
   }
   if (loc_1d_upts)
   {
@@ -464,6 +474,17 @@ extern "C" int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const d
   else if (n == "pos_fpts") a = &E->pos_fpts;
   else if (n == "filter_upts" && E->filter_upts.get_dim(0) > 0) a = &E->filter_upts;
   else if (n == "Jacobian_fpts" && E->Jacobian_fpts.get_dim(0) > 0) a = &E->Jacobian_fpts;
+  else if (n == "inv_vandermonde" && E->inv_vandermonde.get_dim(0) > 0) a = &E->inv_vandermonde;
+  else if (n == "exp_filter" && E->exp_filter.get_dim(0) > 0) a = &E->exp_filter;
+  else if (n == "norm_basis_persson" && E->norm_basis_persson.get_dim(0) > 0) a = &E->norm_basis_persson;
+  else if (n == "persson_high_modes" && E->persson_high_modes.get_dim(0) > 0)
+  {
+    // (an int array: handed out as doubles through this double-typed getter)
+    hf_array<int> &hm = E->persson_high_modes;
+    s->high_modes_d.setup(hm.get_dim(0));
+    for (int i = 0; i < hm.get_dim(0); i++) s->high_modes_d(i) = hm(i);
+    a = &s->high_modes_d;
+  }
   if (!a) { g_err = "hfxh_simplex_get_array: unknown array " + n; return 1; }
   *ptr = a->get_ptr_cpu();
   for (int i = 0; i < 4; i++) dims[i] = a->get_dim(i);

@@ -92,7 +92,7 @@ public:
   void set_opp_p();
   int calc_disu_ppts_all();                                         // every element at once, on the device
   void calc_disu_ppts(int in_ele, hf_array<double> &out_disu_ppts); // the reference's per-element accessor
-  int set_shock_capture_operators(); // set_vandermonde1D/3D, calc_norm_basis, set_exp_filter
+  virtual int set_shock_capture_operators(); // set_vandermonde1D/3D, calc_norm_basis, set_exp_filter; eles_tets / eles_pris override it
   virtual int compute_filter_upts(); // src/eles_hexas.cpp:583, src/eles_quads.cpp:428 (LES_filter); eles_tets overrides it
   hf_array<double> filter_upts_1D, filter_upts;
   int set_over_int();                // set_over_int (cubature points, interpolation, L2-projection filter)
@@ -166,6 +166,7 @@ protected:
   double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
   void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
   int compute_filter_upts() override; // src/eles_tets.cpp:576-690 (modal filter, element average)
+  int set_shock_capture_operators() override; // src/eles_tets.cpp:705-797 (set_vandermonde, set_exp_filter, shock_det_persson's mode set)
   std::vector<int> mode_i, mode_j, mode_k; // the orthonormal modal basis the nodal one is computed through
   std::vector<double> vinv;                // inverse Vandermonde matrix, row-major
 };
@@ -184,6 +185,7 @@ protected:
   void fill_opp_3(hf_array<double> &opp_3) override;
   double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
   void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
+  int set_shock_capture_operators() override; // src/eles_pris.cpp:609-730 (set_vandermonde3D, set_exp_filter, calc_norm_basis)
   struct Impl;
   Impl *impl;
 };

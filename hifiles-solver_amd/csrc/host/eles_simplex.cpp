@@ -418,11 +418,7 @@ int eles_tets::setup_ele_type_specific()
   ele_type = 2;
   n_dims = 3;
   if (run_input->equation != 0) { fail("Equation not supported"); return 1; }
-  if (run_input->shock_cap || run_input->over_int)
-  {
-    fail("eles_tets: shock capturing and over-integration are built for the tensor-product classes only");
-    return 1;
-  }
+  if (run_input->over_int) { fail("eles_tets: over-integration is built for the tensor-product classes only (no cubature tables of tetrahedra here)"); return 1; }
   if (run_input->vcjh_scheme_tet < 0 || run_input->vcjh_scheme_tet > 4) { fail("VCJH tetrahedral scheme not recognized"); return 1; } /* src/eles_tets.cpp:1389 */
   if (run_input->upts_type_tet != 0 || run_input->fpts_type_tet != 0) { fail("eles_tets: point rule not implemented (rule 0, internal, is)"); return 1; }
   n_fields = 5;
@@ -543,6 +539,66 @@ int eles_tets::compute_filter_upts()
     for (int j = 0; j < N; j++) filter_upts(i, j) /= norm;
     for (int j = 0; j < N; j++) filter_upts(N - i - 1, N - j - 1) = filter_upts(i, j);
   }
+  return 0;
+}
+
+// Shock capturing on a simplex class: from the modes (in the reference's numbering), their values at the solution points, the
+// filter strength and the norm of every mode and the set of highest modes -> vandermonde, inv_vandermonde,
+// exp_filter = V diag(sigma) V^-1, norm_basis_persson, persson_high_modes
+static int modal_shock_operators(eles *E, int n, const std::vector<double> &V, const std::vector<double> &sigma,
+                                 const std::vector<double> &norm, const std::vector<int> &high, std::string &err)
+{
+  std::vector<double> Vi = V;
+  if (!invert(Vi, n)) { err = "singular Vandermonde matrix"; return 1; }
+  E->vandermonde.setup(n, n);
+  E->inv_vandermonde.setup(n, n);
+  E->exp_filter.setup(n, n);
+  E->norm_basis_persson.setup(n);
+  E->persson_high_modes.setup(n);
+  for (int i = 0; i < n; i++)
+  {
+    E->norm_basis_persson(i) = norm[i];
+    E->persson_high_modes(i) = high[i];
+    for (int j = 0; j < n; j++)
+    {
+      E->vandermonde(i, j) = V[(size_t)i * n + j];
+      E->inv_vandermonde(i, j) = Vi[(size_t)i * n + j];
+      double t = 0.0;
+      for (int m = 0; m < n; m++) t += V[(size_t)i * n + m] * sigma[m] * Vi[(size_t)m * n + j];
+      E->exp_filter(i, j) = t;
+    }
+  }
+  return 0;
+}
+
+// the exponential filter's strength at the normalised degree eta (src/eles_tets.cpp:733-737, src/eles_pris.cpp:647-653)
+static double expf_sigma(const input *in, double eta, double eta_c)
+{
+  if (eta <= eta_c) return 1.0;
+  return std::exp(-in->expf_fac * std::pow((eta - eta_c) / (1. - eta_c), in->expf_order));
+}
+
+// src/eles_tets.cpp:705-797.  The modes in the order of the reference's Vandermonde matrix (by total degree, src/funcs.cpp:
+// 1461-1497); the basis is orthonormal, so every norm is one and the sensor's highest modes are those past the P(order-1) space.
+int eles_tets::set_shock_capture_operators()
+{
+  if (run_input->shock_cap != 1) { fail("Shock capturing method not implemented."); return 1; } /* src/eles_tets.cpp:79 */
+  const int n = n_upts_per_ele, p = order;
+  std::vector<double> V((size_t)n * n), sigma(n), norm(n, 1.0);
+  std::vector<int> high(n);
+  const double eta_c = (double)run_input->expf_cutoff / (double)p;
+  int m = 0;
+  for (int tot = 0; tot <= p; tot++)
+    for (int nn = 0; nn <= tot; nn++)
+      for (int k = 0; k <= nn; k++, m++)
+      {
+        const int j = nn - k, i = tot - j - k;
+        for (int u = 0; u < n; u++) V[(size_t)u * n + m] = simplex3d(loc_upts(0, u), loc_upts(1, u), loc_upts(2, u), i, j, k);
+        sigma[m] = expf_sigma(run_input, (double)tot / (double)p, eta_c);
+        high[m] = (m >= p * (p + 1) * (p + 2) / 6) ? 1 : 0;
+      }
+  std::string e;
+  if (modal_shock_operators(this, n, V, sigma, norm, high, e)) { fail("eles_tets: " + e); return 1; }
   return 0;
 }
 
@@ -705,11 +761,7 @@ int eles_pris::setup_ele_type_specific()
   ele_type = 3;
   n_dims = 3;
   if (run_input->equation != 0) { fail("Equation not supported"); return 1; }
-  if (run_input->shock_cap || run_input->over_int)
-  {
-    fail("eles_pris: shock capturing and over-integration are built for the tensor-product classes only");
-    return 1;
-  }
+  if (run_input->over_int) { fail("eles_pris: over-integration is built for the tensor-product classes only (no cubature tables of prisms here)"); return 1; }
   // the reference's prism class builds no LES filter (src/eles_pris.cpp:134, commented out): the closures that filter the
   // solution would multiply by an empty matrix there
   if (run_input->LES && run_input->SGS_model >= 2) { fail("eles_pris: the reference builds no LES filter for prisms (SGS_model 0 or 1 only)"); return 1; }
@@ -905,6 +957,36 @@ static inline void pri15(const hf_array<double> &loc, int idx, double &tri, doub
     tri = 4. * m[a] * m[b];
     for (int k = 0; k < 2; k++) dtri[k] = 4. * (m[a] * dm[b][k] + m[b] * dm[a][k]);
   }
+}
+
+// src/eles_pris.cpp:609-730.  The hierarchical prism basis: orthonormal triangle mode (i, j) times the Legendre polynomial P_k
+// along the line, numbered by i + j + k, then k, then j (src/eles_pris.cpp:1238-1283); norm 2 / (2k + 1); the filter damps the
+// triangle's and the line's degree separately; the sensor's highest modes have i + j == order or k == order.
+int eles_pris::set_shock_capture_operators()
+{
+  if (run_input->shock_cap != 1) { fail("Shock capturing method not implemented."); return 1; }
+  const int n = n_upts_per_ele, p = order;
+  std::vector<double> V((size_t)n * n), sigma(n), norm(n);
+  std::vector<int> high(n);
+  const double eta_c = (double)run_input->expf_cutoff / (double)p;
+  int m = 0;
+  for (int l = 0; l <= 2 * p; l++)
+    for (int k = 0; k <= l; k++)
+      for (int j = 0; j <= l - k; j++)
+      {
+        const int i = l - k - j;
+        if (k > p || i + j > p) continue;
+        for (int u = 0; u < n; u++)
+          V[(size_t)u * n + m] = simplex2d(loc_upts(0, u), loc_upts(1, u), i, j) * eval_legendre(loc_upts(2, u), k);
+        sigma[m] = expf_sigma(run_input, (double)(i + j) / (double)p, eta_c) * expf_sigma(run_input, (double)k / (double)p, eta_c);
+        norm[m] = 2.0 / (2.0 * k + 1.0);
+        high[m] = (i + j == p || k == p) ? 1 : 0;
+        m++;
+      }
+  if (m != n) { fail("eles_pris: mode count"); return 1; }
+  std::string e;
+  if (modal_shock_operators(this, n, V, sigma, norm, high, e)) { fail("eles_pris: " + e); return 1; }
+  return 0;
 }
 
 double eles_pris::eval_nodal_s_basis(int in_index, const hf_array<double> &loc, int in_n_spts)

@@ -347,18 +347,24 @@ class Simplex:
     """eles_tets (ele_type 2) / eles_pris (3) of the host mirror as producers of operators and metrics for the given
     elements: shape (3, n_spts, n_eles), n_spts 4 / 6 (straight-sided) or 10 / 15 (quadratic)."""
 
+    class Keys(C.Structure):
+        _fields_ = [("vcjh_scheme", C.c_int), ("c", C.c_double), ("SGS_model", C.c_int), ("filter_type", C.c_int),
+                    ("filter_ratio", C.c_double), ("shock_cap", C.c_int), ("expf_fac", C.c_double), ("expf_order", C.c_int),
+                    ("expf_cutoff", C.c_int)]
+
     def __init__(self, ele_type, order, shape, viscous=1, loc_1d_upts=None, vcjh_scheme=1, c=0.0, SGS_model=-1, filter_type=0,
-                 filter_ratio=1.0):
+                 filter_ratio=1.0, shock_cap=0, expf_fac=36.0, expf_order=4, expf_cutoff=0):
         """vcjh_scheme: vcjh_scheme_tet / vcjh_scheme_tri (0: c given, 1 DG, 2 SD-like, 3 Huynh-like, 4 c+); SGS_model >= 0: a
-        run with an LES closure (Jacobian_fpts, and filter_upts on tetrahedra for the closures that filter the solution)"""
+        run with an LES closure (Jacobian_fpts, and filter_upts on tetrahedra for the closures that filter the solution);
+        shock_cap 1: the shock-capturing operators (inv_vandermonde, exp_filter, norm_basis_persson, persson_high_modes)"""
         shp = np.asfortranarray(np.array(shape, dtype=np.float64))
         assert shp.shape[0] == 3 and shp.shape[1] in ((4, 10) if ele_type == 2 else (6, 15))
         x1 = None if loc_1d_upts is None else np.ascontiguousarray(np.array(loc_1d_upts, dtype=np.float64))
         self.h = C.c_void_p()
-        check(lib().hfxh_simplex_create_les(C.c_int(ele_type), C.c_int(order), C.c_int(viscous), C.c_int(shp.shape[2]),
-                                            C.c_int(shp.shape[1]), shp.ctypes.data_as(dp), None if x1 is None else x1.ctypes.data_as(dp),
-                                            C.c_int(vcjh_scheme), C.c_double(c), C.c_int(SGS_model), C.c_int(filter_type),
-                                            C.c_double(filter_ratio), C.byref(self.h)))
+        k = Simplex.Keys(vcjh_scheme, c, SGS_model, filter_type, filter_ratio, shock_cap, expf_fac, expf_order, expf_cutoff)
+        check(lib().hfxh_simplex_create_keys(C.c_int(ele_type), C.c_int(order), C.c_int(viscous), C.c_int(shp.shape[2]),
+                                             C.c_int(shp.shape[1]), shp.ctypes.data_as(dp), None if x1 is None else x1.ctypes.data_as(dp),
+                                             C.byref(k), C.byref(self.h)))
 
     def array(self, name):
         p = dp()

@@ -143,16 +143,30 @@ int hfxh_simplex_create(int ele_type, int order, int viscous, int n_eles, const 
  * src/funcs.cpp:717-795) */
 int hfxh_simplex_create_vcjh(int ele_type, int order, int viscous, int n_eles, const double *shape, const double *loc_1d_upts,
                              int vcjh_scheme, double c, hfxh_simplex **out);
-/* the same for a run with an LES closure (run_input.LES = 1; SGS_model < 0: none): set_transforms also fills Jacobian_fpts
- * (what hfx_eles_set_les takes), and for the closures that filter the solution (SGS_model 2, 3, 4) eles_tets builds
- * filter_upts (/root/reference/src/eles_tets.cpp:576-690: filter_type 2 modal, 3 element average; 0 and 1 stop as the reference
- * does).  The reference's prism class builds no filter (src/eles_pris.cpp:134): SGS_model >= 2 is refused there.
+/* the general form: the input keys the simplex classes read beyond order / viscous.
+ *  - vcjh_scheme, c: as above;
+ *  - SGS_model >= 0: a run with an LES closure (run_input.LES = 1; < 0: none): set_transforms also fills Jacobian_fpts (what
+ *    hfx_eles_set_les takes), and for the closures that filter the solution (SGS_model 2, 3, 4) eles_tets builds filter_upts
+ *    (/root/reference/src/eles_tets.cpp:576-690: filter_type 2 modal, 3 element average; 0 and 1 stop as the reference does).  The
+ *    reference's prism class builds no filter (src/eles_pris.cpp:134): SGS_model >= 2 is refused there;
+ *  - shock_cap 1: the operators of shock capturing (what hfx_eles_set_shock_capture takes): inv_vandermonde, exp_filter,
+ *    norm_basis_persson, persson_high_modes (read as doubles) -- src/eles_tets.cpp:705-797, src/eles_pris.cpp:609-730.
  * n_spts: shape nodes per element -- 0 for the straight-sided shapes, else 4 or 10 (the quadratic tetrahedron of
  * src/eles_tets.cpp:1047-1069, nodes 4-9 on the edges (0,1) (0,2) (0,3) (1,2) (2,3) (3,1)), 6 or 15 (the quadratic prism of
  * src/eles_pris.cpp:1115-1146); shape is then (3, n_spts, n_eles). */
-int hfxh_simplex_create_les(int ele_type, int order, int viscous, int n_eles, int n_spts, const double *shape,
-                            const double *loc_1d_upts, int vcjh_scheme, double c, int SGS_model, int filter_type,
-                            double filter_ratio, hfxh_simplex **out);
+typedef struct hfxh_simplex_keys
+{
+  int vcjh_scheme; /* vcjh_scheme_tet / vcjh_scheme_tri */
+  double c;        /* c_tet / c_tri (scheme 0) */
+  int SGS_model;   /* < 0: no LES */
+  int filter_type;
+  double filter_ratio;
+  int shock_cap;   /* 0 off, 1 exponential filter */
+  double expf_fac;
+  int expf_order, expf_cutoff;
+} hfxh_simplex_keys;
+int hfxh_simplex_create_keys(int ele_type, int order, int viscous, int n_eles, int n_spts, const double *shape,
+                             const double *loc_1d_upts, const hfxh_simplex_keys *keys, hfxh_simplex **out);
 int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const double **ptr, int dims[4]);
 int hfxh_simplex_destroy(hfxh_simplex *s);
 

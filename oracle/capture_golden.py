@@ -199,6 +199,17 @@ CASES = [
          expf_order=4, expf_cutoff=0, shock_det_field=1),
     case("quad_p3_shock", dims=2, n=4, amp=0.1, level=1, order=3, steps=1, shock_cap=1, shock_det=0, s0=1.8616e-7,
          expf_fac=36.0, expf_order=4, expf_cutoff=1, shock_det_field=0),
+    # the same two ingredients on the simplex classes (src/eles_tets.cpp:71-94,718-790,946; src/eles_pris.cpp); s0 inside the
+    # widest gap of the first stage's sensor values (14 % wide on the tetrahedra, 1.3e-4 on the prisms, whose values are close)
+    case("tet_p3_shock", n=2, amp=0.1, level=1, order=3, steps=2, tets=True, shock_cap=1, shock_det=0, s0=1.23e-7, expf_fac=36.0,
+         expf_order=4, expf_cutoff=1, shock_det_field=0, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("tet_p2_overint", n=2, amp=0.1, level=2, order=2, steps=1, tets=True, over_int=1, over_int_order=6,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p2_shock", n=2, amp=0.1, level=1, order=2, steps=2, tets="prisms", shock_cap=1, shock_det=0, s0=4.5661e-6, expf_fac=36.0,
+         expf_order=4, expf_cutoff=1, shock_det_field=0, upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0,
+         upts_type_tri=0, vcjh_scheme_tri=1, c_tri=0.0),
+    case("pri_p2_overint", n=2, amp=0.1, level=2, order=2, steps=1, tets="prisms", over_int=1, over_int_order=6,
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0, vcjh_scheme_tri=1, c_tri=0.0),
     # BASELINE.json configs[4] in small: P4 hexes, HLLC, shock capturing AND polynomial de-aliasing together, supersonic
     # in- and outflow, characteristic pressure outlets and slip walls around a box (the pieces of the supersonic-jet
     # case).  No "char" far field here: the Taylor-Green field has u.n = 0 on every side of the box, and that boundary

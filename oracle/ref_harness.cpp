@@ -388,19 +388,43 @@ int main(int argc, char *argv[])
   {
     put_arr("inv_vandermonde", E->inv_vandermonde);
     put_arr("exp_filter", E->exp_filter);
-    eles_hexas *EH = (n_dims == 3) ? &FlowSol.mesh_eles_hexas : NULL;
-    eles_quads *EQ = (n_dims == 2) ? &FlowSol.mesh_eles_quads : NULL;
+    // the class's own mode norms and highest modes (hexes / quads: a mode of degree `order` in any direction, src/eles_hexas.cpp:
+    // 1007-1059; prisms: degree `order` on the triangle or along the line, src/eles_pris.cpp:716-722; tetrahedra: the modes past
+    // the P(order-1) space of an orthonormal basis -- all norms one, src/eles_tets.cpp:748-797)
+    eles_hexas *EH = (etype == 4) ? &FlowSol.mesh_eles_hexas : NULL;
+    eles_quads *EQ = (etype == 1) ? &FlowSol.mesh_eles_quads : NULL;
+    eles_pris *EP = (etype == 3) ? &FlowSol.mesh_eles_pris : NULL;
     if (EH) put_arr("norm_basis_persson", EH->norm_basis_persson);
     if (EQ) put_arr("norm_basis_persson", EQ->norm_basis_persson);
+    if (EP) put_arr("norm_basis_persson", EP->norm_basis_persson);
+    if (etype == 2)
+    {
+      vector<double> ones(n_upts, 1.0);
+      put_d("norm_basis_persson", ones.data(), {n_upts});
+    }
+    if (etype == 0) { fprintf(stderr, "harness: shock capturing on triangles is not dumped\n"); return 1; }
     vector<int32_t> hi(n_upts);
     for (int j = 0; j < n_upts; j++)
     {
       int x = 0, y = 0, z = 0;
+      const int p = run_input.order;
       if (EH)
-        EH->get_legendre_basis_3D_index(j, run_input.order, x, y, z);
+      {
+        EH->get_legendre_basis_3D_index(j, p, x, y, z);
+        hi[j] = (x == p || y == p || z == p) ? 1 : 0;
+      }
+      else if (EQ)
+      {
+        EQ->get_legendre_basis_2D_index(j, p, x, y);
+        hi[j] = (x == p || y == p) ? 1 : 0;
+      }
+      else if (EP)
+      {
+        EP->get_pris_basis_index(j, p, x, y, z);
+        hi[j] = (x + y == p || z == p) ? 1 : 0;
+      }
       else
-        EQ->get_legendre_basis_2D_index(j, run_input.order, x, y);
-      hi[j] = (x == run_input.order || y == run_input.order || (n_dims == 3 && z == run_input.order)) ? 1 : 0;
+        hi[j] = (j >= p * (p + 1) * (p + 2) / 6) ? 1 : 0;
     }
     put_i("persson_high_modes", hi.data(), {n_upts});
     put_scalar("s0", run_input.s0);

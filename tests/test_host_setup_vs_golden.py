@@ -253,6 +253,29 @@ def test_simplex_vcjh_members_vs_reference(name, scheme, c):
     dg.close()
 
 
+@pytest.mark.parametrize("name", ["tet_p3_shock", "pri_p2_shock"])
+def test_simplex_shock_capture_operators_vs_reference(name):
+    """set_vandermonde / set_exp_filter / the Persson sensor's norms and highest modes of eles_tets (src/eles_tets.cpp:705-797) and
+    eles_pris (src/eles_pris.cpp:609-730) from the host mirror: exp_filter equals the reference's; inv_vandermonde equals it
+    row by row up to the sign of a mode (the sensor squares the modal coefficients, the filter is V diag V^-1)."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    k = json.loads(bytes(d["meta_json"]).decode())["keys"]
+    sz = [int(v) for v in d["sizes"]]
+    ele_type, order = sz[6], sz[5]
+    x1 = d["loc_upts"][2, ::(order + 1) * (order + 2) // 2] if ele_type == 3 else None
+    S = H.Simplex(ele_type, order, d["shape"], viscous=1, loc_1d_upts=x1, shock_cap=1, expf_fac=k["expf_fac"],
+                  expf_order=k["expf_order"], expf_cutoff=k["expf_cutoff"])
+    E, W = S.array("exp_filter"), d["exp_filter"]
+    assert np.abs(E - W).max() <= 1e-12 * np.abs(W).max()
+    Vi, Wi = S.array("inv_vandermonde"), d["inv_vandermonde"]
+    sign = np.sign((Vi * Wi).sum(axis=1))
+    assert (sign != 0).all()
+    assert np.abs(Vi * sign[:, None] - Wi).max() <= 1e-12 * np.abs(Wi).max()
+    assert np.abs(S.array("norm_basis_persson") - np.ravel(d["norm_basis_persson"])).max() <= 1e-15
+    assert (S.array("persson_high_modes").astype(int) == np.ravel(d["persson_high_modes"])).all()
+    S.close()
+
+
 def test_simplex_classes_refuse_what_they_do_not_build():
     d = dict(np.load(os.path.join(GOLDEN, "tet_p2_n2_deformed.npz")))
     with pytest.raises(Exception):

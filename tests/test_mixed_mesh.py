@@ -282,6 +282,54 @@ def test_simplex_les_from_the_host_mirrors_own_operators(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tet_p3_shock", "pri_p2_shock"])
+def test_simplex_shock_capturing_from_the_host_mirrors_own_operators(name):
+    """shock capturing on tetrahedra and prisms (src/eles.cpp:2918 with the class's sensor, src/eles_tets.cpp:748, src/eles_pris.cpp:
+    678): every operator and metric, the modal matrices, the filter and the sensor's mode set from the host mirror; the reference's
+    call sequence with shock_capture after every AdvanceSolution; sensor and states against the genuine reference"""
+    import hfx
+    import hfx_host as H
+    from test_gpu_methods_vs_golden import build
+    from test_gpu_deferred import calc_residual_calls, tag
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    k = json.loads(bytes(d["meta_json"]).decode())["keys"]
+    sz = [int(v) for v in d["sizes"]]
+    x1 = d["loc_upts"][2, ::(sz[5] + 1) * (sz[5] + 2) // 2] if sz[6] == 3 else None
+    S = H.Simplex(sz[6], sz[5], d["shape"], viscous=1, loc_1d_upts=x1, shock_cap=1, expf_fac=k["expf_fac"],
+                  expf_order=k["expf_order"], expf_cutoff=k["expf_cutoff"])
+    names = ["opp_0", "opp_3", "opp_6", "detjac_upts", "JGinv_upts", "detjac_fpts", "JGinv_fpts", "tdA_fpts", "norm_fpts",
+             "inv_vandermonde", "exp_filter"] + ["opp_%d_%d" % (w, dd) for w in (1, 2, 4, 5) for dd in range(3)]
+    for n in names:
+        a = S.array(n)
+        assert a.shape == d[n].shape, n
+        d[n] = a
+    d["norm_basis_persson"] = S.array("norm_basis_persson")
+    d["persson_high_modes"] = S.array("persson_high_modes").astype(np.int32)
+    S.close()
+    nstage = int(d["sizes"][7])
+    adv = int(np.ravel(d["adv_type"])[0])
+    steps = sorted({int(q.split("_")[1][4:]) for q in d if q.startswith("u_step")})
+    ctx = hfx.Context(0)
+    ctx.set_option("deferred", 1)
+    e, faces = build(ctx, d)
+    tag(e, d)
+    for st in steps:
+        for rk in range(nstage):
+            calc_residual_calls([e], faces, True, rk)
+            e.AdvanceSolution(rk, adv)
+            e.shock_capture()
+            if st == 0 and rk == 0:
+                assert relerr(e.download(hfx.SENSOR), np.ravel(d["s0_sensor"])) < 1e-10
+            key = "u_step%d_stage%d" % (st, rk)
+            if key in d:
+                assert relerr(e.download(hfx.DISU_UPTS0), d[key]) < 1e-11, key
+    for f in faces:
+        f.close()
+    e.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_general_fused_stage_at_bench_size_properties():
     """BASELINE.json configs[3] at the size bench.py --workload mixed runs (the reference's mixed channel tiled; here 512
     tiles, every tile with its OWN state: the conserved variables scaled by a tile-dependent factor, which keeps the
