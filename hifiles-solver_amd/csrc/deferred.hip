@@ -216,7 +216,8 @@ static void make_plan(hfx_ctx *ctx, const std::vector<DeferCall> &log, DeferPlan
     P.kind = mpi ? 2 : 1;
     return;
   }
-  if (P.sgs_terms || P.shock) { P.why = "general fused stage: LES and shock capturing run per method"; return; }
+  if (P.sgs_terms) { P.why = "general fused stage: LES runs per method"; return; }
+  if (P.shock && mpi) { P.why = "general fused stage on partitioned blocks: shock capturing runs per method (the flux-point values have left for the neighbours)"; return; }
   {
     std::vector<hfx_inters *> all = P.faces;
     all.insert(all.end(), P.mpi_faces.begin(), P.mpi_faces.end());
@@ -300,6 +301,7 @@ static int run_fused(hfx_ctx *ctx, const DeferPlan &P, int in_step, bool write_d
     break;
   case 3:
     if (general_deferred_stage(P.eles.data(), (int)P.eles.size(), faces, nfb, in_step, write_div)) return 1;
+    if (P.shock && general_shock_capture(P.eles.data(), (int)P.eles.size())) return 1;
     break;
   case 4:
     if (general_partitioned_stage(P.eles.data(), (int)P.eles.size(), faces, nfb, P.mpi_faces.data(), (int)P.mpi_faces.size(), P.comm, in_step, start))

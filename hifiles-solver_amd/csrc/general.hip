@@ -904,7 +904,8 @@ static size_t update_lds_bytes(const GeneralData *g) { return sizeof(double) * G
 static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_eles *const *eles, int neb)
 {
   HFX_CHECK(e->n_dims == 3 && e->n_fields == 5, "general fused stage: three-dimensional Navier-Stokes / Euler blocks only");
-  HFX_CHECK(!e->les_ready && !e->over_int_ready && !e->shock_ready, "general fused stage: LES, over-integration and shock capturing run per method");
+  // (shock capturing follows the stage as its own step: general_shock_capture)
+  HFX_CHECK(!e->les_ready && !e->over_int_ready, "general fused stage: LES and over-integration run per method");
   const bool visc = e->ctx->params.viscous != 0;
   HFX_CHECK(!visc || e->viscous_ops, "general fused stage: viscous run but the block has no opp_4/5/6");
   if (!e->general) e->general = new GeneralData();
@@ -1291,6 +1292,19 @@ int general_deferred_stage(hfx_eles *const *eles, int neb, hfx_inters *const *fa
   return general_stage(eles, neb, faces, nfb, in_step, write_div, 0);
 }
 
+// eles::shock_capture behind a general fused stage (src/HiFiLES.cpp:214-216): the modal filter changes the state of the elements
+// the sensor marks, so the flux-point values the update kernel left for the next stage are extrapolated again
+int general_shock_capture(hfx_eles *const *eles, int neb)
+{
+  for (int i = 0; i < neb; i++)
+    if (eles[i]->shock_ready)
+    {
+      if (hfx_eles_shock_capture(eles[i])) return 1;
+      if (hfx_eles_extrapolate_solution(eles[i])) return 1;
+    }
+  return 0;
+}
+
 int general_run_steps(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int n_steps)
 {
   if (general_prepare(eles, neb, faces, nfb)) return 1;
@@ -1314,7 +1328,10 @@ int general_run_steps(hfx_eles *const *eles, int neb, hfx_inters *const *faces, 
       ctx->params.dt = dt_min;
     }
     for (int rk = 0; rk < nst; rk++)
+    {
       if (general_stage(eles, neb, faces, nfb, rk, rk == nst - 1, 0)) return 1;
+      if (general_shock_capture(eles, neb)) return 1;
+    }
     advance_ramp_counters(faces, nfb); /* src/HiFiLES.cpp:224-225 */
   }
   return 0;

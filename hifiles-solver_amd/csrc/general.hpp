@@ -8,7 +8,7 @@ namespace hfx
 void general_invalidate(hfx_eles *e);
 void general_destroy(hfx_eles *e);
 // n_steps time steps over several element blocks (a mixed mesh) and the face blocks between them; fails loudly when a
-// block does not qualify (2-D, LES, over-integration, shock capturing, partition faces)
+// block does not qualify (2-D, LES, over-integration); shock capturing follows every stage (general_shock_capture)
 int general_run_steps(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int n_steps);
 // average duration (ms, HIP events on the context stream) of the stage's four parts over `reps` stages: face_delta,
 // flux kernels (all blocks), face_flux, update kernels (all blocks)
@@ -22,4 +22,6 @@ int general_deferred_prepare(hfx_eles *const *eles, int neb, hfx_inters *const *
 int general_stage_part(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool write_div, int which);
 const double *general_fn_fpts(const hfx_eles *e);
 int general_deferred_stage(hfx_eles *const *eles, int neb, hfx_inters *const *faces, int nfb, int in_step, bool write_div);
+// eles::shock_capture of the blocks that registered it, and the flux-point values of the filtered state
+int general_shock_capture(hfx_eles *const *eles, int neb);
 } // namespace hfx
