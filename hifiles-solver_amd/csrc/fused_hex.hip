@@ -361,6 +361,7 @@ static int tensor_build(hfx_eles *e, FusedData *F, int N, const std::vector<doub
   if (F->t_coef) { (void)hipFree(F->t_coef); F->t_coef = nullptr; }
   if (F->t_idx) { (void)hipFree(F->t_idx); F->t_idx = nullptr; }
   if (upload((void **)&F->t_coef, coef.data(), sizeof(double) * coef.size())) return 1;
+  F->h_coef = coef;
   if (upload((void **)&F->t_idx, idx.data(), sizeof(int) * idx.size())) return 1;
   F->tensor_ok = true;
   return 0;
@@ -682,9 +683,12 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   }
   // Will the flux kernel form the LDG corrections of the interior points itself?  (the loader-wave form of the sum-factorised
   // kernel only: same conditions as its selection below)
+  // (with over-integration the loader-wave form is taken when the over-integration kernel can hand over its folded result)
+  const bool oi_fold_ok = !e->over_int_ready ||
+                          (opt.over_int_fold && tensor_over_int_available(e) && e->ctx->contract_mode != HFX_CONTRACT_DENSE);
   bool gather = false;
   if (variant == 3 && P.viscous && opt.gather_delta && F->nbr && F->tensor_ok && !opt.dictionary_rows && opt.loader_wave &&
-      opt.buffer_addressing && opt.flux_waves == 2 && loader_wave_fits<ND, N>())
+      opt.buffer_addressing && opt.flux_waves == 2 && loader_wave_fits<ND, N>() && oi_fold_ok)
   {
     bool any_bdy = false;
     for (int b = 0; b < nfb; b++) any_bdy = any_bdy || faces[b]->is_bdy;
@@ -720,7 +724,33 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
   // (variant 2 with an LES closure) alone, 8 = part 2 without them
   if (variant == 3)
   {
-    if (which == 5 && e->over_int_ready && hfx_eles_evaluate_invFlux_over_int(e)) return 1;
+    // Over-integration (src/solver.cpp:82-91).  With the loader-wave flux kernel the sum-factorised kernel hands over
+    // sum_l Dc[l] tdisf_l -- the de-aliased flux's whole contribution to (div_tdisf - opp_3 norm_tdisf), n_fields values per
+    // solution point (tensor_ops.hip) -- which that kernel adds to its divergence; otherwise tdisf_upts itself.
+    const bool lw_form = loader_wave_fits<ND, N>() && opt.loader_wave && opt.flux_waves == 2 && opt.buffer_addressing &&
+                         F->tensor_ok && !opt.dictionary_rows;
+    const bool oi_fold = e->over_int_ready && lw_form && oi_fold_ok;
+    auto run_over_int = [&]() -> int {
+      if (!oi_fold) return hfx_eles_evaluate_invFlux_over_int(e);
+      if (!tensor_over_int_folded(e))
+      {
+        // Dc[d] = D - c3[d][0] (L1 Lf)[d][0]^T - c3[d][1] (L1 Lf)[d][1]^T, as the flux kernel's prologue forms it (split3_kernels.hpp)
+        using T = TGeo<ND, N>;
+        const std::vector<double> &c = F->h_coef;
+        std::vector<double> Dc((size_t)ND * N * N);
+        for (int d = 0; d < ND; d++)
+          for (int mp = 0; mp < N; mp++)
+            for (int m = 0; m < N; m++)
+            {
+              const double ta = c[T::C_3 + (d * 2 + 0) * N + mp] * (c[T::C_L1 + (d * 2 + 0) * N] * c[T::C_LF + (d * 2 + 0) * N + m]);
+              const double tb = c[T::C_3 + (d * 2 + 1) * N + mp] * (c[T::C_L1 + (d * 2 + 1) * N] * c[T::C_LF + (d * 2 + 1) * N + m]);
+              Dc[((size_t)d * N + mp) * N + m] = c[T::C_D + mp * N + m] - ta - tb;
+            }
+        if (tensor_over_int_set_fold(e, Dc.data())) return 1;
+      }
+      return tensor_over_int_launch(e, true);
+    };
+    if (which == 5 && e->over_int_ready && run_over_int()) return 1;
     // 21 / 22 / 23: the flux kernel on a part of the elements (partitioned blocks, hfx_run_steps_partitioned): the first half of
     // the elements without partition-face points, those with, the second half -- the solution exchange runs beside the
     // first launch, the exchange of the projected fluxes beside the third
@@ -738,7 +768,7 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
       if (e->over_int_ready)
       {
         // polynomial de-aliasing (src/solver.cpp:82-91): tdisf_upts = over_int_filter . F(opp_over_int_cubpts . u)
-        if (which != 7 && hfx_eles_evaluate_invFlux_over_int(e)) return 1;
+        if (which != 7 && run_over_int()) return 1;
         e2.tdisf_in = e->arr[HFX_TDISF_UPTS];
       }
       const bool dict_only = opt.dictionary_rows != 0;
@@ -760,7 +790,9 @@ static int launch_split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, Sp
                      e2, F->t_coef, F->t_idx)
       const bool no_lw = !opt.loader_wave;
       constexpr bool lw_fits = loader_wave_fits<ND, N>();
-      const bool lw = lw_fits && buf && !no_lw && waves == 2;
+      // (a block whose de-aliased flux arrives whole -- dense over-integration -- takes the form without the loader wave)
+      const bool lw = lw_fits && buf && !no_lw && waves == 2 && (!oi || oi_fold);
+      HFX_CHECK(!oi_fold || (lw && F->tensor_ok && !dict_only), "over-integration: the folded form needs the loader-wave flux kernel");
       bool launched = false;
       // a closure with an SGS flux (every model but the spectral vanishing viscosity, which only filters the state)
       const bool les = e->les_ready && e->les.sgs_model != 3;

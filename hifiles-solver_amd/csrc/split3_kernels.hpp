@@ -44,7 +44,8 @@ struct Split2Args
   double *disu_next;
   double *grad_upts, *grad_fpts; // optional outputs (NULL: not written)
   int xcd_order;                 // EleOrder: contiguous element ranges per XCD
-  const double *tdisf_in;        // over-integration: the transformed inviscid flux, already evaluated (NULL: computed here)
+  const double *tdisf_in;        // over-integration: the transformed inviscid flux, already evaluated (NULL: computed here); the loader-wave
+                                 // form takes the over-integration kernel's FOLDED result there instead: sum_l Dc[l] tdisf_l, (n_upts, n_eles, n_fields)
   const unsigned char *meta;     // with grad_fpts: only flux points whose bit2 is set are written (NULL: all)
   int simd_roles;    // 1: the waves' parts are dealt by SIMD (split_flux_tensor_kernel)
   int light_short;   // 1: a wave without solution points runs the flux-point physics alone instead of the paired form on dummies
@@ -904,9 +905,10 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       lds_barrier(); // 1b
       stamp(13);
     }
-    // over-integration: the de-aliased inviscid flux of this point is requested here, a phase ahead of its use
-    double td[OI ? NG : 1];
-    if (OI && is_u)
+    // over-integration: the de-aliased inviscid flux of this point is requested here, a phase ahead of its use (the loader-wave
+    // form takes its folded contribution to the divergence instead, requested at the top of phase C)
+    double td[(OI && !LW) ? NG : 1];
+    if (OI && !LW && is_u)
     {
 #pragma unroll
       for (int q = 0; q < NG; q++) td[q] = g_td.ld(eu + q * plane_u, lu);
@@ -1016,16 +1018,6 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         for (int k = 0; k < NF; k++) x[k] = ldsv(&su[k * NUS + am[m]]);
 #pragma unroll
         for (int k = 0; k < NF; k++) uf[k] += Lrow[m] * x[k];
-      }
-    }
-    if constexpr (OI && LW)
-    {
-      // the de-aliased flux requested at the top of this phase waits in this thread's own column of the (still unused) flux
-      // region instead of in 15 registers across the point physics of phase B
-      if (is_u)
-      {
-#pragma unroll
-        for (int q = 0; q < NG; q++) st[q * NU + tu] = td[q];
       }
     }
     stamp(3);
@@ -1190,7 +1182,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 #pragma unroll
           for (int l = 0; l < ND; l++)
           {
-            double s = OI ? ldsv(&st[(k + NF * l) * NU + tu]) : 0.0; // (OI: parked there at the end of phase A)
+            double s = 0.0;
 #pragma unroll
             for (int m = 0; m < ND; m++) s += jg2[0][l + ND * m] * ft[k + NF * m];
             if constexpr (LES) s += tsg[k + NF * l];
@@ -1263,9 +1255,10 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
       // the transformed flux is accumulated in this thread's own st column (LDS) instead of 15 registers
       if (OI)
       {
-        // over-integration: the de-aliased inviscid flux was evaluated at the cubature points and projected back
+        // over-integration: the de-aliased inviscid flux was evaluated at the cubature points and projected back (loader-wave
+        // form: its contribution joins the divergence in phase D)
 #pragma unroll
-        for (int q = 0; q < NG; q++) st[q * NU + tu] = td[q];
+        for (int q = 0; q < NG; q++) st[q * NU + tu] = LW ? 0.0 : td[q];
       }
       else
       {
@@ -1359,6 +1352,17 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- C: next element's inputs on their way; divergence parts pencil-wise, normal flux at the flux points
+    // (over-integration, loader-wave form: the de-aliased flux's folded contribution sum_l Dc[l] tdisf_l of this solution point
+    // is requested here and joins the sum of phase D)
+    double oi_res[(OI && LW) ? NF : 1];
+    if constexpr (OI && LW)
+    {
+      if (is_u)
+      {
+#pragma unroll
+        for (int k = 0; k < NF; k++) oi_res[k] = g_td.ld(eu + k * plane_u, lu);
+      }
+    }
     if (e_next >= 0)
     {
       if (!LW)
@@ -1450,6 +1454,7 @@ __global__ __launch_bounds__((SGeo<ND, N>::TB + (LW ? 64 : 0)), WV) void split_f
         double s = part[0][k];
         s += part[1][k];
         if (ND == 3) s += part[ND - 1][k];
+        if constexpr (OI && LW) s += oi_res[k];
         g_div.st(eu + k * plane_u, lu, s);
       }
     }

@@ -2,6 +2,8 @@
 // (device code of the split fused stage; included by fused_hex.hip only -- one translation unit, so that every kernel is
 // instantiated once)
 #pragma once
+#include <vector>
+
 #include "fused_hex.hpp"
 #include "physics.hpp"
 
@@ -23,7 +25,8 @@ struct FusedData
   // tensor-product tables of the sum-factorised flux kernel (valid when tensor_ok)
   long long *stamps = nullptr; // diagnostics buffer (HFX_FLUX_STAMPS=1)
   bool tensor_ok = false;
-  double *t_coef = nullptr; // Dm[N][N] | c5[ND][2][N] | Lf[ND][2][N] | L1[ND][2][N]
+  double *t_coef = nullptr; // Dm[N][N] | c5[ND][2][N] | Lf[ND][2][N] | L1[ND][2][N] | c3[ND][2][N]
+  std::vector<double> h_coef; // host copy
   int *t_idx = nullptr;     // pf[ND][L][2] | fdq[NFP] | fbase[NFP]
   unsigned *pk_g = nullptr, *pk_r = nullptr; // packed operator rows of the gradient / residual kernel
   double *tab_g = nullptr, *tab_r = nullptr; // value tables (MAX_TAB doubles)

@@ -120,6 +120,9 @@ struct TensorOps
   bool over_int = false;
   int N = 0, Nc = 0;
   double *I1 = nullptr, *F1 = nullptr; // device: (Nc x N) interpolation, (N x Nc) projection
+  std::vector<double> hF1;             // host copy of F1
+  double *F1f = nullptr;               // device: n_dims matrices (N x Nc): the projection followed by a 1-D operator of the caller
+  bool folded = false;
   // shock capturing
   bool shock = false;
   double *W1 = nullptr, *E1 = nullptr;         // device: (N x N) modal transform, (N x N) filter
@@ -136,7 +139,7 @@ void tensor_ops_destroy(hfx_eles *e)
 {
   TensorOps *T = (TensorOps *)e->tensor_ops;
   if (!T) return;
-  for (double **p : {&T->I1, &T->F1, &T->W1, &T->E1, &T->wnum, &T->wden}) free_dev(*p);
+  for (double **p : {&T->I1, &T->F1, &T->F1f, &T->W1, &T->E1, &T->wnum, &T->wden}) free_dev(*p);
   delete T;
   e->tensor_ops = nullptr;
 }
@@ -181,11 +184,38 @@ int tensor_over_int_setup(hfx_eles *e, int n_cubpts, const double *opp_cub, cons
   if (!kron_factor(opp_cub, e->n_dims, Nc, N, I1, KRON_TOL)) return 0;
   if (!kron_factor(filter, e->n_dims, N, Nc, F1, KRON_TOL)) return 0;
   if (upload_d(&T->I1, I1) || upload_d(&T->F1, F1)) return 1;
+  T->hF1 = F1;
+  T->folded = false;
   T->N = N;
   T->Nc = Nc;
   T->over_int = true;
   return 0;
 }
+
+// The fused stage consumes the de-aliased flux through ONE linear map per direction, res = sum_l A_l tdisf_l with
+// A_l = opp_2[l] - opp_3 opp_1[l] (divergence minus the folded correction, fused_hex.hip), which on a tensor-product element acts
+// along direction l only: a 1-D matrix Dc[l] (N x N, row-major, the caller's).  Composed with the projection,
+// res = sum_l (F1 (x) .. Dc[l] F1 .. (x) F1) t_l: the SAME passes with another matrix in direction l, and the kernel writes
+// n_fields values per solution point instead of n_fields * n_dims.
+int tensor_over_int_set_fold(hfx_eles *e, const double *Dc)
+{
+  TensorOps *T = (TensorOps *)e->tensor_ops;
+  HFX_CHECK(T && T->over_int, "over-integration: no tensor factors");
+  const int N = T->N, Nc = T->Nc, nd = e->n_dims;
+  std::vector<double> M((size_t)nd * N * Nc, 0.0);
+  for (int d = 0; d < nd; d++)
+    for (int c = 0; c < Nc; c++)
+      for (int mp = 0; mp < N; mp++)
+      {
+        double s = 0.0;
+        for (int m = 0; m < N; m++) s += Dc[((size_t)d * N + mp) * N + m] * T->hF1[m + (size_t)N * c];
+        M[(size_t)d * N * Nc + mp + (size_t)N * c] = s;
+      }
+  if (upload_d(&T->F1f, M)) return 1;
+  T->folded = true;
+  return 0;
+}
+bool tensor_over_int_folded(const hfx_eles *e) { return tensor_over_int_available(e) && ((TensorOps *)e->tensor_ops)->folded; }
 
 int tensor_shock_setup(hfx_eles *e, const double *inv_vandermonde, const double *exp_filter, const double *norm_basis,
                        const int *high_modes)
@@ -288,13 +318,41 @@ struct OverIntArgs
   const double *u, *JGc, *I1, *F1;
   double *tdisf;
   double gamma;
+  const double *F1f; // FOLD: n_dims matrices (N x NC), the projection followed by the caller's 1-D operator of that direction
 };
+
+// the projection passes of flux direction `l` with the folded matrix in direction l
+template <int ND, int N, int NC, typename MT>
+__device__ __forceinline__ double *tproject_fold(double *a, double *b, const MT &F, const MT &Ff, int nf, int l)
+{
+  double *src = a, *dst = b;
+  int P = 1;
+#pragma unroll
+  for (int d = 0; d < ND; d++)
+  {
+    int rest = nf;
+#pragma unroll
+    for (int q = d + 1; q < ND; q++) rest *= NC;
+    if (d == l)
+      tpass<N, NC>(src, dst, Ff, P, P * rest);
+    else
+      tpass<N, NC>(src, dst, F, P, P * rest);
+    lds_sync();
+    P *= N;
+    double *t = src;
+    src = dst;
+    dst = t;
+  }
+  return src;
+}
 
 // threads of the over-integration workgroup (7^3 = 343 points on 6 waves, one point per thread, took 98 registers instead
 // of 150 and 20.7 k cycles per element instead of 23.5 k, but with three 6-wave workgroups per CU the stage was not faster)
+// (round 3, with the folded form: 384 threads 0.56 ms against 0.466; 256 threads compiled for four waves per SIMD -- 128 registers,
+// 40 of them spilled -- 0.61 ms)
 constexpr int oi_threads(int) { return 256; }
 
-template <int ND, int N, int NC>
+template <int ND, int N, int NC, bool FOLD = false>
 __global__ __launch_bounds__(oi_threads(cpow(NC, ND))) void overint_tensor_kernel(const OverIntArgs a)
 {
   constexpr int NF = ND + 2, NQ = ND * ND, nu = cpow(N, ND), nc = cpow(NC, ND);
@@ -373,6 +431,12 @@ __global__ __launch_bounds__(oi_threads(cpow(NC, ND))) void overint_tensor_kerne
       }
     }
     if (e + gridDim.x < a.n_eles) fetch_jg(e + gridDim.x);
+    double racc[FOLD ? UPT : 1];
+    if constexpr (FOLD)
+    {
+#pragma unroll
+      for (int i = 0; i < UPT; i++) racc[i] = 0.0;
+    }
 #pragma unroll
     for (int l = 0; l < ND; l++)
     {
@@ -387,6 +451,20 @@ __global__ __launch_bounds__(oi_threads(cpow(NC, ND))) void overint_tensor_kerne
         }
       }
       lds_sync();
+      if constexpr (FOLD)
+      {
+        // projection followed by the caller's operator along l; the directions' results are summed in registers (l ascending)
+        const tcptr cFf = (tcptr)(uintptr_t)(a.F1f + (size_t)l * N * NC);
+        double *res = tproject_fold<ND, N, NC>(fa, fb, cF, cFf, NF, l);
+#pragma unroll
+        for (int i = 0; i < UPT; i++)
+        {
+          const int q = threadIdx.x + THR * i;
+          if (q < NF * nu) racc[i] += res[q];
+        }
+        lds_sync();
+        continue;
+      }
       // projection back on the solution points (over_int_filter . t)
       double *res = tapply<ND, N, NC>(fa, fb, cF, NF);
       for (int q = threadIdx.x; q < NF * nu; q += blockDim.x)
@@ -396,23 +474,42 @@ __global__ __launch_bounds__(oi_threads(cpow(NC, ND))) void overint_tensor_kerne
       }
       lds_sync();
     }
+    if constexpr (FOLD)
+    {
+#pragma unroll
+      for (int i = 0; i < UPT; i++)
+      {
+        const int q = threadIdx.x + THR * i;
+        if (q < NF * nu)
+        {
+          const int k = q / nu, pt = q - k * nu;
+          a.tdisf[pt + (long)nu * e + k * plane_u] = racc[i];
+        }
+      }
+    }
   }
 }
 
 constexpr int TMAX = 10; // largest 1-D extent instantiated
 
-template <int ND, int N, int NC>
-static int oi_launch_one(hfx_eles *e, const OverIntArgs &a, size_t lds, int grid)
+template <int ND, int N, int NC, bool FOLD>
+static int oi_launch_form(hfx_eles *e, const OverIntArgs &a, size_t lds, int grid)
 {
-  HFX_HIP(hipFuncSetAttribute((const void *)overint_tensor_kernel<ND, N, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HFX_HIP(hipFuncSetAttribute((const void *)overint_tensor_kernel<ND, N, NC, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // persistent grid: exactly the workgroups that are resident at once (registers and LDS decide), so that no workgroup
   // waits for a slot while the others are half way through their elements
   int per_cu = 0;
-  HFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, overint_tensor_kernel<ND, N, NC>, oi_threads(cpow(NC, ND)), lds));
+  HFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, overint_tensor_kernel<ND, N, NC, FOLD>, oi_threads(cpow(NC, ND)), lds));
   grid = (int)std::min<long>(e->n_eles, (long)e->ctx->n_cu * std::max(per_cu, 1));
-  hipLaunchKernelGGL((overint_tensor_kernel<ND, N, NC>), dim3(grid), dim3(oi_threads(cpow(NC, ND))), lds, e->ctx->stream, a);
+  hipLaunchKernelGGL((overint_tensor_kernel<ND, N, NC, FOLD>), dim3(grid), dim3(oi_threads(cpow(NC, ND))), lds, e->ctx->stream, a);
   HFX_HIP(hipGetLastError());
   return 0;
+}
+
+template <int ND, int N, int NC>
+static int oi_launch_one(hfx_eles *e, const OverIntArgs &a, size_t lds, int grid)
+{
+  return a.F1f ? oi_launch_form<ND, N, NC, true>(e, a, lds, grid) : oi_launch_form<ND, N, NC, false>(e, a, lds, grid);
 }
 
 template <int ND, int N, int NC>
@@ -441,13 +538,16 @@ static int oi_pick_n(hfx_eles *e, const OverIntArgs &a, size_t lds, int grid, in
   }
 }
 
-int tensor_over_int_launch(hfx_eles *e)
+int tensor_over_int_launch(hfx_eles *e, bool folded)
 {
   TensorOps *T = (TensorOps *)e->tensor_ops;
   HFX_CHECK(T && T->over_int, "over-integration: no tensor factors");
+  HFX_CHECK(!folded || T->folded, "over-integration: the folded form was not set up");
   OverIntArgs a{};
   a.n_eles = e->n_eles;
   a.u = e->arr[HFX_DISU_UPTS0]; a.JGc = e->JGinv_over_int_cubpts; a.I1 = T->I1; a.F1 = T->F1;
+  a.F1f = folded ? T->F1f : nullptr;
+  // (folded: n_fields values per solution point, in the first n_fields planes of tdisf_upts)
   a.tdisf = e->arr[HFX_TDISF_UPTS];
   a.gamma = e->ctx->params.gamma;
   // two regions of n_fields * Nc^nd doubles and the projection's intermediate, n_fields * N * Nc^(nd-1)

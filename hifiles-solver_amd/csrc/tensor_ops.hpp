@@ -15,7 +15,12 @@ int tensor_shock_setup(hfx_eles *e, const double *inv_vandermonde, const double 
                        const int *high_modes);
 bool tensor_over_int_available(const hfx_eles *e);
 bool tensor_shock_available(const hfx_eles *e);
-int tensor_over_int_launch(hfx_eles *e); // disu_upts(0) -> tdisf_upts (the de-aliased transformed inviscid flux)
+// disu_upts(0) -> tdisf_upts (the de-aliased transformed inviscid flux); folded: -> sum_l Dc[l]-along-l of it, n_fields values
+// per solution point in the first n_fields planes of tdisf_upts (tensor_over_int_set_fold gave the 1-D operators Dc[l], N x N
+// row-major each -- the fused stage's divergence-minus-correction matrices)
+int tensor_over_int_launch(hfx_eles *e, bool folded = false);
+int tensor_over_int_set_fold(hfx_eles *e, const double *Dc);
+bool tensor_over_int_folded(const hfx_eles *e);
 // sensor, and the filtered state where sensor >= s0; refresh_disu_fpts: also the flux-point solution of those elements
 int tensor_shock_launch(hfx_eles *e, bool refresh_disu_fpts = false);
 void tensor_ops_destroy(hfx_eles *e);

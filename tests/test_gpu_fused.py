@@ -180,6 +180,35 @@ def test_fused_full_size_conservation(mode):
     c.close(); m.close()
 
 
+@pytest.mark.parametrize("dims,order,viscous", [(3, 4, 1), (3, 2, 1), (2, 3, 1), (2, 3, 0)])
+def test_over_integration_folded_into_the_divergence(dims, order, viscous):
+    """The sum-factorised over-integration kernel hands the loader-wave flux kernel sum_l Dc[l] tdisf_l (the de-aliased flux's
+    contribution to div_tdisf - opp_3 norm_tdisf, n_fields values per point) instead of tdisf_upts (option over_int_fold, default
+    1): the same state as with the whole flux handed over, and as the per-method path, to rounding (a re-association)."""
+    n = [4] * dims + [1] * (3 - dims)
+    kw = dict(dims=dims, order=order, amp=0.1, viscous=viscous, over_int=1, over_int_order=order + 2)
+    if not viscous:  # the isentropic vortex of BASELINE.json configs[0] (Euler, Rusanov)
+        n = [6, 6, 1]
+        kw.update(ic_form=0, riemann_solve_type=0, dt=0.001, rho_c_ic=1.0, u_c_ic=1.0, v_c_ic=1.0, p_c_ic=1.0)
+    got = {}
+    for fold in (1, 0, None):
+        c = H.Case(n, **kw)
+        if fold is None:
+            c.set_deferred(False)
+        c.to_device(0)
+        if fold is None:
+            c.run(2)
+        else:
+            hfx.Context.set_option(_Ctx(c.handles()[0]), "over_int_fold", fold)
+            c.run_steps_lib(2, fused=3)
+        c.sync_host()
+        got[fold] = c.array("disu_upts0").copy()
+        c.close()
+    assert relerr(got[1], got[0]) < 1e-12
+    assert relerr(got[1], got[None]) < 1e-12
+    assert np.isfinite(got[1]).all()
+
+
 def test_config5_ingredients_full_size_properties():
     """BASELINE.json configs[4]'s ingredients at bench size (tools/bench_config5.sh, the `config5_overint_shock` leg of bench.py):
     32^3 P4 hexes with over-integration (7 cubature points per direction) and shock capturing after every stage.  The split
