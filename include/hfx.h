@@ -126,7 +126,8 @@ int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
  * "split_flux" (1: hfx_run_steps_partitioned runs the flux kernel in three launches -- half of the elements without partition-face points,
  * those with, the other half -- so that both exchanges run beside element work), "split_update" (1: hfx_run_steps_partitioned updates the elements with partition-face points in a first launch, so that their exchange
  * runs beside the update of the others), "light_wave_short" (1: a flux-kernel wave without solution points runs the flux-point physics alone), "les_flux_kernel" (1: the LES
- * closure inside the flux kernel of variant 3), "bdy_beside" (0; 1: the fused stages' viscous boundary-face kernels on a side stream
+ * closure inside the flux kernel of variant 3), "over_int_fold" (1: the sum-factorised over-integration kernel hands the loader-wave flux kernel its
+ * contribution to the divergence, n_fields values per solution point, instead of tdisf_upts), "bdy_beside" (0; 1: the fused stages' viscous boundary-face kernels on a side stream
  * beside the interior-face kernel), "general_waves" (0 = by LDS image | 3 | 4 | 8), "dense_waves" (0 = by the operator's rows | 4 | 8) and "dense_split" (0 | 1 | 2 | 4:
  * shape of the dense MFMA contraction's workgroup) -- see hfx_ctx::Options in csrc/hfx_internal.hpp; and "deferred" (0), which is
  * not a measurement knob: see below;
