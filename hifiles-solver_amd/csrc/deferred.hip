@@ -216,7 +216,7 @@ static void make_plan(hfx_ctx *ctx, const std::vector<DeferCall> &log, DeferPlan
     P.kind = mpi ? 2 : 1;
     return;
   }
-  if (P.sgs_terms) { P.why = "general fused stage: LES runs per method"; return; }
+
   if (P.shock && mpi) { P.why = "general fused stage on partitioned blocks: shock capturing runs per method (the flux-point values have left for the neighbours)"; return; }
   {
     std::vector<hfx_inters *> all = P.faces;

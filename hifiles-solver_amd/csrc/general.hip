@@ -120,6 +120,10 @@ struct GenArgs
   int adv_type, in_step, dt_local_on, write_div, need_u1;
   double dt, rk_a, rk_b;
   long long *stamps; // diagnostics (option flux_stamps): cycle counter of every wave of ONE workgroup at the phase boundaries
+  // LES closure evaluated in the flux kernel (LESG form): parameters (with the Leonard terms of the similarity models), the wall
+  // distance of the Smagorinsky damping, and tdA at the flux points (F_sgs . n = (F~_sgs . n~) / tdA)
+  LesParams les;
+  const double *wall_distance, *tdA_fpts;
 };
 
 // NA output tiles at once, sharing the operator fragments: acc[j] += op[rt*16 + (0..15)][0 .. 4 ksteps) . plane_j[k][16 elements],
@@ -196,9 +200,18 @@ __device__ __forceinline__ void split_rounds(int n, int wave, F &&item)
 // ---------------------------------------------------------------------------------------------------------------
 // NUc, NFPc: the element class's point counts as compile-time constants (0: read from the arguments); the common sizes
 // are instantiated so that trip counts, LDS offsets and the index divisions fold
-template <int W, int NUc, int NFPc>
+// LESG: the eddy-viscosity / similarity closure of an LES run (eles::calc_sgsf_upts, src/eles.cpp:2395-2650) evaluated in P3 on the
+// physical gradient the point physics holds.  The reference adds F_sgs to the total flux at the solution points
+// (src/eles.cpp:2360-2392) and, at the flux points, extrapolates the TRANSFORMED SGS flux (opp_0), takes it back to physical space
+// and adds it to each side's viscous flux in the common-flux sweep (src/eles.cpp:2817-2893, src/int_inters.cpp:299-313).  What the
+// face kernel needs of that is F_sgs . n = (F~_sgs . n~) / tdA = (sum_d opp_1[d] F~_sgs,d) / tdA -- the contraction P4 runs for
+// norm_tdisf in the form without the folded correction.  So P3 first leaves the transformed SGS flux ALONE in G (the rest of the
+// point's transformed flux waits in registers), one more contraction adds its normal projection to the Fn this workgroup stored
+// in P2, and then the rest joins G for P4.
+template <int W, int NUc, int NFPc, bool LESG = false>
 __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a)
 {
+  static_assert(!LESG || NUc != 0, "the LES form is instantiated for the element classes with compile-time sizes");
   constexpr int NF = 5, ND = 3, T = 64 * W;
   extern __shared__ double lds[];
   const int nu = NUc ? NUc : a.nu, nfp = NFPc ? NFPc : a.nfp;
@@ -530,7 +543,116 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
     stamp(6);
   }
 
-  p3_points(tid, T);
+  if constexpr (LESG)
+  {
+    constexpr int TRIPS = (NUc * GB + T - 1) / T;
+    double Tiv[TRIPS][NF * ND]; // transformed inviscid + viscous flux of this thread's points
+#pragma unroll
+    for (int tr = 0; tr < TRIPS; tr++)
+    {
+      const int q = tid + T * tr;
+      const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
+      const bool in = q < nu * GB, ok = in && el < nval;
+      const long o = ok ? pt + (long)nu * (e0 + el) : 0;
+      double JG[9];
+#pragma unroll
+      for (int c = 0; c < 9; c++) JG[c] = a.JGinv_upts[o * 9 + c];
+      const double dj = a.detjac_upts[o];
+      double y = 0.0;
+      if (a.les.sgs_model == 0)
+      {
+#pragma unroll
+        for (int i = 0; i < ND; i++)
+        {
+          const double w = a.wall_distance[o + i * plane_u];
+          y += w * w;
+        }
+        y = sqrt(y);
+      }
+      const int so = sw(in ? pt : 0, in ? el : 0);
+      double u[NF], F[NF * ND], g[NF * ND], fv[NF * ND], sg[NF * ND];
+#pragma unroll
+      for (int k = 0; k < NF; k++) u[k] = ok ? U[k * KU * GB + so] : 1.0;
+      calc_invf<ND, true>(a.P.gamma, u, F);
+      const double idj = 1.0 / dj;
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+      {
+        double tg[ND], cg[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) tg[d] = G[(k + NF * d) * KU * GB + so];
+        g_to_physical(idj, JG, tg, cg);
+#pragma unroll
+        for (int d = 0; d < ND; d++) g[k + NF * d] = ok ? cg[d] : 0.0;
+      }
+      calc_visf<ND, true>(a.P, u, g, fv);
+      calc_sgsf<ND>(a.P, a.les, u, g, dj, y, o, plane_u, sg);
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int l = 0; l < ND; l++)
+        {
+          double t = 0.0, ts = 0.0;
+#pragma unroll
+          for (int m = 0; m < ND; m++)
+          {
+            t += JG[l + ND * m] * (F[k + NF * m] + fv[k + NF * m]);
+            ts += JG[l + ND * m] * sg[k + NF * m];
+          }
+          Tiv[tr][k + NF * l] = ok ? t : 0.0;
+          if (in) G[(k + NF * l) * KU * GB + so] = ok ? ts : 0.0;
+        }
+    }
+    __syncthreads();
+    // F~_sgs . n~ at the flux points, joined to the Fn of P2: rows of opp_1[d] against G(., d), as P4's norm_tdisf tiles
+    {
+      const int n_ft = MF / 16;
+      auto sgs_item = [&](int rt, auto nf_c, int f0) {
+        constexpr int NFS = decltype(nf_c)::value;
+        g_f64x4 acc[NFS];
+#pragma unroll
+        for (int f = 0; f < NFS; f++) acc[f] = g_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < ND; d++) tile_mac<NFS>(acc, a.o1[d], MF, rt, G + (f0 + NF * d) * KU * GB, KU * GB, KU / 4, li, lk);
+        const int row = rt * 16 + li;
+        if (row < nfp)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++)
+          {
+            const int el = lk + 4 * rg;
+            if (el < nval)
+            {
+              const long o = row + (long)nfp * (e0 + el);
+              const double itd = 1.0 / a.tdA_fpts[o];
+#pragma unroll
+              for (int f = 0; f < NFS; f++)
+              {
+                // (the value another wave of this workgroup stored in P2: read past the first-level cache)
+                double *p = a.fn + o + (f0 + f) * plane_f;
+                const double old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *p = old + acc[f][rg] * itd;
+              }
+            }
+          }
+      };
+      split_rounds<W>(n_ft, wave, sgs_item);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tr = 0; tr < TRIPS; tr++)
+    {
+      const int q = tid + T * tr;
+      const int el = (int)__umulhi((unsigned)q, inv_nu), pt = q - el * nu;
+      if (q < nu * GB)
+      {
+        const int so = sw(pt, el);
+#pragma unroll
+        for (int c = 0; c < NF * ND; c++) G[c * KU * GB + so] += Tiv[tr][c];
+      }
+    }
+  }
+  else
+    p3_points(tid, T);
   stamp(7);
   __syncthreads();
   stamp(8);
@@ -904,8 +1026,17 @@ static size_t update_lds_bytes(const GeneralData *g) { return sizeof(double) * G
 static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_eles *const *eles, int neb)
 {
   HFX_CHECK(e->n_dims == 3 && e->n_fields == 5, "general fused stage: three-dimensional Navier-Stokes / Euler blocks only");
-  // (shock capturing follows the stage as its own step: general_shock_capture)
-  HFX_CHECK(!e->les_ready && !e->over_int_ready, "general fused stage: LES and over-integration run per method");
+  // (shock capturing follows the stage as its own step: general_shock_capture; an LES closure is evaluated in the flux kernel)
+  HFX_CHECK(!e->over_int_ready, "general fused stage: over-integration runs per method");
+  if (e->les_ready)
+  {
+    static const int sizes[][2] = {{4, 12}, {10, 24}, {20, 40}, {6, 18}, {18, 39}, {40, 68}};
+    bool known = false;
+    for (const auto &sz : sizes) known = known || (e->n_upts == sz[0] && e->n_fpts == sz[1]);
+    HFX_CHECK(known && e->ctx->params.viscous, "general fused stage: the LES closure is built for tetrahedra / prisms of orders 1..3 on a viscous run");
+    for (int b = 0; b < nfb; b++)
+      HFX_CHECK(!faces[b]->is_mpi, "general fused stage: LES on partitioned blocks runs per method (the SGS flux is a third partition-face message)");
+  }
   const bool visc = e->ctx->params.viscous != 0;
   HFX_CHECK(!visc || e->viscous_ops, "general fused stage: viscous run but the block has no opp_4/5/6");
   if (!e->general) e->general = new GeneralData();
@@ -1093,6 +1224,7 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
     if (hipMalloc((void **)&g->stamps, sizeof(long long) * 16 * 16) == hipSuccess) (void)hipMemset(g->stamps, 0, sizeof(long long) * 16 * 16);
   }
   a.stamps = g->stamps;
+  a.les = e->les; a.wall_distance = e->wall_distance; a.tdA_fpts = e->tdA_fpts;
   a.write_div = 1; // the flux kernel left the discontinuous part there: always complete it (the monitors read it)
   (void)last_stage;
   return a;
@@ -1126,6 +1258,20 @@ static int launch_element_kernels_t(hfx_eles *e, const GenArgs &a, bool flux)
     const size_t lds = flux_lds_bytes(g);
     // (function attributes are per device: set whenever the image exceeds the default, as launch_dense does -- a cached
     // "configured" size would be wrong for a second context on another GPU of the same process)
+    // a closure with an SGS flux (every model but the spectral vanishing viscosity, which only filters the state)
+    const bool les = e->les_ready && e->les.sgs_model != 3 && e->ctx->params.viscous;
+    if constexpr (NUc != 0)
+    {
+      if (les)
+      {
+        if (lds > 48 * 1024)
+          HFX_HIP(hipFuncSetAttribute((const void *)general_flux_kernel<W, NUc, NFPc, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((general_flux_kernel<W, NUc, NFPc, true>), dim3(grid), dim3(64 * W), lds, st, a);
+        HFX_HIP(hipGetLastError());
+        return 0;
+      }
+    }
+    HFX_CHECK(!les, "general fused stage: the LES closure is built for the element classes with compile-time sizes");
     if (lds > 48 * 1024)
       HFX_HIP(hipFuncSetAttribute((const void *)general_flux_kernel<W, NUc, NFPc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((general_flux_kernel<W, NUc, NFPc>), dim3(grid), dim3(64 * W), lds, st, a);
@@ -1329,6 +1475,15 @@ int general_run_steps(hfx_eles *const *eles, int neb, hfx_inters *const *faces, 
     }
     for (int rk = 0; rk < nst; rk++)
     {
+      // closures that filter the solution do so at the first stage of a step (src/solver.cpp:55-62); the SVV closure replaces the
+      // state, whose flux-point values are then recomputed
+      if (rk == 0)
+        for (int i = 0; i < neb; i++)
+          if (eles[i]->les_ready && eles[i]->les.sgs_model >= 2)
+          {
+            if (hfx_eles_calc_sgs_terms(eles[i])) return 1;
+            if (eles[i]->les.sgs_model == 3 && hfx_eles_extrapolate_solution(eles[i])) return 1;
+          }
       if (general_stage(eles, neb, faces, nfb, rk, rk == nst - 1, 0)) return 1;
       if (general_shock_capture(eles, neb)) return 1;
     }
