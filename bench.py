@@ -212,6 +212,14 @@ def general_workload(args):
         big = tile_arrays(per[c], tiles)
         E[c] = hfx.Eles(ctx, [sz[0] * tiles] + sz[1:5], big, ele_type=sz[6], order=sz[5])
         E[c].upload(hfx.DISU_UPTS0, big["u_init"])
+        if args.les_cs >= 0:
+            # LES, WALE closure (evaluated inside the general stage's flux kernel): Jacobian_fpts from the host mirror's element class
+            import hfx_host as H
+            x1 = per[c]["loc_upts"][2, ::(sz[5] + 1) * (sz[5] + 2) // 2] if sz[6] == 3 else None
+            S = H.Simplex(sz[6], sz[5], per[c]["shape"][:, :(4 if sz[6] == 2 else 6), :], viscous=1, loc_1d_upts=x1, SGS_model=1)
+            J = np.asfortranarray(np.concatenate([S.array("Jacobian_fpts")] * tiles, axis=3))
+            S.close()
+            E[c].set_les(1, args.les_cs, 1.0, 0.41, 0.9, J)
     F = [hfx.IntInters(ctx, E[a], E[b], tile_table(L, plane[a], tiles), tile_table(R, plane[b], tiles)) for a, b, L, R in faces]
     for a, L, ids in bdy:
         F.append(hfx.BdyInters(ctx, E[a], tile_table(L, plane[a], tiles), np.tile(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
@@ -284,7 +292,8 @@ def general_workload(args):
             "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_rk_stage": 1e3 * elapsed / args.steps / n_stages, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "timing": {"reps": len(samples), "statistic": "median", "seconds_per_rep": samples, "stages_per_rep": n_stages * args.steps},
-            "config": {"workload": "%s: the reference's fixture %s tiled %d times, Navier-Stokes, HLLC+LDG, RK45" % (desc, name, tiles),
+            "config": {"workload": "%s: the reference's fixture %s tiled %d times, Navier-Stokes, HLLC+LDG, RK45%s" %
+                                   (desc, name, tiles, ", LES WALE C_s %g" % args.les_cs if args.les_cs >= 0 else ""),
                        "n_eles": {str(c): E[c].n_eles for c in classes}, "dof": dof,
                        "path": "general fused stage (fused 4)" if fused else "per method", "multi_gpu": "none"},
             "roofline": roof, "cpu_baseline": cpu}
@@ -303,6 +312,8 @@ ALSO_LEGS = [
     ("config5_overint_shock", "BASELINE.json configs[4]'s ingredients on one GPU: 32^3 P4 hexes, over-integration (7 points per direction) + "
      "shock capturing after every stage", ["--over-int-order", "6", "--shock-s0", "1e-3"]),
     ("les_wale", "32^3 P4 hexes, LES with the WALE closure (SURVEY 8f rank 4)", ["--les-cs", "0.325"]),
+    ("mixed_les_wale", "the mixed tetrahedron / prism channel with the WALE closure, evaluated inside the general fused stage's flux kernel",
+     ["--workload", "mixed", "--les-cs", "0.325"]),
     ("self_partition", "the 2x2x2 rank's share: 32^3 P4 with all 6 144 wrap-around faces as partition faces, exchanged over RCCL with the "
      "rank itself", ["--self-partition"]),
 ]

@@ -57,6 +57,7 @@ struct GeneralData
   bool any_bdy = false;
   bool built = false;
   long long *stamps = nullptr;
+  double *les_len2 = nullptr; // (n_upts, n_eles) squared length scale of an LES closure (les_len2_upload)
 };
 
 void general_invalidate(hfx_eles *e)
@@ -69,7 +70,7 @@ void general_destroy(hfx_eles *e)
   if (!e || !e->general) return;
   GeneralData *g = (GeneralData *)e->general;
   void *p[] = {g->o0, g->o1[0], g->o1[1], g->o1[2], g->o2[0], g->o2[1], g->o2[2], g->o3, g->o4[0], g->o4[1], g->o4[2],
-               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts, g->stamps, g->nbr, g->o2f[0], g->o2f[1], g->o2f[2]};
+               g->o5[0], g->o5[1], g->o5[2], g->o6, g->meta, g->disu_alt, g->fn_fpts, g->stamps, g->nbr, g->o2f[0], g->o2f[1], g->o2f[2], g->les_len2};
   for (void *q : p)
     if (q) (void)hipFree(q);
   delete g;
@@ -123,7 +124,7 @@ struct GenArgs
   // LES closure evaluated in the flux kernel (LESG form): parameters (with the Leonard terms of the similarity models), the wall
   // distance of the Smagorinsky damping, and tdA at the flux points (F_sgs . n = (F~_sgs . n~) / tdA)
   LesParams les;
-  const double *wall_distance, *tdA_fpts;
+  const double *les_len2, *tdA_fpts;
 };
 
 // NA output tiles at once, sharing the operator fragments: acc[j] += op[rt*16 + (0..15)][0 .. 4 ksteps) . plane_j[k][16 elements],
@@ -557,18 +558,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       double JG[9];
 #pragma unroll
       for (int c = 0; c < 9; c++) JG[c] = a.JGinv_upts[o * 9 + c];
-      const double dj = a.detjac_upts[o];
-      double y = 0.0;
-      if (a.les.sgs_model == 0)
-      {
-#pragma unroll
-        for (int i = 0; i < ND; i++)
-        {
-          const double w = a.wall_distance[o + i * plane_u];
-          y += w * w;
-        }
-        y = sqrt(y);
-      }
+      const double dj = a.detjac_upts[o], len2 = a.les_len2[o];
       const int so = sw(in ? pt : 0, in ? el : 0);
       double u[NF], F[NF * ND], g[NF * ND], fv[NF * ND], sg[NF * ND];
 #pragma unroll
@@ -586,7 +576,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
         for (int d = 0; d < ND; d++) g[k + NF * d] = ok ? cg[d] : 0.0;
       }
       calc_visf<ND, true>(a.P, u, g, fv);
-      calc_sgsf<ND>(a.P, a.les, u, g, dj, y, o, plane_u, sg);
+      calc_sgsf_fast<ND>(a.P, a.les, u, g, len2, o, plane_u, sg);
 #pragma unroll
       for (int k = 0; k < NF; k++)
 #pragma unroll
@@ -1037,6 +1027,8 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_ele
     for (int b = 0; b < nfb; b++)
       HFX_CHECK(!faces[b]->is_mpi, "general fused stage: LES on partitioned blocks runs per method (the SGS flux is a third partition-face message)");
   }
+  if (!e->general) e->general = new GeneralData();
+  if (e->les_ready && e->les.sgs_model != 3 && les_len2_upload(e, &((GeneralData *)e->general)->les_len2)) return 1;
   const bool visc = e->ctx->params.viscous != 0;
   HFX_CHECK(!visc || e->viscous_ops, "general fused stage: viscous run but the block has no opp_4/5/6");
   if (!e->general) e->general = new GeneralData();
@@ -1224,7 +1216,7 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
     if (hipMalloc((void **)&g->stamps, sizeof(long long) * 16 * 16) == hipSuccess) (void)hipMemset(g->stamps, 0, sizeof(long long) * 16 * 16);
   }
   a.stamps = g->stamps;
-  a.les = e->les; a.wall_distance = e->wall_distance; a.tdA_fpts = e->tdA_fpts;
+  a.les = e->les; a.les_len2 = g->les_len2; a.tdA_fpts = e->tdA_fpts;
   a.write_div = 1; // the flux kernel left the discontinuous part there: always complete it (the monitors read it)
   (void)last_stage;
   return a;

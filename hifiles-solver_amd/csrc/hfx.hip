@@ -344,6 +344,47 @@ int side_stream_wait(hfx_ctx *ctx)
 
 } // namespace hfx
 
+namespace hfx
+{
+// The squared length scale of the eddy-viscosity closures at every solution point, min(y^2 Kappa^2, C_s^2 Delta^2) for the damped
+// Smagorinsky model and C_s^2 Delta^2 for WALE (src/eles.cpp:2436-2520, Delta = filter_ratio vol^(1/n_dims) / (order + 1) with
+// vol = detjac * the reference element's volume): it depends on the metrics and the wall distance only, so the fused stages' flux
+// kernels read it (calc_sgsf_fast) instead of evaluating a cube root per point and stage.  Evaluated once on the host with the
+// reference's own expression; *dst: a new device array (n_upts, n_eles).
+int les_len2_upload(hfx_eles *e, double **dst)
+{
+  const long plane = (long)e->n_upts * e->n_eles;
+  std::vector<double> dj(plane), len2(plane), wd;
+  HFX_HIP(hipMemcpy(dj.data(), e->detjac_upts, sizeof(double) * plane, hipMemcpyDeviceToHost));
+  const int nd = e->n_dims;
+  if (e->les.sgs_model == 0)
+  {
+    HFX_CHECK(e->wall_distance, "the Smagorinsky closure needs wall_distance");
+    wd.resize((size_t)plane * nd);
+    HFX_HIP(hipMemcpy(wd.data(), e->wall_distance, sizeof(double) * wd.size(), hipMemcpyDeviceToHost));
+  }
+  for (long p = 0; p < plane; p++)
+  {
+    const double vol = dj[p] * e->les.vol_factor;
+    const double delta = e->les.filter_ratio * std::pow(vol, 1. / nd) / (e->les.order + 1.);
+    double l2 = e->les.C_s * e->les.C_s * delta * delta;
+    if (e->les.sgs_model == 0)
+    {
+      double y = 0.0;
+      for (int i = 0; i < nd; i++) y += wd[p + (size_t)i * plane] * wd[p + (size_t)i * plane];
+      y = std::sqrt(y);
+      l2 = std::fmin(y * y * e->les.Kappa * e->les.Kappa, l2);
+    }
+    len2[p] = l2;
+  }
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  HFX_HIP(hipMalloc((void **)dst, sizeof(double) * std::max<long>(plane, 1)));
+  HFX_HIP(hipMemcpy(*dst, len2.data(), sizeof(double) * plane, hipMemcpyHostToDevice));
+  return 0;
+}
+
+} // namespace hfx
+
 using namespace hfx;
 
 // ===========================================================================

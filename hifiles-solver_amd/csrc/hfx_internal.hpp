@@ -289,6 +289,8 @@ inline void invalidate_fpts(hfx_eles *e) { e->fpts_valid = e->fpts_sent = false;
 int side_stream_fork(hfx_ctx *ctx);
 int side_stream_join(hfx_ctx *ctx);
 int side_stream_wait(hfx_ctx *ctx);
+// (hfx.hip) the squared length scale of the eddy-viscosity closures at every solution point, for the fused stages' flux kernels
+int les_len2_upload(hfx_eles *e, double **dst);
 } // namespace hfx
 // a per-method entry point: recorded while the context defers (and is not replaying)
 #define HFX_DEFER(ctx_, method_, e_, f_, c_, i0_, i1_)  \
