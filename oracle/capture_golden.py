@@ -170,6 +170,9 @@ CASES = [
          filter_type=2, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
     case("tet_p3_les_sim", n=2, amp=0.1, level=1, order=3, steps=2, tets=True, LES=1, SGS_model=4, C_s=0.325, filter_ratio=2.0,
          filter_type=3, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    # the spectral vanishing viscosity closure: the state itself is replaced by its modal-filtered form at the first stage of a step
+    case("tet_p3_les_svv", n=2, amp=0.1, level=1, order=3, steps=2, tets=True, LES=1, SGS_model=3, C_s=0.325, filter_ratio=2.0,
+         filter_type=2, upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
     # curved elements: the quadratic tetrahedron (10 shape nodes, src/eles_tets.cpp:1047) and the quadratic prism (15,
     # src/eles_pris.cpp:1115) with every mid-edge node moved off its edge
     case("tet_p2_curved", n=2, amp=0.1, level=1, order=2, steps=1, tets=True, curve=0.06,

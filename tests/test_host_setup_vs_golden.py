@@ -314,7 +314,7 @@ def test_les_filter_vs_reference(name):
     c.close()
 
 
-@pytest.mark.parametrize("name", ["tet_p3_les_wsm", "tet_p3_les_sim"])
+@pytest.mark.parametrize("name", ["tet_p3_les_wsm", "tet_p3_les_sim", "tet_p3_les_svv"])
 def test_tet_les_filter_vs_reference(name):
     """eles_tets::compute_filter_upts (src/eles_tets.cpp:576-690): the modal filter and the element average, after the
     reference's in-place symmetrisation and normalisation passes, from the host mirror's eles_tets"""

@@ -179,7 +179,8 @@ def test_general_fused_stage_on_mixed_mesh_vs_reference(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tet_p2_n2_deformed", "tet_p3_n2_deformed", "pri_p2_n2_deformed", "pri_p3_n2_deformed",
                                   "tet_p2_vcjh_sd", "tet_p3_vcjh_cplus", "tet_p2_vcjh_c", "pri_p2_vcjh_hu", "tet_p2_curved", "pri_p2_curved",
-                                  "tet_p3_shock", "pri_p2_shock", "tet_p2_les_wale", "pri_p2_les_wale", "tet_p3_les_wsm", "tet_p3_les_sim"])
+                                  "tet_p3_shock", "pri_p2_shock", "tet_p2_les_wale", "pri_p2_les_wale", "tet_p3_les_wsm", "tet_p3_les_sim",
+                                  "tet_p3_les_svv"])
 def test_general_fused_stage_single_class_vs_reference(name):
     """the same on the periodic single-class tetrahedron and prism fixtures (a last batch of fewer than 16 elements
     included), and what it leaves in the public arrays against the per-method path"""
@@ -240,7 +241,7 @@ def test_mixed_channel_from_the_host_mirrors_own_operators(fused):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tet_p2_les_wale", "pri_p2_les_wale", "tet_p3_les_wsm", "tet_p3_les_sim"])
+@pytest.mark.parametrize("name", ["tet_p2_les_wale", "pri_p2_les_wale", "tet_p3_les_wsm", "tet_p3_les_sim", "tet_p3_les_svv"])
 def test_simplex_les_from_the_host_mirrors_own_operators(name):
     """LES on tetrahedra and prisms (src/eles.cpp:2395 with the class's calc_ele_vol; src/eles_tets.cpp:576 for the filter of the
     closures that filter the solution): operators, metrics, Jacobian_fpts and filter_upts from the host mirror's eles_tets /
