@@ -125,6 +125,9 @@ struct GenArgs
   // distance of the Smagorinsky damping, and tdA at the flux points (F_sgs . n = (F~_sgs . n~) / tdA)
   LesParams les;
   const double *les_len2, *tdA_fpts;
+  // over-integration: the de-aliased transformed inviscid flux (eles::evaluate_invFlux_over_int, formed by the dense contractions
+  // before this launch), taken in P3 instead of the collocated one; NULL: none
+  const double *tdisf_in;
 };
 
 // NA output tiles at once, sharing the operator fragments: acc[j] += op[rt*16 + (0..15)][0 .. 4 ksteps) . plane_j[k][16 elements],
@@ -408,7 +411,24 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       double u[NF], F[NF * ND];
 #pragma unroll
       for (int k = 0; k < NF; k++) u[k] = U[k * KU * GB + so];
-      calc_invf<ND, true>(a.P.gamma, u, F);
+      const bool oi = a.tdisf_in != nullptr;
+      double td[NF * ND];
+      if (oi)
+      {
+        const long o = pt + (long)nu * (e0 + el);
+#pragma unroll
+        for (int c = 0; c < NF * ND; c++)
+        {
+          td[c] = a.tdisf_in[o + c * plane_u];
+          F[c] = 0.0;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int c = 0; c < NF * ND; c++) td[c] = 0.0;
+        calc_invf<ND, true>(a.P.gamma, u, F);
+      }
       if (visc)
       {
         const double idj = 1.0 / dj;
@@ -432,7 +452,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
 #pragma unroll
         for (int l = 0; l < ND; l++)
         {
-          double t = 0.0;
+          double t = td[k + NF * l];
 #pragma unroll
           for (int m = 0; m < ND; m++) t += JG[l + ND * m] * F[k + NF * m];
           G[(k + NF * l) * KU * GB + so] = t;
@@ -563,7 +583,14 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       double u[NF], F[NF * ND], g[NF * ND], fv[NF * ND], sg[NF * ND];
 #pragma unroll
       for (int k = 0; k < NF; k++) u[k] = ok ? U[k * KU * GB + so] : 1.0;
-      calc_invf<ND, true>(a.P.gamma, u, F);
+      const bool oi = a.tdisf_in != nullptr;
+      if (oi)
+      {
+#pragma unroll
+        for (int c = 0; c < NF * ND; c++) F[c] = 0.0;
+      }
+      else
+        calc_invf<ND, true>(a.P.gamma, u, F);
       const double idj = 1.0 / dj;
 #pragma unroll
       for (int k = 0; k < NF; k++)
@@ -582,7 +609,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
 #pragma unroll
         for (int l = 0; l < ND; l++)
         {
-          double t = 0.0, ts = 0.0;
+          double t = oi ? a.tdisf_in[o + (k + NF * l) * plane_u] : 0.0, ts = 0.0;
 #pragma unroll
           for (int m = 0; m < ND; m++)
           {
@@ -1016,8 +1043,8 @@ static size_t update_lds_bytes(const GeneralData *g) { return sizeof(double) * G
 static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_eles *const *eles, int neb)
 {
   HFX_CHECK(e->n_dims == 3 && e->n_fields == 5, "general fused stage: three-dimensional Navier-Stokes / Euler blocks only");
-  // (shock capturing follows the stage as its own step: general_shock_capture; an LES closure is evaluated in the flux kernel)
-  HFX_CHECK(!e->over_int_ready, "general fused stage: over-integration runs per method");
+  // (shock capturing follows the stage as its own step: general_shock_capture; an LES closure is evaluated in the flux kernel;
+  // over-integration: the de-aliased flux is formed by the dense contractions before the flux kernel, which takes it in P3)
   if (e->les_ready)
   {
     static const int sizes[][2] = {{4, 12}, {10, 24}, {20, 40}, {6, 18}, {18, 39}, {40, 68}};
@@ -1217,6 +1244,7 @@ static GenArgs gen_args(hfx_eles *e, int in_step, bool last_stage)
   }
   a.stamps = g->stamps;
   a.les = e->les; a.les_len2 = g->les_len2; a.tdA_fpts = e->tdA_fpts;
+  a.tdisf_in = e->over_int_ready ? e->arr[HFX_TDISF_UPTS] : nullptr;
   a.write_div = 1; // the flux kernel left the discontinuous part there: always complete it (the monitors read it)
   (void)last_stage;
   return a;
@@ -1320,6 +1348,8 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
   if (which == 0 || which == 2)
     for (int i = 0; i < neb; i++)
     {
+      // polynomial de-aliasing (src/solver.cpp:82-91): tdisf_upts = over_int_filter . F(opp_over_int_cubpts . u)
+      if (eles[i]->over_int_ready && hfx_eles_evaluate_invFlux_over_int(eles[i])) return 1;
       const GenArgs a = gen_args(eles[i], in_step, last_stage);
       // two workgroups per CU where the batch's LDS image allows it (4 waves each), otherwise one of 8 waves
       int w = ctx->opt.general_waves;

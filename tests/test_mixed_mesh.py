@@ -180,7 +180,7 @@ def test_general_fused_stage_on_mixed_mesh_vs_reference(name):
 @pytest.mark.parametrize("name", ["tet_p2_n2_deformed", "tet_p3_n2_deformed", "pri_p2_n2_deformed", "pri_p3_n2_deformed",
                                   "tet_p2_vcjh_sd", "tet_p3_vcjh_cplus", "tet_p2_vcjh_c", "pri_p2_vcjh_hu", "tet_p2_curved", "pri_p2_curved",
                                   "tet_p3_shock", "pri_p2_shock", "tet_p2_les_wale", "pri_p2_les_wale", "tet_p3_les_wsm", "tet_p3_les_sim",
-                                  "tet_p3_les_svv"])
+                                  "tet_p3_les_svv", "tet_p2_overint", "pri_p2_overint"])
 def test_general_fused_stage_single_class_vs_reference(name):
     """the same on the periodic single-class tetrahedron and prism fixtures (a last batch of fewer than 16 elements
     included), and what it leaves in the public arrays against the per-method path"""
