@@ -658,6 +658,10 @@ int hfx_run_steps_partitioned_blocks(hfx_eles *const *eles, int n_ele_blocks, hf
   {
     for (int rk = 0; rk < nst; rk++)
     {
+      // closures that filter the solution do so at the first stage of a step (src/solver.cpp:55-62)
+      if (rk == 0)
+        for (int i = 0; i < n_ele_blocks; i++)
+          if (eles[i]->les_ready && eles[i]->les.sgs_model >= 2 && hfx_eles_calc_sgs_terms(eles[i])) return 1;
       if (general_partitioned_stage(eles, n_ele_blocks, int_faces, n_int, mpi_faces, n_mpi, comm, rk, start)) return 1;
       start = false;
     }

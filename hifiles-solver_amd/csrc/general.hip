@@ -1051,8 +1051,10 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_ele
     bool known = false;
     for (const auto &sz : sizes) known = known || (e->n_upts == sz[0] && e->n_fpts == sz[1]);
     HFX_CHECK(known && e->ctx->params.viscous, "general fused stage: the LES closure is built for tetrahedra / prisms of orders 1..3 on a viscous run");
+    // (partitioned blocks: the projected flux a partition face sends already contains F_sgs . n -- no third message; the
+    // SVV closure filters the state after its flux-point values have left for the neighbours)
     for (int b = 0; b < nfb; b++)
-      HFX_CHECK(!faces[b]->is_mpi, "general fused stage: LES on partitioned blocks runs per method (the SGS flux is a third partition-face message)");
+      HFX_CHECK(!faces[b]->is_mpi || e->les.sgs_model != 3, "general fused stage: the SVV closure on partitioned blocks runs per method");
   }
   if (!e->general) e->general = new GeneralData();
   if (e->les_ready && e->les.sgs_model != 3 && les_len2_upload(e, &((GeneralData *)e->general)->les_len2)) return 1;

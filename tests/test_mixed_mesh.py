@@ -416,6 +416,41 @@ def self_partition(ctx, E, faces):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tet_p2_les_wale", "tet_p3_les_wsm", "pri_p2_les_wale"])
+def test_simplex_les_on_partitioned_blocks(name):
+    """hfx_run_steps_partitioned_blocks with an LES closure: the projected flux a partition face sends already contains F_sgs . n
+    (the closure is evaluated in the general stage's flux kernel), so the self-partitioned block -- half of its faces exchanged
+    with itself over RCCL -- equals the genuine reference's undivided run.  (Of the prism box only the triangular faces are
+    partitioned: two of its quadrilateral faces have a flux point where the x component of the normal is rounding noise, and the
+    reference's LDG switch, src/inters.cpp:568-581, is decided there by the LEFT normal's noise on an interior face and by each
+    side's own on a partition face -- the undivided and the partitioned reference differ at those two points by construction.)"""
+    import hfx
+    from test_gpu_methods_vs_golden import build
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    ctx = hfx.Context(0)
+    e, whole = build(ctx, d)
+    for f in whole:
+        f.close()
+    c = int(d["sizes"][6])
+    faces = [(c, c, d["int%d_L" % t], d["int%d_R" % t]) for t in range(3) if "int%d_L" % t in d]
+    rest, M = self_partition(ctx, {c: e}, faces[:1] if c == 3 else faces)
+    rest = rest + (faces[1:] if c == 3 else [])
+    assert len(M) >= 1
+    F = [hfx.IntInters(ctx, e, e, L, R) for a, b, L, R in rest]
+    comm = hfx.Comm(ctx.h, hfx.comm_unique_id(), 1, 0)
+    nstage = int(d["sizes"][7])
+    steps = sorted({int(k.split("_")[1][4:]) for k in d if k.startswith("u_step")})
+    for st in steps:
+        hfx.run_steps_partitioned_blocks([e], F, M, comm, 1)
+        assert relerr(e.download(hfx.DISU_UPTS0), d["u_step%d_stage%d" % (st, nstage - 1)]) < 1e-11, st
+    for f in F + M:
+        f.close()
+    comm.close()
+    e.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("how", ["run_steps", "deferred"])
 def test_mixed_channel_on_partitioned_blocks(how):
     """hfx_run_steps_partitioned_blocks (and the same stage through the deferred call sequence, send_* / receive_* included):
