@@ -1028,6 +1028,7 @@ int hfx_eles_set_les(hfx_eles *e, const hfx_les *les, const double *wall_distanc
     }
   e->les_ready = true;
   fused_invalidate(e);
+  general_invalidate(e); // (the general stage takes the closure / the de-aliased flux from the registration too)
   return 0;
 }
 
@@ -1301,6 +1302,7 @@ int hfx_eles_set_over_int(hfx_eles *e, int n_cubpts, const double *opp_over_int_
   if (dev_alloc_copy(&e->t_cub, nullptr, pc * e->n_fields * e->n_dims)) return 1;
   e->over_int_ready = true;
   fused_invalidate(e);
+  general_invalidate(e); // (the general stage takes the closure / the de-aliased flux from the registration too)
   // tensor-product elements: 1-D factors of the two matrices for the sum-factorised kernel (tensor_ops.hip)
   return tensor_over_int_setup(e, n_cubpts, opp_over_int_cubpts, over_int_filter);
 }

@@ -416,6 +416,36 @@ def self_partition(ctx, E, faces):
 
 
 @pytest.mark.gpu
+def test_general_stage_follows_a_changed_closure():
+    """hfx_eles_set_les after a fused run (another C_s): the general stage's tables -- the closure's length scale among them -- are
+    rebuilt, and the next fused step equals the per-method path with the new closure (and differs from the old one)"""
+    import hfx
+    from test_gpu_methods_vs_golden import build
+    d = dict(np.load(os.path.join(GOLDEN, "tet_p2_les_wale.npz")))
+    sc = lambda k: float(np.ravel(d[k])[0])
+    ctx = hfx.Context(0)
+    e, faces = build(ctx, d)
+    m, mfaces = build(ctx, d)
+    hfx.run_steps(e, faces, 1, fused=4)
+    hfx.run_steps(m, mfaces, 1, fused=0)
+    assert relerr(e.download(hfx.DISU_UPTS0), m.download(hfx.DISU_UPTS0)) < 1e-12
+    old = e.download(hfx.DISU_UPTS0)
+    for x in (e, m):
+        x.set_les(int(sc("SGS_model")), 4.0 * sc("C_s"), sc("filter_ratio"), sc("Kappa"), sc("prandtl_t"), d["Jacobian_fpts"])
+    o, ofaces = build(ctx, d)  # the old closure for comparison
+    o.upload(hfx.DISU_UPTS0, old)
+    hfx.run_steps(e, faces, 1, fused=4)
+    hfx.run_steps(m, mfaces, 1, fused=0)
+    hfx.run_steps(o, ofaces, 1, fused=4)
+    assert relerr(e.download(hfx.DISU_UPTS0), m.download(hfx.DISU_UPTS0)) < 1e-12
+    assert relerr(e.download(hfx.DISU_UPTS0), o.download(hfx.DISU_UPTS0)) > 1e-9
+    for f in faces + mfaces + ofaces:
+        f.close()
+    e.close(); m.close(); o.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tet_p2_les_wale", "tet_p3_les_wsm", "pri_p2_les_wale"])
 def test_simplex_les_on_partitioned_blocks(name):
     """hfx_run_steps_partitioned_blocks with an LES closure: the projected flux a partition face sends already contains F_sgs . n
