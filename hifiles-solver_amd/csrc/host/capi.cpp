@@ -150,6 +150,7 @@ extern "C" int hfxh_case_get_array(hfxh_case *c, const char *name, const double 
   else if (n == "opp_over_int_cubpts") a = &E->opp_over_int_cubpts;
   else if (n == "over_int_filter") a = &E->over_int_filter;
   else if (n == "filter_upts") a = &E->filter_upts;
+  else if (n == "wall_distance" && E->wall_distance.get_dim(0) > 0) a = &E->wall_distance;
   else if (n == "filter_upts_1D") a = &E->filter_upts_1D;
   else if (n == "JGinv_over_int_cubpts") a = &E->JGinv_over_int_cubpts;
   else if (n == "loc_over_int_cubpts") a = &E->loc_over_int_cubpts;

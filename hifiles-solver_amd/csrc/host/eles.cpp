@@ -183,6 +183,33 @@ void eles::calc_d_pos(const hf_array<double> &in_loc, int in_ele, hf_array<doubl
     }
 }
 
+void eles::calc_wall_distance(const std::vector<double> &loc_noslip_bdy)
+{
+  const size_t np = loc_noslip_bdy.size() / (size_t)n_dims;
+  wall_distance.setup(n_upts_per_ele, n_eles, n_dims);
+  for (int i = 0; i < n_eles; i++)
+    for (int j = 0; j < n_upts_per_ele; j++)
+    {
+      double distmin = 1e20, vecmin[3] = {1e20, 1e20, 1e20};
+      for (size_t q = 0; q < np; q++)
+      {
+        double vec[3] = {0, 0, 0}, dist = 0.0;
+        for (int n = 0; n < n_dims; n++)
+        {
+          vec[n] = pos_upts(j, i, n) - loc_noslip_bdy[n + (size_t)n_dims * q];
+          dist += vec[n] * vec[n];
+        }
+        dist = std::sqrt(dist);
+        if (dist < distmin) // (the first of equally near points stays, as in the reference)
+        {
+          for (int n = 0; n < n_dims; n++) vecmin[n] = vec[n];
+          distmin = dist;
+        }
+      }
+      for (int n = 0; n < n_dims; n++) wall_distance(j, i, n) = vecmin[n];
+    }
+}
+
 int eles::set_transforms_pts(int which)
 {
   // which 2: the over-integration cubature points (src/eles.cpp:4155-4210): JGinv only
@@ -413,8 +440,16 @@ int eles::mv_all_cpu_gpu(hfx_ctx *ctx)
     hfx_les l{};
     l.sgs_model = run_input->SGS_model;
     l.C_s = run_input->C_s; l.filter_ratio = run_input->filter_ratio; l.Kappa = run_input->Kappa; l.prandtl_t = run_input->prandtl_t;
-    if (run_input->SGS_model == 0) { fail("Smagorinsky closure: the host mirror has no wall distance (use WALE, SGS_model 1)"); return 1; }
-    if (hfx_eles_set_les(dev, &l, nullptr, Jacobian_fpts.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
+    if (run_input->SGS_model == 0 && wall_distance.get_dim(0) == 0)
+    {
+      fail("Smagorinsky closure: no wall distance (the mesh has no no-slip wall on this rank, or its walls lie on other ranks)");
+      return 1;
+    }
+    if (hfx_eles_set_les(dev, &l, run_input->SGS_model == 0 ? wall_distance.get_ptr_cpu() : nullptr, Jacobian_fpts.get_ptr_cpu()))
+    {
+      fail(hfx_last_error());
+      return 1;
+    }
     if (run_input->SGS_model >= 2 && hfx_eles_set_les_filter(dev, filter_upts.get_ptr_cpu())) { fail(hfx_last_error()); return 1; }
   }
   if (n_ppts_per_ele > 0 && hfx_eles_set_opp_p(dev, n_ppts_per_ele, opp_p.get_ptr_cpu()))

@@ -80,6 +80,11 @@ public:
   hf_array<double> grad_disu_upts;
   hf_array<double> h_ref, dt_local;
   hf_array<double> Jacobian_fpts; // (n_dims,n_dims,n_fpts,n_eles) d(pos)/d(loc) at the flux points, LES only (src/eles.cpp:4231)
+  // eles::calc_wall_distance (src/eles.cpp:2701-2810): for every solution point the vector from the nearest flux point of a no-slip
+  // wall face (brute force; loc_noslip_bdy: (n_dims, n_points) column-major, faces in the mesh's order); the damped Smagorinsky closure
+  // uses its length
+  void calc_wall_distance(const std::vector<double> &loc_noslip_bdy);
+  hf_array<double> wall_distance; // (n_upts,n_eles,n_dims)
   // ---- modal operators of the tensor-product classes (eles_modal.cpp): shock capturing and over-integration
   // (include/eles.h:926-935; eles_hexas.h / eles_quads.h: vandermonde, inv_vandermonde, norm_basis_persson)
   hf_array<double> vandermonde, inv_vandermonde, exp_filter, norm_basis_persson;

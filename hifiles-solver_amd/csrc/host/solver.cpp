@@ -354,6 +354,29 @@ int GeoPreprocess_box(solution *S, const box_mesh &mesh)
     }
     if (M.failed()) { S->err = M.last_error(); return 1; }
   }
+  // wall distance of the damped Smagorinsky closure (src/geometry.cpp:735-892): the flux points of every no-slip wall face, in the
+  // mesh's face order, then eles::calc_wall_distance.  The reference gathers the wall points of all ranks; this box mesh does not
+  if (in.LES && in.SGS_model == 0)
+  {
+    bdy_inters &B = S->mesh_bdy_inters(ftype);
+    std::vector<double> wall;
+    for (int i = 0; i < B.get_n_inters(); i++)
+    {
+      const int flag = in.bc_list[B.boundary_id(i)].flag;
+      if (flag != HFX_BC_ISOTHERM_WALL && flag != HFX_BC_ADIABAT_WALL) continue;
+      for (int j = 0; j < B.n_fpts_per_inter; j++)
+      {
+        const int off = B.disu_fpts_l(j, i), fpt = off % E->n_fpts_per_ele, ele = off / E->n_fpts_per_ele;
+        for (int n = 0; n < dims; n++) wall.push_back(E->pos_fpts(fpt, ele, n));
+      }
+    }
+    if (S->nproc > 1 && mesh.pgrid[0] * mesh.pgrid[1] * (dims == 3 ? mesh.pgrid[2] : 1) > 1)
+    {
+      S->err = "Smagorinsky closure on a partitioned box: the wall points of the other ranks are not gathered (use WALE, SGS_model 1)";
+      return 1;
+    }
+    if (!wall.empty()) E->calc_wall_distance(wall);
+  }
   return 0;
 }
 

@@ -260,6 +260,33 @@ def test_boundary_case_through_the_mirror(name, mode):
 
 
 @pytest.mark.parametrize("mode", ["methods", 3])
+def test_les_smagorinsky_between_walls_through_the_mirror(mode):
+    """The damped Smagorinsky closure from the mesh and the input keys alone: the host mirror collects the flux points of the
+    no-slip wall faces and computes eles::calc_wall_distance (src/eles.cpp:2701-2810, src/geometry.cpp:735-892); the state after
+    the fixture's step equals the genuine reference's, call by call and with the closure inside the split flux kernel"""
+    import bdy_util
+    d = dict(np.load(os.path.join(GOLDEN, "hex_p2_les_smag.npz")))
+    k = bdy_util.json.loads(bytes(d["meta_json"]).decode())["keys"]
+    c, meta = bdy_util.case_from_fixture(d, LES=1, SGS_model=0, C_s=k["C_s"], filter_ratio=k["filter_ratio"])
+    # the wall distance itself: its length everywhere, the vector up to the choice between two equally near wall points (the
+    # points half way between the walls: the reference keeps the first it meets in ITS face order) -- only the length is used
+    w, want = c.array("wall_distance"), d["wall_distance"]
+    assert w.shape == want.shape
+    assert np.abs(np.sqrt((w ** 2).sum(axis=2)) - np.sqrt((want ** 2).sum(axis=2))).max() < 1e-13
+    assert np.abs(np.abs(w) - np.abs(want)).max() < 1e-12
+    assert (np.abs(w - want).max(axis=2) < 1e-12).mean() > 0.8
+    c.to_device(0)
+    if mode == "methods":
+        c.run(1)
+    else:
+        c.run_steps_lib(1, fused=mode)
+    c.sync_host()
+    last = int(d["sizes"][7]) - 1
+    assert rel(c.array("disu_upts0"), d["u_step0_stage%d" % last]) < 1e-11
+    c.close()
+
+
+@pytest.mark.parametrize("mode", ["methods", 3])
 @pytest.mark.parametrize("name", ["hex_p4_jet", "hex_p2_overint", "quad_p3_overint", "hex_p3_shock", "hex_p2_shock_energy",
                                   "quad_p3_shock"])
 def test_dealiasing_and_shock_capturing_through_the_mirror(name, mode):
