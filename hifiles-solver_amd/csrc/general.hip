@@ -583,14 +583,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
       double u[NF], F[NF * ND], g[NF * ND], fv[NF * ND], sg[NF * ND];
 #pragma unroll
       for (int k = 0; k < NF; k++) u[k] = ok ? U[k * KU * GB + so] : 1.0;
-      const bool oi = a.tdisf_in != nullptr;
-      if (oi)
-      {
-#pragma unroll
-        for (int c = 0; c < NF * ND; c++) F[c] = 0.0;
-      }
-      else
-        calc_invf<ND, true>(a.P.gamma, u, F);
+      calc_invf<ND, true>(a.P.gamma, u, F);
       const double idj = 1.0 / dj;
 #pragma unroll
       for (int k = 0; k < NF; k++)
@@ -609,7 +602,7 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
 #pragma unroll
         for (int l = 0; l < ND; l++)
         {
-          double t = oi ? a.tdisf_in[o + (k + NF * l) * plane_u] : 0.0, ts = 0.0;
+          double t = 0.0, ts = 0.0;
 #pragma unroll
           for (int m = 0; m < ND; m++)
           {
@@ -1045,6 +1038,7 @@ static int general_build(hfx_eles *e, hfx_inters *const *faces, int nfb, hfx_ele
   HFX_CHECK(e->n_dims == 3 && e->n_fields == 5, "general fused stage: three-dimensional Navier-Stokes / Euler blocks only");
   // (shock capturing follows the stage as its own step: general_shock_capture; an LES closure is evaluated in the flux kernel;
   // over-integration: the de-aliased flux is formed by the dense contractions before the flux kernel, which takes it in P3)
+  HFX_CHECK(!(e->les_ready && e->over_int_ready), "general fused stage: an LES closure together with over-integration runs per method");
   if (e->les_ready)
   {
     static const int sizes[][2] = {{4, 12}, {10, 24}, {20, 40}, {6, 18}, {18, 39}, {40, 68}};
