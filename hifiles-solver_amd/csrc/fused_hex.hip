@@ -154,6 +154,8 @@ static int dispatch_build_packed(hfx_eles *e, FusedData *F, int N, const std::ve
     case 4: return build_packed<2, 4>(e, F, o1v, o1i);
     case 5: return build_packed<2, 5>(e, F, o1v, o1i);
     case 6: return build_packed<2, 6>(e, F, o1v, o1i);
+    case 7: return build_packed<2, 7>(e, F, o1v, o1i);
+    case 8: return build_packed<2, 8>(e, F, o1v, o1i);
     }
   }
   set_error("fused path: no kernel for N = %d, n_dims = %d", N, e->n_dims);
@@ -371,7 +373,7 @@ static int fused_build(hfx_eles *e, hfx_inters *const *faces, int nfb, bool allo
 {
   HFX_CHECK(e->ele_type == 4 || e->ele_type == 1, "fused path: tensor-product elements only (hexes, quads)");
   const int N = tensor_n(e);
-  HFX_CHECK(N >= 2 && N <= 6, "fused path: built for orders 1..5 (n_upts %d, n_fpts %d)", e->n_upts, e->n_fpts);
+  HFX_CHECK(N >= 2 && N <= (e->n_dims == 2 ? 8 : 6), "fused path: built for orders 1..5 (quads: 1..7) (n_upts %d, n_fpts %d)", e->n_upts, e->n_fpts);
   const int nd = e->n_dims, nfp = e->n_fpts;
   // the registered operators must have the collocated tensor-product sparsity the kernels are sized for
   HFX_CHECK(e->opp_0.nnz_max <= N && e->opp_3.nnz_max <= 2 * nd, "fused path: opp_0 / opp_3 are not tensor-product sparse");
@@ -576,7 +578,7 @@ static bool loader_wave_fits_rt(int nd, int N)
 {
 #define HFX_LWF(ND_, N_) \
   if (nd == ND_ && N == N_) return loader_wave_fits<ND_, N_>();
-  HFX_LWF(3, 2) HFX_LWF(3, 3) HFX_LWF(3, 4) HFX_LWF(3, 5) HFX_LWF(3, 6) HFX_LWF(2, 2) HFX_LWF(2, 3) HFX_LWF(2, 4) HFX_LWF(2, 5) HFX_LWF(2, 6)
+  HFX_LWF(3, 2) HFX_LWF(3, 3) HFX_LWF(3, 4) HFX_LWF(3, 5) HFX_LWF(3, 6) HFX_LWF(2, 2) HFX_LWF(2, 3) HFX_LWF(2, 4) HFX_LWF(2, 5) HFX_LWF(2, 6) HFX_LWF(2, 7) HFX_LWF(2, 8)
 #undef HFX_LWF
   return false;
 }
@@ -928,7 +930,7 @@ static int split_stage(hfx_eles *e, hfx_inters *const *faces, int nfb, int in_st
 #define HFX_SPLIT_CASE(ND_, N_) \
   if (e->n_dims == ND_ && N == N_) rc = launch_split_stage<ND_, N_>(e, faces, nfb, a, which, variant);
   HFX_SPLIT_CASE(3, 2) HFX_SPLIT_CASE(3, 3) HFX_SPLIT_CASE(3, 4) HFX_SPLIT_CASE(3, 5) HFX_SPLIT_CASE(3, 6)
-  HFX_SPLIT_CASE(2, 2) HFX_SPLIT_CASE(2, 3) HFX_SPLIT_CASE(2, 4) HFX_SPLIT_CASE(2, 5) HFX_SPLIT_CASE(2, 6)
+  HFX_SPLIT_CASE(2, 2) HFX_SPLIT_CASE(2, 3) HFX_SPLIT_CASE(2, 4) HFX_SPLIT_CASE(2, 5) HFX_SPLIT_CASE(2, 6) HFX_SPLIT_CASE(2, 7) HFX_SPLIT_CASE(2, 8)
 #undef HFX_SPLIT_CASE
   if (rc) return 1;
   // (the buffer swap: behind the whole update, or behind its first part -- the second part then writes the new buffer by name)

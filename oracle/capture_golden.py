@@ -118,6 +118,9 @@ CASES = [
     # BASELINE.json configs[0]: Euler isentropic vortex on quads, P3 (the reference's own CPU-runnable case, reduced mesh)
     case("quad_p3_vortex", dims=2, n=6, amp=0.0, level=1, order=3, steps=2, viscous=0, ic_form=0, riemann_solve_type=0,
          dt=0.001, rho_c_ic=1.0, u_c_ic=1.0, v_c_ic=1.0, w_c_ic=0.0, p_c_ic=1.0),
+    # quads above P5 (the split fused stage is instantiated to P7 on quads): viscous, deformed
+    case("quad_p6_deformed", dims=2, n=3, amp=0.1, level=1, order=6, steps=1),
+    case("quad_p7_deformed", dims=2, n=3, amp=0.1, level=1, order=7, steps=1),
     # tetrahedra (BASELINE.json configs[3]'s element family): non-tensor-product operators, triangular faces
     case("tet_p2_n2_deformed", n=2, amp=0.1, level=2, order=2, steps=1, tets=True,
          upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),

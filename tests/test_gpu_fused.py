@@ -104,11 +104,13 @@ def test_fused_quads_vs_methods(mode):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("order", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("dims", [2, 3])
 def test_split_paths_every_order_vs_methods(dims, order):
-    """Every instantiated element size (P1..P5, quads and hexes) of the split fused kernels -- with and without the
+    """Every instantiated element size (P1..P5 on hexes, P1..P7 on quads) of the split fused kernels -- with and without the
     loader wave, whichever the size selects -- against the per-method path on a small deformed periodic mesh."""
+    if dims == 3 and order > 5:
+        pytest.skip("hexes above P5 have more than 256 points per element: they run call by call")
     n = [4, 3, 1] if dims == 2 else [3, 3, 3]
     ref = H.Case(n, dims=dims, order=order, amp=0.1)
     ref.to_device(0)
