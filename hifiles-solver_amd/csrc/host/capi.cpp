@@ -474,6 +474,11 @@ extern "C" int hfxh_simplex_get_array(hfxh_simplex *s, const char *name, const d
   else if (n == "pos_upts") a = &E->pos_upts;
   else if (n == "pos_fpts") a = &E->pos_fpts;
   else if (n == "filter_upts" && E->filter_upts.get_dim(0) > 0) a = &E->filter_upts;
+  else if (n == "h_ref")
+  {
+    for (int i = 0; i < E->n_eles; i++) E->h_ref(i) = E->calc_h_ref_specific(i);
+    a = &E->h_ref;
+  }
   else if (n == "Jacobian_fpts" && E->Jacobian_fpts.get_dim(0) > 0) a = &E->Jacobian_fpts;
   else if (n == "inv_vandermonde" && E->inv_vandermonde.get_dim(0) > 0) a = &E->inv_vandermonde;
   else if (n == "exp_filter" && E->exp_filter.get_dim(0) > 0) a = &E->exp_filter;

@@ -99,6 +99,9 @@ public:
   void calc_disu_ppts(int in_ele, hf_array<double> &out_disu_ppts); // the reference's per-element accessor
   virtual int set_shock_capture_operators(); // set_vandermonde1D/3D, calc_norm_basis, set_exp_filter; eles_tets / eles_pris override it
   virtual int compute_filter_upts(); // src/eles_hexas.cpp:583, src/eles_quads.cpp:428 (LES_filter); eles_tets overrides it
+  // reference length of an element for the CFL time step (calc_h_ref_specific of the class); the box meshes of hexes / quads set
+  // h_ref themselves (solver.cpp), the simplex classes here
+  virtual double calc_h_ref_specific(int) { return 0.0; }
   hf_array<double> filter_upts_1D, filter_upts;
   int set_over_int();                // set_over_int (cubature points, interpolation, L2-projection filter)
   void tensor_modes(hf_array<int> &deg) const;
@@ -171,6 +174,7 @@ protected:
   double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
   void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
   int compute_filter_upts() override; // src/eles_tets.cpp:576-690 (modal filter, element average)
+  double calc_h_ref_specific(int in_ele) override; // src/eles_tets.cpp:1599-1633: the insphere diameter
   int set_shock_capture_operators() override; // src/eles_tets.cpp:705-797 (set_vandermonde, set_exp_filter, shock_det_persson's mode set)
   std::vector<int> mode_i, mode_j, mode_k; // the orthonormal modal basis the nodal one is computed through
   std::vector<double> vinv;                // inverse Vandermonde matrix, row-major
@@ -191,6 +195,7 @@ protected:
   double eval_nodal_s_basis(int in_index, const hf_array<double> &in_loc, int in_n_spts) override;
   void eval_d_nodal_s_basis(hf_array<double> &d, const hf_array<double> &in_loc, int in_n_spts) override;
   int set_shock_capture_operators() override; // src/eles_pris.cpp:609-730 (set_vandermonde3D, set_exp_filter, calc_norm_basis)
+  double calc_h_ref_specific(int in_ele) override; // src/eles_pris.cpp:1535-1557: shortest vertical edge or triangle incircle diameter
   struct Impl;
   Impl *impl;
 };

@@ -602,6 +602,27 @@ int eles_tets::set_shock_capture_operators()
   return 0;
 }
 
+// the insphere diameter 6 V / (sum of the face areas) of the tetrahedron on the first four shape nodes (src/eles_tets.cpp:1599-1633)
+double eles_tets::calc_h_ref_specific(int in_ele)
+{
+  double a[3], b[3], c[3], d[3], e[3];
+  for (int i = 0; i < 3; i++)
+  {
+    a[i] = shape(i, 1, in_ele) - shape(i, 0, in_ele);
+    b[i] = shape(i, 2, in_ele) - shape(i, 0, in_ele);
+    c[i] = shape(i, 3, in_ele) - shape(i, 0, in_ele);
+    d[i] = shape(i, 2, in_ele) - shape(i, 1, in_ele);
+    e[i] = shape(i, 3, in_ele) - shape(i, 1, in_ele);
+  }
+  auto area = [](const double *p, const double *q) {
+    return 0.5 * std::sqrt(std::pow(p[1] * q[2] - p[2] * q[1], 2) + std::pow(p[0] * q[2] - p[2] * q[0], 2) + std::pow(p[0] * q[1] - p[1] * q[0], 2));
+  };
+  // triple product a . (b x c) (src/funcs.cpp trip_prod)
+  const double trip = a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+  const double vol = 1. / 6. * trip;
+  return 6. * vol / (area(a, b) + area(a, c) + area(b, c) + area(d, e));
+}
+
 double eles_tets::eval_nodal_basis(int in_index, const hf_array<double> &loc)
 {
   const int n = n_upts_per_ele;
@@ -987,6 +1008,27 @@ int eles_pris::set_shock_capture_operators()
   std::string e;
   if (modal_shock_operators(this, n, V, sigma, norm, high, e)) { fail("eles_pris: " + e); return 1; }
   return 0;
+}
+
+// the smallest of the three vertical edges and of the incircle diameters of the lower and the upper triangle (src/eles_pris.cpp:1535-1557)
+double eles_pris::calc_h_ref_specific(int in_ele)
+{
+  auto len = [&](int p, int q) {
+    double s = 0.0;
+    for (int k = 0; k < 3; k++) s += std::pow(shape(k, p, in_ele) - shape(k, q, in_ele), 2.0);
+    return std::sqrt(s);
+  };
+  double length[5];
+  for (int i = 0; i < 3; i++) length[i] = len(i, i + 3);
+  for (int i = 3; i < 5; i++)
+  {
+    const int d = (i - 3) * 3;
+    const double a = len(d, d + 1), b = len(d + 1, d + 2), c = len(d + 2, d), s = 0.5 * (a + b + c);
+    length[i] = 2 * std::sqrt(((s - a) * (s - b) * (s - c)) / s);
+  }
+  double m = length[0];
+  for (int i = 1; i < 5; i++) m = std::fmin(m, length[i]);
+  return m;
 }
 
 double eles_pris::eval_nodal_s_basis(int in_index, const hf_array<double> &loc, int in_n_spts)

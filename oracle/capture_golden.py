@@ -194,6 +194,12 @@ CASES = [
     # CFL time stepping: global minimum (dt_type 1) and local (dt_type 2)
     case("hex_p2_cfl_global", amp=0.15, level=1, order=2, steps=2, dt_type=1, CFL=0.4),
     case("hex_p2_cfl_local", amp=0.15, level=1, order=2, steps=2, dt_type=2, CFL=0.4, adv_type=0),
+    # the same on the simplex classes: calc_h_ref_specific is the tetrahedron's insphere diameter (src/eles_tets.cpp:1599-1633) and the
+    # smallest of the prism's vertical edges and its triangles' incircle diameters (src/eles_pris.cpp:1535-1557)
+    case("tet_p2_cfl_local", n=2, amp=0.1, level=1, order=2, steps=2, tets=True, dt_type=2, CFL=0.4, adv_type=0,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p2_cfl_global", n=2, amp=0.1, level=1, order=2, steps=2, tets="prisms", dt_type=1, CFL=0.4,
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0, vcjh_scheme_tri=1, c_tri=0.0),
     # over-integration of the inviscid flux (polynomial de-aliasing)
     case("hex_p2_overint", amp=0.15, level=2, order=2, steps=1, over_int=1, over_int_order=6),
     case("quad_p3_overint", dims=2, n=4, amp=0.1, level=2, order=3, steps=1, over_int=1, over_int_order=9),

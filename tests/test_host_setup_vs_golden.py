@@ -276,6 +276,20 @@ def test_simplex_shock_capture_operators_vs_reference(name):
     S.close()
 
 
+@pytest.mark.parametrize("name", ["tet_p2_cfl_local", "pri_p2_cfl_global"])
+def test_simplex_reference_length_vs_reference(name):
+    """calc_h_ref_specific of tetrahedra (insphere diameter) and prisms (shortest vertical edge / triangle incircle diameter), the
+    length scale of the CFL time step, from the host mirror's classes"""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    sz = [int(v) for v in d["sizes"]]
+    x1 = d["loc_upts"][2, ::(sz[5] + 1) * (sz[5] + 2) // 2] if sz[6] == 3 else None
+    S = H.Simplex(sz[6], sz[5], d["shape"], viscous=1, loc_1d_upts=x1)
+    h = np.ravel(S.array("h_ref"))
+    assert h.shape == np.ravel(d["h_ref"]).shape
+    assert np.abs(h - np.ravel(d["h_ref"])).max() < 1e-13 * np.abs(d["h_ref"]).max()
+    S.close()
+
+
 def test_simplex_classes_refuse_what_they_do_not_build():
     d = dict(np.load(os.path.join(GOLDEN, "tet_p2_n2_deformed.npz")))
     with pytest.raises(Exception):
