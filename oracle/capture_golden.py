@@ -191,6 +191,12 @@ CASES = [
          integral_quantities="5 kineticenergy enstropy pressuredilatation straincolonproduct devstraincolonproduct"),
     case("quad_p3_integrals", dims=2, n=4, amp=0.1, level=1, order=3, steps=1,
          integral_quantities="3 enstropy kineticenergy devstraincolonproduct"),
+    case("tet_p2_integrals", n=2, amp=0.1, level=1, order=2, steps=1, tets=True,
+         integral_quantities="5 kineticenergy enstropy pressuredilatation straincolonproduct devstraincolonproduct",
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p2_integrals", n=2, amp=0.1, level=1, order=2, steps=1, tets="prisms",
+         integral_quantities="3 enstropy kineticenergy devstraincolonproduct",
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0, vcjh_scheme_tri=1, c_tri=0.0),
     # CFL time stepping: global minimum (dt_type 1) and local (dt_type 2)
     case("hex_p2_cfl_global", amp=0.15, level=1, order=2, steps=2, dt_type=1, CFL=0.4),
     case("hex_p2_cfl_local", amp=0.15, level=1, order=2, steps=2, dt_type=2, CFL=0.4, adv_type=0),
