@@ -130,6 +130,10 @@ CASES = [
     # plot-point interpolation (VTU output's calc_disu_ppts): operator, plot points, interpolated initial state
     case("hex_p3_plot", amp=0.15, level=0, order=3, steps=1, p_res=4, ppts=True),
     case("quad_p2_plot", dims=2, n=4, amp=0.1, level=0, order=2, steps=1, p_res=3, ppts=True),
+    case("tet_p2_plot", n=2, amp=0.1, level=0, order=2, steps=1, p_res=3, ppts=True, tets=True,
+         upts_type_tet=0, fpts_type_tet=0, vcjh_scheme_tet=1, eta_tet=0.0),
+    case("pri_p2_plot", n=2, amp=0.1, level=0, order=2, steps=1, p_res=3, ppts=True, tets="prisms",
+         upts_type_pri_tri=0, upts_type_pri_1d=0, vcjh_scheme_pri_1d=1, eta_pri=0.0, upts_type_tri=0, vcjh_scheme_tri=1, c_tri=0.0),
     # a longer run: 40 time steps (200 RK stages) of the genuine reference, the state after every step -- rounding
     # differences between the paths must not grow
     case("hex_p2_long", amp=0.15, level=0, order=2, steps=40, keep_every=10),

@@ -416,6 +416,31 @@ def self_partition(ctx, E, faces):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,block", [("tet_p2_plot", "tet_p2_n2_deformed"), ("pri_p2_plot", "pri_p2_n2_deformed")])
+def test_plot_point_interpolation_on_simplex_classes(name, block):
+    """eles::calc_disu_ppts (the VTU writer's input) on tetrahedra and prisms: the reference's opp_p of the class registered on a
+    device block of the same mesh, one contraction for all elements, against the reference's interpolated state"""
+    import ctypes as C
+    import hfx
+    from test_gpu_methods_vs_golden import build
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    b = dict(np.load(os.path.join(GOLDEN, block + ".npz")))
+    assert [int(v) for v in d["sizes"][:7]] == [int(v) for v in b["sizes"][:7]]
+    ctx = hfx.Context(0)
+    e, faces = build(ctx, b)
+    e.upload(hfx.DISU_UPTS0, d["u_init"])
+    opp = np.asfortranarray(d["opp_p"])
+    hfx.check(hfx.lib().hfx_eles_set_opp_p(e.h, C.c_int(opp.shape[0]), opp.ctypes.data_as(hfx.dp)))
+    out = np.zeros(d["disu_ppts"].shape, order="F")
+    hfx.check(hfx.lib().hfx_eles_calc_disu_ppts(e.h, out.ctypes.data_as(hfx.dp)))
+    assert relerr(out, d["disu_ppts"]) < 1e-13
+    for f in faces:
+        f.close()
+    e.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_general_stage_follows_a_changed_closure():
     """hfx_eles_set_les after a fused run (another C_s): the general stage's tables -- the closure's length scale among them -- are
     rebuilt, and the next fused step equals the per-method path with the new closure (and differs from the old one)"""
