@@ -1396,7 +1396,13 @@ static int general_stage(hfx_eles *const *eles, int neb, hfx_inters *const *face
     for (int i = 0; i < neb; i++)
     {
       const GenArgs a = gen_args(eles[i], in_step, last_stage);
-      if (launch_element_kernels<4>(eles[i], a, false)) return 1;
+      // four waves where all of a thread's staging loads fit its registers at once (general_update_kernel, BATCH), else eight:
+      // P3 prisms stage 5 + 3 doubles per field and thread on four waves -- past the limit, every trip of the staging loops then
+      // waited for its own loads (0.233 ms for 451 MB)
+      const int w_opt = ctx->opt.general_update_waves;
+      const int mq_d = (a.KF * GB + 255) / 256, mq_u = (a.nu * GB + 255) / 256;
+      const bool eight = w_opt ? w_opt == 8 : (mq_d * 5 > 20 || mq_u * 5 > 15);
+      if (eight ? launch_element_kernels<8>(eles[i], a, false) : launch_element_kernels<4>(eles[i], a, false)) return 1;
     }
     for (int i = 0; i < neb; i++) std::swap(eles[i]->arr[HFX_DISU_FPTS], ((GeneralData *)eles[i]->general)->disu_alt);
   }

@@ -478,6 +478,7 @@ int hfx_ctx_set_option(hfx_ctx *ctx, const char *name, int value)
   else if (n == "flux_grid_per_cu") { HFX_CHECK(value >= 0, "flux_grid_per_cu must be >= 0"); o.flux_grid_per_cu = value; }
   else if (n == "xcd_order") o.xcd_order = value != 0;
   else if (n == "over_int_fold") o.over_int_fold = value != 0;
+  else if (n == "general_update_waves") { HFX_CHECK(value == 0 || value == 4 || value == 8, "general_update_waves must be 0, 4 or 8"); o.general_update_waves = value; }
   else if (n == "dictionary_rows") o.dictionary_rows = value != 0;
   else if (n == "flux_waves") { HFX_CHECK(value == 2 || value == 3, "flux_waves must be 2 or 3"); o.flux_waves = value; }
   else if (n == "buffer_addressing") o.buffer_addressing = value != 0;

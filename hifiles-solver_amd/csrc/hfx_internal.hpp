@@ -147,6 +147,7 @@ struct hfx_ctx
     int tensor_ops = 1;         // sum-factorised over-integration / shock capturing on tensor-product classes
     int dense_waves = 0;        // waves per workgroup of the dense MFMA contraction: 0 by the operator's rows, else 4 or 8
     int dense_split = 0;        // column groups per 16-row tile dealt to the waves: 0 by the operator's rows, else 1, 2 or 4
+    int general_update_waves = 0; // waves per workgroup of the general stage's update kernel: 0 by the staging registers, else 4 or 8
     int over_int_fold = 1;      // 1: with the loader-wave flux kernel the over-integration kernel hands over its contribution to the divergence (n_fields values per point), not tdisf_upts
     int light_wave_short = 1;   // 1: a flux-kernel wave without solution points runs the flux-point physics alone (not the paired form)
     int bdy_beside = 0;         // 1: the fused stages' viscous boundary-face kernels run on a side stream beside the interior-face kernel (measured neutral: off)

@@ -128,7 +128,7 @@ int hfx_ctx_set_CFL(hfx_ctx *ctx, double CFL);
  * runs beside the update of the others), "light_wave_short" (1: a flux-kernel wave without solution points runs the flux-point physics alone), "les_flux_kernel" (1: the LES
  * closure inside the flux kernel of variant 3), "over_int_fold" (1: the sum-factorised over-integration kernel hands the loader-wave flux kernel its
  * contribution to the divergence, n_fields values per solution point, instead of tdisf_upts), "bdy_beside" (0; 1: the fused stages' viscous boundary-face kernels on a side stream
- * beside the interior-face kernel), "general_waves" (0 = by LDS image | 3 | 4 | 8), "dense_waves" (0 = by the operator's rows | 4 | 8) and "dense_split" (0 | 1 | 2 | 4:
+ * beside the interior-face kernel), "general_waves" (0 = by LDS image | 3 | 4 | 8), "general_update_waves" (0 = by the staging registers | 4 | 8), "dense_waves" (0 = by the operator's rows | 4 | 8) and "dense_split" (0 | 1 | 2 | 4:
  * shape of the dense MFMA contraction's workgroup) -- see hfx_ctx::Options in csrc/hfx_internal.hpp; and "deferred" (0), which is
  * not a measurement knob: see below;
  * tests/test_gpu_fused.py::test_split3_variant_knobs_agree holds the variants to each other. */
