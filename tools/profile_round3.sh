@@ -35,6 +35,7 @@ stats general_mixed --workload mixed --steps 4 --warmup 1
 traffic general_mixed --workload mixed --steps 1 --warmup 1
 pmc general_mixed "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" --workload mixed --steps 1 --warmup 1
 stats general_tets --workload tets --steps 4 --warmup 1
+stats general_mixed_les --workload mixed --les-cs 0.325 --steps 4 --warmup 1
 stats partitioned --self-partition --steps 10 --warmup 2
 stats config5 --steps 6 --warmup 2 --over-int-order 6 --shock-s0 1e-3
 stats les --les-cs 0.325 --steps 6 --warmup 2
