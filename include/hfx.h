@@ -240,10 +240,13 @@ int hfx_mpi_inters_calculate_common_viscFlux(hfx_inters *f); /* mpi_inters::calc
  * (n_dims,n_dims,n_fpts,n_eles) is what extrapolate_sgsFlux uses to take the flux back to physical space
  * (src/eles.cpp:2862-2893).  Once set, evaluate_viscFlux adds the SGS flux, hfx_CalcResidual calls
  * extrapolate_sgsFlux (src/solver.cpp:162-167) and interior faces add sgsf_fpts to both sides' viscous flux
- * (src/int_inters.cpp:302-318), partition faces after the third exchange (hfx_mpi_inters_send / receive_sgsf_fpts);
- * hfx_run_steps(..., fused=2) does the same inside its split stage, and a block with a closure runs that variant when
- * fused=3 is asked for (variant 3 keeps the gradients the closure reads in registers), also on partitioned blocks
- * (hfx_stage_partitioned / hfx_run_steps_partitioned: the SGS flux is the third message of the stage). */
+ * (src/int_inters.cpp:302-318), partition faces after the third exchange (hfx_mpi_inters_send / receive_sgsf_fpts).
+ * The filter width uses the element class's calc_ele_vol (|J| times the reference element's volume: hexes 8, quads 4,
+ * prisms 4, tetrahedra 8/6, triangles 2; the block's ele_type decides).
+ * The fused stages evaluate the closure inside their flux kernels -- split variant 3 on hexes / quads (option "les_flux_kernel"),
+ * the general stage on tetrahedra / prisms of orders 1..3 -- and add F_sgs . n to the projected viscous flux of every flux point,
+ * so a partition face's second message already carries it and the third one is not sent there; hfx_run_steps(..., fused=2) keeps
+ * the reference's arrays (gradients, sgsf_upts, sgsf_fpts) and the third message (hfx_stage_partitioned). */
 typedef struct hfx_les
 {
   int sgs_model, pad; /* 0 Smagorinsky, 1 WALE, 2 WALE + similarity, 3 spectral vanishing viscosity, 4 similarity */
