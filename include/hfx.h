@@ -365,6 +365,10 @@ int hfx_run_steps(hfx_eles *e, hfx_inters *const *faces, int n_face_blocks, int 
  * FP64 matrix cores over batches of 16 elements; like fused 3 it keeps the corrected gradients on chip (only boundary
  * points get grad_disu_fpts) and leaves disu_upts(0), disu_upts(1), disu_fpts of the new state and div_tconf_upts;
  * norm_tdisf_fpts (folded into the divergence operator) and delta_disu_fpts of pairs inside a block are not refreshed.
+ * What the blocks registered takes part: an LES closure is evaluated inside the flux kernel (tetrahedra / prisms of orders 1..3;
+ * calc_sgs_terms before the first stage of a step), over-integration forms tdisf_upts by the dense contractions and the flux kernel
+ * takes it, shock capturing follows every stage (the filter, then disu_fpts of the filtered state); a closure TOGETHER with
+ * over-integration is refused (run fused 0).
  * A block with one element class may of course be passed alone (hfx_run_steps(e, ..., 4) is the same call). */
 int hfx_run_steps_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *faces, int n_face_blocks, int n_steps,
                          int fused);
@@ -441,7 +445,9 @@ int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_i
  * (mpi_inters::set_mpi takes any in_ele_type_l, src/mpi_inters.cpp:154); int_faces holds the interior blocks (whose two sides may
  * lie in different element blocks) and the boundary blocks.  Each stage: LDG corrections and common fluxes of the partition faces
  * by the one-sided kernels, the flux-point solution and each side's projected viscous flux Fn as the two messages.  Fixed time
- * step (dt_type 0) only; three-dimensional blocks without LES / over-integration / shock capturing, as hfx_run_steps_blocks(..., 4).
+ * step (dt_type 0) only; three-dimensional blocks as hfx_run_steps_blocks(..., 4) takes them -- an LES closure is evaluated in the
+ * flux kernel (its F_sgs . n travels inside Fn: no third message; the SVV closure is refused here), over-integration feeds it,
+ * shock capturing on such blocks runs call by call.
  * With deferred execution the mirrored CalcResidual of such a mesh runs this stage when its send_* / receive_* name one hfx_comm. */
 int hfx_run_steps_partitioned_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *int_faces, int n_int,
                                      hfx_inters *const *mpi_faces, int n_mpi, hfx_comm *comm, int n_steps);
