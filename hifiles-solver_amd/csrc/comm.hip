@@ -368,7 +368,7 @@ int partitioned_stage_deferred(hfx_eles *e, hfx_inters *const *int_faces, int n_
 //   wait; common fluxes at the partition faces                 update kernels (new flux-point solution)
 //   pack the new flux-point solution, exchange (for the next stage)
 int general_partitioned_stage(hfx_eles *const *eles, int neb, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
-                              int n_mpi, hfx_comm *comm, int rk, bool start)
+                              int n_mpi, hfx_comm *comm, int rk, bool start, bool shock)
 {
   HFX_CHECK(neb > 0 && comm, "general partitioned stage: bad argument");
   hfx_ctx *ctx = eles[0]->ctx;
@@ -414,6 +414,9 @@ int general_partitioned_stage(hfx_eles *const *eles, int neb, hfx_inters *const 
   if (visc && wait_exchange(comm, 1)) return 1;
   if (mpi_all(6)) return 1;
   if (part(4)) return 1;
+  // eles::shock_capture (src/HiFiLES.cpp:214-216) before the new flux-point solution is packed: the filter, then the flux-point
+  // values of the filtered state
+  if (shock && general_shock_capture(eles, neb)) return 1;
   if (mpi_all(0)) return 1;
   return start_exchange(comm, mpi_faces, n_mpi, 0, false);
 }
@@ -662,7 +665,7 @@ int hfx_run_steps_partitioned_blocks(hfx_eles *const *eles, int n_ele_blocks, hf
       if (rk == 0)
         for (int i = 0; i < n_ele_blocks; i++)
           if (eles[i]->les_ready && eles[i]->les.sgs_model >= 2 && hfx_eles_calc_sgs_terms(eles[i])) return 1;
-      if (general_partitioned_stage(eles, n_ele_blocks, int_faces, n_int, mpi_faces, n_mpi, comm, rk, start)) return 1;
+      if (general_partitioned_stage(eles, n_ele_blocks, int_faces, n_int, mpi_faces, n_mpi, comm, rk, start, true)) return 1;
       start = false;
     }
     advance_ramp_counters(int_faces, n_int);

@@ -217,7 +217,6 @@ static void make_plan(hfx_ctx *ctx, const std::vector<DeferCall> &log, DeferPlan
     return;
   }
 
-  if (P.shock && mpi) { P.why = "general fused stage on partitioned blocks: shock capturing runs per method (the flux-point values have left for the neighbours)"; return; }
   {
     std::vector<hfx_inters *> all = P.faces;
     all.insert(all.end(), P.mpi_faces.begin(), P.mpi_faces.end());
@@ -304,7 +303,7 @@ static int run_fused(hfx_ctx *ctx, const DeferPlan &P, int in_step, bool write_d
     if (P.shock && general_shock_capture(P.eles.data(), (int)P.eles.size())) return 1;
     break;
   case 4:
-    if (general_partitioned_stage(P.eles.data(), (int)P.eles.size(), faces, nfb, P.mpi_faces.data(), (int)P.mpi_faces.size(), P.comm, in_step, start))
+    if (general_partitioned_stage(P.eles.data(), (int)P.eles.size(), faces, nfb, P.mpi_faces.data(), (int)P.mpi_faces.size(), P.comm, in_step, start, P.shock))
       return 1;
     break;
   default:

@@ -39,5 +39,5 @@ int partitioned_stage_deferred(hfx_eles *e, hfx_inters *const *int_faces, int n_
                                hfx_comm *comm, int rk, bool start);
 // the general fused stage on partitioned element blocks (comm.hip)
 int general_partitioned_stage(hfx_eles *const *eles, int neb, hfx_inters *const *int_faces, int n_int, hfx_inters *const *mpi_faces,
-                              int n_mpi, hfx_comm *comm, int rk, bool start);
+                              int n_mpi, hfx_comm *comm, int rk, bool start, bool shock);
 } // namespace hfx

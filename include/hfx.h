@@ -447,7 +447,7 @@ int hfx_run_steps_partitioned(hfx_eles *e, hfx_inters *const *int_faces, int n_i
  * by the one-sided kernels, the flux-point solution and each side's projected viscous flux Fn as the two messages.  Fixed time
  * step (dt_type 0) only; three-dimensional blocks as hfx_run_steps_blocks(..., 4) takes them -- an LES closure is evaluated in the
  * flux kernel (its F_sgs . n travels inside Fn: no third message; the SVV closure is refused here), over-integration feeds it,
- * shock capturing on such blocks runs call by call.
+ * shock capturing follows the update before the next solution message is packed.
  * With deferred execution the mirrored CalcResidual of such a mesh runs this stage when its send_* / receive_* name one hfx_comm. */
 int hfx_run_steps_partitioned_blocks(hfx_eles *const *eles, int n_ele_blocks, hfx_inters *const *int_faces, int n_int,
                                      hfx_inters *const *mpi_faces, int n_mpi, hfx_comm *comm, int n_steps);

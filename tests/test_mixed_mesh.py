@@ -471,11 +471,12 @@ def test_general_stage_follows_a_changed_closure():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tet_p2_les_wale", "tet_p3_les_wsm", "pri_p2_les_wale"])
+@pytest.mark.parametrize("name", ["tet_p2_les_wale", "tet_p3_les_wsm", "pri_p2_les_wale", "tet_p3_shock", "tet_p2_overint"])
 def test_simplex_les_on_partitioned_blocks(name):
     """hfx_run_steps_partitioned_blocks with an LES closure: the projected flux a partition face sends already contains F_sgs . n
     (the closure is evaluated in the general stage's flux kernel), so the self-partitioned block -- half of its faces exchanged
-    with itself over RCCL -- equals the genuine reference's undivided run.  (Of the prism box only the triangular faces are
+    with itself over RCCL -- equals the genuine reference's undivided run.  The same with shock capturing (the filter and the
+    flux-point values of the filtered state before the next solution message is packed) and with over-integration.  (Of the prism box only the triangular faces are
     partitioned: two of its quadrilateral faces have a flux point where the x component of the normal is rounding noise, and the
     reference's LDG switch, src/inters.cpp:568-581, is decided there by the LEFT normal's noise on an interior face and by each
     side's own on a partition face -- the undivided and the partitioned reference differ at those two points by construction.)"""
