@@ -374,9 +374,10 @@ __global__ __launch_bounds__(64 * W, 2) void general_flux_kernel(const GenArgs a
     }
   }
   // K padding rows of G (read as zero by the opp_6 / opp_1 / opp_2 tiles)
-  for (int q = tid; q < NF * ND * (KU - nu) * GB; q += T)
+  const int pad_rows = (KU - nu) * GB, pad_div = pad_rows > 0 ? pad_rows : 1; // (no padding rows where n_upts is a multiple of 4)
+  for (int q = tid; q < NF * ND * pad_rows; q += T)
   {
-    const int c = q / ((KU - nu) * GB), p = q - c * (KU - nu) * GB;
+    const int c = q / pad_div, p = q - c * pad_rows;
     G[c * KU * GB + sw(nu + p / GB, p % GB)] = 0.0;
   }
   stamp(1);
