@@ -185,8 +185,9 @@ def general_workload(args):
     fused = 4): the reference's own fixture of a small mesh -- P3 tetrahedra, P3 prisms, or the MIXED channel (prism
     layers on the walls, tetrahedra in the core, isothermal / adiabatic walls) -- with its operators, metrics and face
     tables, tiled `--tiles` times: identical, mutually disconnected copies, i.e. the per-element and per-face work of one
-    large mesh with every array at full size in HBM.  The host mirror has no tetrahedron / prism setup yet, which is why
-    the mesh comes from a fixture."""
+    large mesh with every array at full size in HBM.  The host mirror has the element classes of tetrahedra and prisms but no
+    mesh preprocessor for them (connectivity, face matching: out of scope), which is why the mesh comes from
+    a fixture of the genuine reference."""
     import torch  # noqa: F401  (maps torch's HIP runtime first, see tests/conftest.py)
     import hfx
     import mixed_util as MU
