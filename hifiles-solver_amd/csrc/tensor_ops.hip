@@ -582,19 +582,47 @@ __global__ __launch_bounds__(256) void shock_tensor_kernel(const ShockArgs a)
   const tcptr sW = (tcptr)(uintptr_t)a.W1, sE = (tcptr)(uintptr_t)a.E1;
   const long plane_u = (long)nu * a.n_eles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a thread's sensor weights once, and the sensor field of the NEXT element requested while this one is worked on: an element's
+  // chain was three memory latencies long (field, weights, nothing else to do in between) for a few hundred multiply-adds
+  constexpr int QPT = (nu + 255) / 256;
+  double wn[QPT], wd[QPT], pf[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; i++)
+  {
+    const int q = threadIdx.x + 256 * i, qc = q < nu ? q : nu - 1;
+    wn[i] = a.wnum[qc];
+    wd[i] = a.wden[qc];
+    pf[i] = ((long)blockIdx.x < a.n_eles) ? a.u[qc + (long)nu * blockIdx.x + a.field * plane_u] : 0.0;
+  }
   for (long e = blockIdx.x; e < a.n_eles; e += gridDim.x)
   {
     lds_sync();
-    for (int q = threadIdx.x; q < nu; q += blockDim.x) R0[q] = a.u[q + (long)nu * e + a.field * plane_u];
+#pragma unroll
+    for (int i = 0; i < QPT; i++)
+      if (threadIdx.x + 256 * i < nu) R0[threadIdx.x + 256 * i] = pf[i];
     lds_sync();
+    {
+      const long en = e + gridDim.x < a.n_eles ? e + gridDim.x : e;
+#pragma unroll
+      for (int i = 0; i < QPT; i++)
+      {
+        const int q = threadIdx.x + 256 * i, qc = q < nu ? q : nu - 1;
+        pf[i] = a.u[qc + (long)nu * en + a.field * plane_u];
+      }
+    }
     // modal coefficients of the sensor field (tensor mode order)
     const double *modal = tapply<ND, N, N>(R0, R1, sW, 1);
     double sn = 0.0, sd = 0.0;
-    for (int q = threadIdx.x; q < nu; q += blockDim.x)
+#pragma unroll
+    for (int i = 0; i < QPT; i++)
     {
-      const double m2 = modal[q] * modal[q];
-      sn += m2 * a.wnum[q];
-      sd += a.wden[q] * m2;
+      const int q = threadIdx.x + 256 * i;
+      if (q < nu)
+      {
+        const double m2 = modal[q] * modal[q];
+        sn += m2 * wn[i];
+        sd += wd[i] * m2;
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
