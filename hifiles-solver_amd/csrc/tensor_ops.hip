@@ -586,6 +586,11 @@ __global__ __launch_bounds__(256) void shock_tensor_kernel(const ShockArgs a)
   // chain was three memory latencies long (field, weights, nothing else to do in between) for a few hundred multiply-adds
   constexpr int QPT = (nu + 255) / 256;
   double wn[QPT], wd[QPT], pf[QPT];
+  // the modal transform's 1-D matrix stays in (scalar) registers across the elements: every pass re-read it through the scalar
+  // cache otherwise, N * N doubles behind a wait, three times per element
+  double Wm[N * N];
+#pragma unroll
+  for (int i = 0; i < N * N; i++) Wm[i] = sW[i];
 #pragma unroll
   for (int i = 0; i < QPT; i++)
   {
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(256) void shock_tensor_kernel(const ShockArgs a)
       }
     }
     // modal coefficients of the sensor field (tensor mode order)
-    const double *modal = tapply<ND, N, N>(R0, R1, sW, 1);
+    const double *modal = tapply<ND, N, N>(R0, R1, Wm, 1);
     double sn = 0.0, sd = 0.0;
 #pragma unroll
     for (int i = 0; i < QPT; i++)
