@@ -387,6 +387,64 @@ def test_general_fused_stage_at_bench_size_properties():
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_general_les_stage_at_bench_size_properties():
+    """The mixed channel with the WALE closure at the size of bench.py's `mixed_les_wale` leg (256 tiles here, every tile with its own
+    state): the closure inside the general stage's flux kernel -- whose flux-point part re-reads and completes the projected flux the
+    workgroup stored a phase earlier -- equals the per-method path on every element of every tile after a time step, on thousands of
+    workgroups in flight."""
+    import hfx
+    import hfx_host as H
+    import bench
+    d = dict(np.load(os.path.join(GOLDEN, "mixed_p3_channel.npz")))
+    tiles = 256
+    classes, per, faces, bdy = MU.split(d)
+    factor = 1.0 + 0.02 * (np.arange(tiles) % 7)
+    J = {}
+    for c in classes:
+        sz = [int(v) for v in per[c]["sizes"]]
+        x1 = per[c]["loc_upts"][2, ::(sz[5] + 1) * (sz[5] + 2) // 2] if sz[6] == 3 else None
+        S = H.Simplex(sz[6], sz[5], per[c]["shape"][:, :(4 if sz[6] == 2 else 6), :], viscous=1, loc_1d_upts=x1, SGS_model=1)
+        J[c] = np.asfortranarray(np.concatenate([S.array("Jacobian_fpts")] * tiles, axis=3))
+        S.close()
+
+    def make(ctx):
+        ctx.set_params(hfx.params_from(per[classes[0]]))
+        E, plane = {}, {}
+        for c in classes:
+            sz = [int(v) for v in per[c]["sizes"]]
+            plane[c] = sz[0] * sz[2]
+            big = bench.tile_arrays(per[c], tiles)
+            u = big["u_init"].copy(order="F")
+            u *= np.repeat(factor, sz[0])[None, :, None]
+            E[c] = hfx.Eles(ctx, [sz[0] * tiles] + sz[1:5], big, ele_type=sz[6], order=sz[5])
+            E[c].upload(hfx.DISU_UPTS0, u)
+            E[c].set_les(1, 0.325, 1.0, 0.41, 0.9, J[c])
+        F = [hfx.IntInters(ctx, E[a], E[b], bench.tile_table(L, plane[a], tiles), bench.tile_table(R, plane[b], tiles)) for a, b, L, R in faces]
+        for a, L, ids in bdy:
+            F.append(hfx.BdyInters(ctx, E[a], bench.tile_table(L, plane[a], tiles), np.tile(ids, tiles), hfx.bc_records(d["bc_flags"], d["bc_params"]),
+                                   float(np.ravel(d["bc_R_ref"])[0]), int(np.ravel(d["ramp_counter"])[0])))
+        return E, F
+
+    ctx = hfx.Context(0)
+    Ea, Fa = make(ctx)
+    Eb, Fb = make(ctx)
+    hfx.run_steps_blocks([Ea[c] for c in classes], Fa, 1, fused=4)
+    hfx.run_steps_blocks([Eb[c] for c in classes], Fb, 1, fused=0)
+    for c in classes:
+        ua, ub = Ea[c].download(hfx.DISU_UPTS0), Eb[c].download(hfx.DISU_UPTS0)
+        assert Ea[c].check_nan() == -1
+        assert relerr(ua, ub) < 1e-11, c
+        ne = int(per[c]["sizes"][0])
+        assert relerr(ua[:, ne:2 * ne, :], ua[:, :ne, :]) > 1e-3
+        assert relerr(ua[:, 7 * ne:8 * ne, :], ua[:, :ne, :]) < 1e-13
+    for f in Fa + Fb:
+        f.close()
+    for c in classes:
+        Ea[c].close(); Eb[c].close()
+    ctx.close()
+
+
 # ---- the mixed channel on PARTITIONED element blocks ----------------------------------------------------------------------
 def self_partition(ctx, E, faces):
     """Every second face of every interior block that joins a class to ITSELF becomes a pair of one-sided partition faces whose
